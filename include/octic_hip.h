@@ -1,0 +1,176 @@
+/*
+ * octic_hip.h — C ABI of the MI355X (gfx950) octic-ViT block engine.
+ *
+ * The reference (davnords/octic-vits) is pure Python; its replaceable surface for the hot path
+ * is the set of torch modules in octic_vits/d8_layers.py and the one custom-op boundary
+ * TritonGeluD8Function (octic_vits/d8_gelu.py:456-478).  This header is the boundary a
+ * maintainer binds instead (ctypes stub in INTEGRATION.md): plain pointers, sizes and a HIP
+ * stream — no torch types.  Every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers.  Nothing here allocates, frees or synchronises; work is
+ *    enqueued on `stream` (a hipStream_t passed as void*), so calls are graph-capturable.
+ *  - Return value: 0 on success, a negative OCTIC_E* code on a rejected argument, or the positive
+ *    hipError_t of a failed launch.  octic_strerror() renders either.
+ *  - An octic feature of M token rows and D = 8c channels is a 5-tuple (A1,A2,B1,B2:[M,c];
+ *    E:[M,2,2c]) exactly as in the reference (d8_layers.py:64-81,111-112).  It is passed as an
+ *    octic_view: five base pointers plus five row strides (in elements).  Two layouts matter:
+ *      tuple  : five separate contiguous tensors            ld = {c,c,c,c,4c}
+ *      packed : one [M, 8c] row  [A1|A2|B1|B2|E_row0|E_row1]  ptr[i] = base + i*c (i<4),
+ *               ptr[4] = base + 4c, ld = {8c,...}  — the engine's native HBM layout
+ *               ("(B, tokens, irrep, channel)"): one token = one contiguous row.
+ *    Row r of E for token m starts at ptr[4] + m*ld[4] + r*2c.  E[..,r,0:c] / E[..,r,c:2c] are the
+ *    two E copies (8-tuple entries x(4+r) / x(6+r), d8_utils.py:358-385).
+ *  - c must be a multiple of 8 (16-byte vectors in bf16); every base pointer and row stride
+ *    must keep rows 16-byte aligned.  Violations return OCTIC_EALIGN/OCTIC_ESHAPE — they are never
+ *    silently routed to a slower path.
+ *  - dtype codes: OCTIC_F32 (exact f32 MFMA path, used for the reference's fp32 equivariance
+ *    tolerances) and OCTIC_BF16 (bf16 operands, f32 accumulate — the training path).
+ */
+#ifndef OCTIC_HIP_H
+#define OCTIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCTIC_ABI_VERSION 1
+
+enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
+
+enum {
+  OCTIC_OK = 0,
+  OCTIC_ESHAPE = -1,   /* c not a multiple of 8, non-positive sizes, heads not dividing c ... */
+  OCTIC_EALIGN = -2,   /* pointer or row stride breaks 16-byte row alignment */
+  OCTIC_EDTYPE = -3,   /* unsupported dtype combination */
+  OCTIC_ENULL = -4,    /* required pointer is NULL */
+  OCTIC_EWORKSPACE = -5 /* workspace too small (see the *_workspace_bytes query) */
+};
+
+typedef struct {
+  void* ptr[5];   /* A1, A2, B1, B2, E */
+  int64_t ld[5];  /* row stride in ELEMENTS (E: stride between tokens, the 2 rows are adjacent) */
+} octic_view;
+
+int octic_abi_version(void);
+const char* octic_strerror(int code);
+
+/* ---- D8 GELU -------------------------------------------------------------------------------
+ * Replaces d8_gelu_fwd / d8_gelu_bwd (Triton, d8_gelu.py:104-196, 210-331, 333-453) and the
+ * torch twin GeluD8 (d8_layers.py:98-102): per (row, channel j) gather the 8 isotypic
+ * components, iso->regular butterfly, exact-erf GELU, regular->iso.  Arithmetic is f32 in
+ * registers for both dtypes (the reference's bf16 path does the butterflies in bf16,
+ * d8_gelu.py:11-26; f32 is strictly more accurate).  y may alias x.                       */
+int octic_gelu_d8_fwd(const octic_view* x, const octic_view* y, int64_t M, int c, int dtype, void* stream);
+/* gin = F( gelu'(F^-1 x) * F^-1 g )   (d8_gelu.py:283-321) */
+int octic_gelu_d8_bwd(const octic_view* g, const octic_view* x, const octic_view* gin, int64_t M, int c,
+                      int dtype, void* stream);
+
+/* ---- LayerNormD8 (+AffineD8) -----------------------------------------------------------------
+ * Replaces LayerNormD8.forward (d8_layers.py:166-186): per-segment mean removal, one shared
+ * std = (sqrt2/4)*sqrt(sum_1D var + mean_rows var_E + eps), then alpha (and beta on A1).
+ * x is f32 (the residual stream); y is out_dtype.  alpha[i] may be NULL as a group (=> no affine,
+ * elementwise_affine=False); beta may be NULL.  stats (optional, [M,8] f32: 6 means, rstd, 0) is
+ * what the backward needs.                                                                     */
+int octic_layernorm_d8_fwd(const octic_view* x, const octic_view* y, const float* const alpha[5],
+                           const float* beta, float* stats, int64_t M, int c, float eps, int out_dtype,
+                           void* stream);
+/* dx = (dres ? dres : 0) + LN'(g).  g is g_dtype, x/dx/dres are f32.  Column sums for the affine
+ * parameters are written as per-block partial slabs into `partials` ([nblk, 2, 8c] f32,
+ * nblk = octic_layernorm_d8_bwd_blocks(M)); reduce them with octic_layernorm_d8_bwd_finish.     */
+int octic_layernorm_d8_bwd_blocks(int64_t M);
+int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float* stats,
+                           const float* const alpha[5], const octic_view* dres, const octic_view* dx,
+                           float* partials, int64_t M, int c, int g_dtype, void* stream);
+int octic_layernorm_d8_bwd_finish(const float* partials, int nblk, int c, float* const dalpha[5], float* dbeta,
+                                  void* stream);
+
+/* ---- LinearD8 (irrep-blocked GEMM on MFMA) ----------------------------------------------------
+ * Replaces LinearD8.forward (d8_layers.py:124-127) = five nn.Linear calls, as ONE launch:
+ *     y_g[m, n] = resid_g[m, n] + rs[token(m)/rows_per_sample] * cs_g[n] * ( sum_k x_g[m,k] W_g[n,k] + bias[n] (g==A1) )
+ * W_g: [cout_g, cin_g] row-major in `dtype` (nn.Linear layout), g = A1,A2,B1,B2 (c wide) and E
+ * (2c wide, shared by both E rows, d8_layers.py:127).  resid (out_dtype view), rs (f32 per
+ * sample: drop-path mask/keep-prob, d8_layers.py:256-270), cs (f32 per channel: AffineD8 /
+ * LayerScaleD8 gamma, d8_layers.py:147-158,205-212) and bias (f32 [cout]) are each optional
+ * (NULL) — together they fuse `x + drop_path(gamma * linear(h))` (d8_layers.py:704-707) into
+ * the GEMM epilogue.  The same entry point computes the input gradient when given the
+ * transposed weights (dX = dY W  ==  linear with W^T).  x and W are `dtype`; y/resid are
+ * out_dtype.  Supported (dtype,out_dtype): (F32,F32), (BF16,BF16), (BF16,F32).             */
+int octic_linear_d8_fwd(const octic_view* x, const void* const w[5], const float* bias, const octic_view* y,
+                        const octic_view* resid, const float* rs, int64_t rows_per_sample,
+                        const float* const cs[5], int64_t M, int cin, int cout, int dtype, int out_dtype,
+                        void* stream);
+
+/* Weight gradient  G_g[n,k] = sum_rows dy_g[row,n] x_g[row,k]  (E: both rows).  Reduction over the
+ * M (2M) rows is split over `splits` row ranges whose f32 partial slabs go to `workspace`
+ * (octic_linear_d8_wgrad_workspace_bytes).  The finish kernel sums the slabs in a fixed order
+ * (bitwise reproducible) and applies the layer-scale chain rule when cs != NULL:
+ *     dW_g[n,k] = cs_g[n] * G_g[n,k]
+ *     dcs_g[n]  = sum_k W_g[n,k] G_g[n,k]  + (g==A1 ? bias[n]*dysum[n] : 0)
+ *     dbias[n]  = cs_A1[n] * dysum[n]          with dysum = column sums of dy_A1
+ * which is the gradient of  y = resid + rs*cs*(xW^T+b)  w.r.t. W, cs, b when dy = rs*dL/dy.
+ * w32 (f32 master weights) and bias are only read when cs != NULL.                            */
+int64_t octic_linear_d8_wgrad_workspace_bytes(int cin, int cout, int splits);
+int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout);
+int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, int cin, int cout, int dtype,
+                          float* workspace, int splits, void* stream);
+int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, int cout,
+                                 const float* const w32[5], const float* const cs[5], const float* bias,
+                                 const float* dysum, float* const dw[5], float* const dcs[5], float* dbias,
+                                 void* stream);
+
+/* Column sums of the A1 block of dy (bias gradient, bias exists on A1 only: d8_layers.py:117-122).
+ * out[n] = sum_m dy_A1[m,n]; `partials` holds octic_colsum_blocks(M) * c floats.               */
+int octic_colsum_blocks(int64_t M);
+int octic_colsum_a1(const octic_view* dy, int64_t M, int c, int dtype, float* partials, float* out, void* stream);
+
+/* y = rs[token/rows_per_sample] * x, converted f32 -> out_dtype (cotangent entering a fused
+ * residual branch: dL/d(branch) = drop-path mask * dL/dx_out).  rs may be NULL (pure cast).     */
+int octic_cast_rowscale(const octic_view* x, const octic_view* y, const float* rs, int64_t rows_per_sample,
+                        int64_t M, int c, int out_dtype, void* stream);
+
+/* ---- attention head packing (d8_layers.py:631-643, 650-656) ------------------------------------
+ * pack:  qkv view (3*8c channels: per irrep [q|k|v] thirds) -> q,k,v  [B,H,T,8w], w = c/H, per-head
+ *        vector [A1 w|A2 w|B1 w|B2 w|E_row0 2w|E_row1 2w].  qkv_out = 3 consecutive [B,H,T,8w] arrays.
+ * unpack: o [B,H,T,8w] -> view with 8c channels.  Each is the other's adjoint (n_s = 3 / 1).    */
+int octic_attn_pack_heads(const octic_view* qkv, void* qkv_out, int64_t B, int64_t T, int H, int c, int n_s,
+                          int dtype, void* stream);
+int octic_attn_unpack_heads(const void* o, const octic_view* y, int64_t B, int64_t T, int H, int c, int n_s,
+                            int dtype, void* stream);
+
+/* ---- octic -> standard hand-off (model.py:196-200) ---------------------------------------------
+ * hybrid:    dense[m, :] = cat(A1,A2,B1,B2, E[0,:c], E[1,:c], E[0,c:], E[1,c:])   (8-tuple order,
+ *            d8_utils.py:370-385; the following standard blocks' weights depend on it)
+ * invariant: dense[m, :] = cat(A1,|A2|,|B1|,|B2|, sqrt(E[0]^2+E[1]^2))  [6c]  (PowerSpectrumInvariant,
+ *            d8_invariantization.py:49-64)
+ * x is f32 (residual stream); dense is out_dtype.  The *_bwd forms take dense f32 gradients.    */
+int octic_handoff_cat_fwd(const octic_view* x, void* dense, int64_t M, int c, int out_dtype, void* stream);
+int octic_handoff_cat_bwd(const float* ddense, const octic_view* dx, int64_t M, int c, void* stream);
+int octic_power_spectrum_fwd(const octic_view* x, void* dense, int64_t M, int c, int out_dtype, void* stream);
+int octic_power_spectrum_bwd(const float* ddense, const octic_view* x, const octic_view* dx, int64_t M, int c,
+                             void* stream);
+
+/* ---- lift patch embedding (d8_layers.py:284-486, model.py:172-181) -----------------------------
+ * im2col: img [B,Cin,Himg,Wimg] f32 -> patches [B*G*G, Kpad] `dtype`, column = (ch, py, px), zero
+ * padded to Kpad (a multiple of 8 >= Cin*p*p).  The conv with stride = kernel is then one GEMM
+ * against the symmetry-expanded weights; use octic_lift_gemm: out_packed[b, tok0 + n, :] =
+ * patches[b*G*G + n, :] W^T + bias + pos[n, :]  with W:[8c, Kpad] rows in packed channel order and
+ * pos:[G*G, 8c] f32 (unfolded positional embedding, may be NULL); rows [0,tok0) of every sample
+ * are left untouched (cls token).  out is f32 [B, tok0+G*G, 8c].                               */
+int octic_im2col_patches(const float* img, void* patches, int64_t B, int Cin, int Himg, int Wimg, int p,
+                         int Kpad, int dtype, void* stream);
+int octic_lift_gemm(const void* patches, const void* w, const float* bias, const float* pos, float* out,
+                    int64_t B, int64_t n_patches, int tok0, int Kpad, int D, int dtype, void* stream);
+/* dW[n,k] = sum_rows dout[row, n] patches[row, k]  with dout the [rows, D] cotangent of the patch
+ * tokens in `dtype` (cls rows removed by the caller); f32 result, split-row slabs like wgrad.
+ * (bias here is a full [D] vector, zero outside the A1 block.)                                   */
+int64_t octic_lift_wgrad_workspace_bytes(int Kpad, int D, int splits);
+int octic_lift_wgrad(const void* patches, const void* dout, float* dw, float* workspace, int splits, int64_t rows,
+                     int Kpad, int D, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTIC_HIP_H */

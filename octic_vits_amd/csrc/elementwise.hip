@@ -1,0 +1,513 @@
+// HBM-bound elementwise / permutation kernels of the octic block engine (gfx950).
+// All of them move 16 bytes per lane per access (8 bf16 or 4+4 f32) over the token-row layout;
+// arithmetic is f32 in registers.  Roofline: HBM (bytes moved / 8 TB/s); see DESIGN.md.
+#include "octic_common.hpp"
+
+namespace octic {
+
+template <typename T>
+__device__ inline void load8(const T* p, float v[8]);
+template <>
+__device__ inline void load8<float>(const float* p, float v[8]) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <>
+__device__ inline void load8<bf16>(const bf16* p, float v[8]) {
+  bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <typename T>
+__device__ inline void store8(T* p, const float v[8]);
+template <>
+__device__ inline void store8<float>(float* p, const float v[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  *(f32x4*)p = a;
+  *(f32x4*)(p + 4) = b;
+}
+template <>
+__device__ inline void store8<bf16>(bf16* p, const float v[8]) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+  *(bf16x8*)p = a;
+}
+
+// Offsets (in elements, relative to the token row of each tensor) of the 8 isotypic components of
+// hidden channel j: x0..x3 in A1..B2 at j; x4 = E[0,j], x5 = E[1,j], x6 = E[0,c+j], x7 = E[1,c+j].
+template <typename T>
+__device__ inline void comp_ptrs(const View& v, int64_t m, int j, int c, T* p[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = (T*)v.p[i] + m * v.ld[i] + j;
+  T* e = (T*)v.p[4] + m * v.ld[4] + j;
+  p[4] = e; p[5] = e + 2 * c; p[6] = e + c; p[7] = e + 3 * c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(View x, View y, int64_t M, int c) {
+  const int c8 = c >> 3;
+  const int64_t total = M * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / c8;
+    const int j = (int)(idx - m * c8) << 3;
+    T *px[8], *py[8];
+    comp_ptrs<T>(x, m, j, c, px);
+    comp_ptrs<T>(y, m, j, c, py);
+    float a[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) load8<T>(px[i], a[i]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v[8], r[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = a[i][e];
+      iso_to_reg(v, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = gelu_exact(kSqrt2Over4 * r[i]);
+      reg_to_iso(r, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i][e] = kSqrt2Over4 * v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) store8<T>(py[i], a[i]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(View g, View x, View gin, int64_t M, int c) {
+  const int c8 = c >> 3;
+  const int64_t total = M * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / c8;
+    const int j = (int)(idx - m * c8) << 3;
+    T *px[8], *pg[8], *po[8];
+    comp_ptrs<T>(x, m, j, c, px);
+    comp_ptrs<T>(g, m, j, c, pg);
+    comp_ptrs<T>(gin, m, j, c, po);
+    float a[8][8], b[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      load8<T>(px[i], a[i]);
+      load8<T>(pg[i], b[i]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v[8], r[8], gv[8], gr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = a[i][e];
+        gv[i] = b[i][e];
+      }
+      iso_to_reg(v, r);     // the transform is orthogonal: its transpose is its inverse, so the
+      iso_to_reg(gv, gr);   // cotangent goes through the same iso->regular map (d8_gelu.py:284-294)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gr[i] = (kSqrt2Over4 * gr[i]) * gelu_grad(kSqrt2Over4 * r[i]);
+      reg_to_iso(gr, gv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[i][e] = kSqrt2Over4 * gv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) store8<T>(po[i], b[i]);
+  }
+}
+
+// y = rs * x  (f32 -> TOUT), 8 logical packed columns per thread.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void cast_rowscale_kernel(View x, View y, const float* rs, int64_t rps, int64_t M,
+                                                            int c) {
+  const int64_t total = M * c;  // 8c/8 chunks per row
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / c;
+    const int e = (int)(idx - m * c) << 3;
+    float v[8];
+    load8<float>(view_ptr<float>(x, m, e, c), v);
+    if (rs) {
+      const float s = rs[m / rps];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= s;
+    }
+    store8<TOUT>(view_ptr<TOUT>(y, m, e, c), v);
+  }
+}
+
+// Head packing.  DIR 0: view -> heads, DIR 1: heads -> view.  V consecutive elements per thread
+// (V divides w).  heads layout [n_s][B][H][T][8w]; the view has n_s*8c channels.
+template <typename T, int V, int DIR>
+__global__ __launch_bounds__(256) void heads_permute_kernel(View v, T* heads, int64_t B, int64_t T_, int H, int c,
+                                                            int n_s) {
+  const int w = c / H;
+  const int hdv = (8 * w) / V;
+  const int64_t total = (int64_t)n_s * B * H * T_ * hdv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    int64_t r = idx;
+    const int ev = (int)(r % hdv); r /= hdv;
+    const int64_t t = r % T_; r /= T_;
+    const int h = (int)(r % H); r /= H;
+    const int64_t b = r % B; r /= B;
+    const int s = (int)r;
+    const int e = ev * V;
+    const int64_t m = b * T_ + t;
+    T* q;
+    if (e < 4 * w) {
+      const int g = e / w, jj = e - g * w;
+      q = (T*)v.p[g] + m * v.ld[g] + s * c + h * w + jj;
+    } else {
+      const int rr = (e - 4 * w) / (2 * w), jj = (e - 4 * w) - rr * 2 * w;
+      q = (T*)v.p[4] + m * v.ld[4] + rr * (2 * n_s * c) + s * 2 * c + h * 2 * w + jj;
+    }
+    T* hp = heads + idx * V;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      if (DIR == 0) hp[i] = q[i];
+      else q[i] = hp[i];
+    }
+  }
+}
+
+// dense (8-tuple order) <-> view.  DIR 0: view(f32) -> dense(TOUT); DIR 1: dense(f32) -> view(f32).
+template <typename TOUT, int DIR>
+__global__ __launch_bounds__(256) void handoff_cat_kernel(View x, TOUT* dense, int64_t M, int c) {
+  const int c8 = c >> 3;
+  const int64_t total = M * c;  // 8c/8 chunks per row
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / c;
+    const int q = (int)(idx - m * c);
+    const int blk = q / c8, off = (q - blk * c8) << 3;
+    float* src;
+    if (blk < 4) src = (float*)x.p[blk] + m * x.ld[blk] + off;
+    else {
+      // 8-tuple entries 4..7 = E[0,:c], E[1,:c], E[0,c:], E[1,c:]
+      const int row = (blk - 4) & 1, half = (blk - 4) >> 1;
+      src = (float*)x.p[4] + m * x.ld[4] + row * 2 * c + half * c + off;
+    }
+    TOUT* d = dense + m * (int64_t)(8 * c) + (int64_t)q * 8;
+    float v[8];
+    if (DIR == 0) {
+      load8<float>(src, v);
+      store8<TOUT>(d, v);
+    } else {
+      load8<TOUT>(d, v);
+      store8<float>(src, v);
+    }
+  }
+}
+
+template <typename TOUT>
+__global__ __launch_bounds__(256) void power_spectrum_fwd_kernel(View x, TOUT* dense, int64_t M, int c) {
+  const int c8 = c >> 3;
+  const int64_t total = M * (6 * c8);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / (6 * c8);
+    const int q = (int)(idx - m * (6 * c8));
+    float v[8];
+    if (q < 4 * c8) {
+      const int g = q / c8, off = (q - g * c8) << 3;
+      load8<float>((float*)x.p[g] + m * x.ld[g] + off, v);
+      if (g > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fabsf(v[i]);
+      }
+    } else {
+      const int off = (q - 4 * c8) << 3;
+      float a[8], b[8];
+      const float* e = (float*)x.p[4] + m * x.ld[4] + off;
+      load8<float>(e, a);
+      load8<float>(e + 2 * c, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = sqrtf(a[i] * a[i] + b[i] * b[i]);
+    }
+    store8<TOUT>(dense + m * (int64_t)(6 * c) + (int64_t)q * 8, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void power_spectrum_bwd_kernel(const float* dd, View x, View dx, int64_t M, int c) {
+  const int c8 = c >> 3;
+  const int64_t total = M * (6 * c8);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / (6 * c8);
+    const int q = (int)(idx - m * (6 * c8));
+    float g[8];
+    load8<float>(dd + m * (int64_t)(6 * c) + (int64_t)q * 8, g);
+    if (q < 4 * c8) {
+      const int gi = q / c8, off = (q - gi * c8) << 3;
+      if (gi > 0) {
+        float v[8];
+        load8<float>((float*)x.p[gi] + m * x.ld[gi] + off, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = v[i] > 0.f ? g[i] : (v[i] < 0.f ? -g[i] : 0.f);
+      }
+      store8<float>((float*)dx.p[gi] + m * dx.ld[gi] + off, g);
+    } else {
+      const int off = (q - 4 * c8) << 3;
+      float a[8], b[8], da[8], db[8];
+      const float* e = (float*)x.p[4] + m * x.ld[4] + off;
+      load8<float>(e, a);
+      load8<float>(e + 2 * c, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float n = sqrtf(a[i] * a[i] + b[i] * b[i]);
+        const float s = n > 0.f ? g[i] / n : 0.f;
+        da[i] = a[i] * s;
+        db[i] = b[i] * s;
+      }
+      float* de = (float*)dx.p[4] + m * dx.ld[4] + off;
+      store8<float>(de, da);
+      store8<float>(de + 2 * c, db);
+    }
+  }
+}
+
+// img [B,Cin,H,W] f32 -> patches [B*G*G, Kpad] T ; column = (ch, py, px); zero padded.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* img, T* patches, int64_t B, int Cin, int Himg,
+                                                     int Wimg, int p, int Kpad) {
+  const int Gh = Himg / p, Gw = Wimg / p, K = Cin * p * p, k8 = Kpad >> 3;
+  const int64_t total = B * Gh * Gw * k8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / k8;
+    const int kc = (int)(idx - row * k8) << 3;
+    const int64_t b = row / (Gh * Gw);
+    const int n = (int)(row - b * (Gh * Gw));
+    const int gy = n / Gw, gx = n - gy * Gw;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = kc + i;
+      float val = 0.f;
+      if (k < K) {
+        const int ch = k / (p * p), rem = k - ch * p * p, py = rem / p, px = rem - py * p;
+        val = img[((b * Cin + ch) * Himg + (gy * p + py)) * (int64_t)Wimg + gx * p + px];
+      }
+      v[i] = val;
+    }
+    store8<T>(patches + row * (int64_t)Kpad + kc, v);
+  }
+}
+
+constexpr int kColsumRows = 512;  // rows per block
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* a, int64_t ld, int64_t M, int c, float* partials) {
+  // block b sums rows [b*kColsumRows, ...) of the [M, c] matrix; thread = (row lane, 8-column chunk)
+  __shared__ float red[256 * 8];
+  const int c8 = c >> 3;
+  const int lanes = 256 / c8 > 0 ? 256 / c8 : 1;
+  const int rl = threadIdx.x / c8, cc = threadIdx.x - rl * c8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
+  const int64_t r1 = r0 + kColsumRows < M ? r0 + kColsumRows : M;
+  if (rl < lanes) {
+    for (int64_t m = r0 + rl; m < r1; m += lanes) {
+      float v[8];
+      load8<T>(a + m * ld + cc * 8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+  __syncthreads();
+  for (int col = threadIdx.x; col < c; col += 256) {
+    const int ch = col >> 3, i = col & 7;
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[(l * c8 + ch) * 8 + i];
+    partials[(int64_t)blockIdx.x * c + col] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* partials, int nblk, int c, float* out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partials[(int64_t)b * c + col];
+  out[col] = s;
+}
+
+inline int grid_for(int64_t total) {
+  int64_t g = (total + 255) / 256;
+  const int64_t cap = 256 * 16;  // 16 blocks per CU, grid-stride beyond
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <typename T, int DIR>
+static int heads_dispatch(const octic_view* v, T* heads, int64_t B, int64_t T_, int H, int c, int n_s, void* stream) {
+  View vv = make_view<void>(v);
+  const int w = c / H;
+  const int V = (w % 8 == 0) ? 8 : (w % 4 == 0) ? 4 : (w % 2 == 0) ? 2 : 1;
+  const int64_t total = (int64_t)n_s * B * H * T_ * (8 * w / V);
+  const int grid = grid_for(total);
+  hipStream_t s = (hipStream_t)stream;
+  switch (V) {
+    case 8: heads_permute_kernel<T, 8, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
+    case 4: heads_permute_kernel<T, 4, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
+    case 2: heads_permute_kernel<T, 2, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
+    default: heads_permute_kernel<T, 1, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
+  }
+  return launch_status();
+}
+
+static int heads_check(const octic_view* v, const void* heads, int64_t B, int64_t T_, int H, int c, int n_s, int dtype) {
+  int e;
+  if ((e = check_c(c))) return e;
+  if (B <= 0 || T_ <= 0 || H <= 0 || (c % H) != 0 || (n_s != 1 && n_s != 3)) return OCTIC_ESHAPE;
+  if ((e = check_view(v, n_s * c, dtype))) return e;
+  if (!heads) return OCTIC_ENULL;
+  if (dtype != OCTIC_F32 && dtype != OCTIC_BF16) return OCTIC_EDTYPE;
+  return OCTIC_OK;
+}
+
+}  // namespace octic
+
+using namespace octic;
+
+extern "C" {
+
+int octic_abi_version(void) { return OCTIC_ABI_VERSION; }
+
+const char* octic_strerror(int code) {
+  switch (code) {
+    case OCTIC_OK: return "ok";
+    case OCTIC_ESHAPE: return "octic: bad shape (c must be a positive multiple of 8; sizes positive; heads must divide c)";
+    case OCTIC_EALIGN: return "octic: pointer or row stride breaks 16-byte row alignment";
+    case OCTIC_EDTYPE: return "octic: unsupported dtype combination";
+    case OCTIC_ENULL: return "octic: required pointer is NULL";
+    case OCTIC_EWORKSPACE: return "octic: workspace too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "octic: unknown error";
+  }
+}
+
+int octic_gelu_d8_fwd(const octic_view* x, const octic_view* y, int64_t M, int c, int dtype, void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(x, c, dtype)) || (e = check_view(y, c, dtype))) return e;
+  if (M <= 0) return OCTIC_ESHAPE;
+  View vx = make_view<void>(x), vy = make_view<void>(y);
+  const int grid = grid_for(M * (c / 8));
+  if (dtype == OCTIC_F32) gelu_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(vx, vy, M, c);
+  else if (dtype == OCTIC_BF16) gelu_fwd_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(vx, vy, M, c);
+  else return OCTIC_EDTYPE;
+  return launch_status();
+}
+
+int octic_gelu_d8_bwd(const octic_view* g, const octic_view* x, const octic_view* gin, int64_t M, int c, int dtype,
+                      void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(g, c, dtype)) || (e = check_view(x, c, dtype)) ||
+      (e = check_view(gin, c, dtype)))
+    return e;
+  if (M <= 0) return OCTIC_ESHAPE;
+  View vg = make_view<void>(g), vx = make_view<void>(x), vo = make_view<void>(gin);
+  const int grid = grid_for(M * (c / 8));
+  if (dtype == OCTIC_F32) gelu_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(vg, vx, vo, M, c);
+  else if (dtype == OCTIC_BF16) gelu_bwd_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(vg, vx, vo, M, c);
+  else return OCTIC_EDTYPE;
+  return launch_status();
+}
+
+int octic_cast_rowscale(const octic_view* x, const octic_view* y, const float* rs, int64_t rows_per_sample, int64_t M,
+                        int c, int out_dtype, void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(x, c, OCTIC_F32)) || (e = check_view(y, c, out_dtype))) return e;
+  if (M <= 0 || (rs && rows_per_sample <= 0)) return OCTIC_ESHAPE;
+  View vx = make_view<void>(x), vy = make_view<void>(y);
+  const int grid = grid_for(M * c);
+  if (out_dtype == OCTIC_F32)
+    cast_rowscale_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(vx, vy, rs, rows_per_sample, M, c);
+  else if (out_dtype == OCTIC_BF16)
+    cast_rowscale_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(vx, vy, rs, rows_per_sample, M, c);
+  else return OCTIC_EDTYPE;
+  return launch_status();
+}
+
+int octic_attn_pack_heads(const octic_view* qkv, void* out, int64_t B, int64_t T_, int H, int c, int n_s, int dtype,
+                          void* stream) {
+  int e = heads_check(qkv, out, B, T_, H, c, n_s, dtype);
+  if (e) return e;
+  return dtype == OCTIC_F32 ? heads_dispatch<float, 0>(qkv, (float*)out, B, T_, H, c, n_s, stream)
+                            : heads_dispatch<bf16, 0>(qkv, (bf16*)out, B, T_, H, c, n_s, stream);
+}
+
+int octic_attn_unpack_heads(const void* o, const octic_view* y, int64_t B, int64_t T_, int H, int c, int n_s, int dtype,
+                            void* stream) {
+  int e = heads_check(y, o, B, T_, H, c, n_s, dtype);
+  if (e) return e;
+  return dtype == OCTIC_F32 ? heads_dispatch<float, 1>(y, (float*)o, B, T_, H, c, n_s, stream)
+                            : heads_dispatch<bf16, 1>(y, (bf16*)o, B, T_, H, c, n_s, stream);
+}
+
+int octic_handoff_cat_fwd(const octic_view* x, void* dense, int64_t M, int c, int out_dtype, void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(x, c, OCTIC_F32))) return e;
+  if (!dense) return OCTIC_ENULL;
+  if (M <= 0) return OCTIC_ESHAPE;
+  View vx = make_view<void>(x);
+  const int grid = grid_for(M * c);
+  if (out_dtype == OCTIC_F32) handoff_cat_kernel<float, 0><<<grid, 256, 0, (hipStream_t)stream>>>(vx, (float*)dense, M, c);
+  else if (out_dtype == OCTIC_BF16) handoff_cat_kernel<bf16, 0><<<grid, 256, 0, (hipStream_t)stream>>>(vx, (bf16*)dense, M, c);
+  else return OCTIC_EDTYPE;
+  return launch_status();
+}
+
+int octic_handoff_cat_bwd(const float* ddense, const octic_view* dx, int64_t M, int c, void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(dx, c, OCTIC_F32))) return e;
+  if (!ddense) return OCTIC_ENULL;
+  if (M <= 0) return OCTIC_ESHAPE;
+  View vx = make_view<void>(dx);
+  handoff_cat_kernel<float, 1><<<grid_for(M * c), 256, 0, (hipStream_t)stream>>>(vx, (float*)ddense, M, c);
+  return launch_status();
+}
+
+int octic_power_spectrum_fwd(const octic_view* x, void* dense, int64_t M, int c, int out_dtype, void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(x, c, OCTIC_F32))) return e;
+  if (!dense) return OCTIC_ENULL;
+  if (M <= 0) return OCTIC_ESHAPE;
+  View vx = make_view<void>(x);
+  const int grid = grid_for(M * 6 * (c / 8));
+  if (out_dtype == OCTIC_F32) power_spectrum_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(vx, (float*)dense, M, c);
+  else if (out_dtype == OCTIC_BF16) power_spectrum_fwd_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(vx, (bf16*)dense, M, c);
+  else return OCTIC_EDTYPE;
+  return launch_status();
+}
+
+int octic_power_spectrum_bwd(const float* ddense, const octic_view* x, const octic_view* dx, int64_t M, int c,
+                             void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(x, c, OCTIC_F32)) || (e = check_view(dx, c, OCTIC_F32))) return e;
+  if (!ddense) return OCTIC_ENULL;
+  if (M <= 0) return OCTIC_ESHAPE;
+  View vx = make_view<void>(x), vd = make_view<void>(dx);
+  power_spectrum_bwd_kernel<<<grid_for(M * 6 * (c / 8)), 256, 0, (hipStream_t)stream>>>(ddense, vx, vd, M, c);
+  return launch_status();
+}
+
+int octic_im2col_patches(const float* img, void* patches, int64_t B, int Cin, int Himg, int Wimg, int p, int Kpad,
+                         int dtype, void* stream) {
+  if (!img || !patches) return OCTIC_ENULL;
+  if (B <= 0 || Cin <= 0 || p <= 0 || Himg % p || Wimg % p || Kpad % 8 || Kpad < Cin * p * p) return OCTIC_ESHAPE;
+  const int64_t total = B * (Himg / p) * (Wimg / p) * (Kpad / 8);
+  const int grid = grid_for(total);
+  if (dtype == OCTIC_F32) im2col_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(img, (float*)patches, B, Cin, Himg, Wimg, p, Kpad);
+  else if (dtype == OCTIC_BF16) im2col_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(img, (bf16*)patches, B, Cin, Himg, Wimg, p, Kpad);
+  else return OCTIC_EDTYPE;
+  return launch_status();
+}
+
+int octic_colsum_blocks(int64_t M) { return (int)((M + kColsumRows - 1) / kColsumRows); }
+
+int octic_colsum_a1(const octic_view* dy, int64_t M, int c, int dtype, float* partials, float* out, void* stream) {
+  int e;
+  if ((e = check_c(c)) || (e = check_view(dy, c, dtype))) return e;
+  if (!partials || !out) return OCTIC_ENULL;
+  if (M <= 0 || c > 2048) return OCTIC_ESHAPE;
+  const int nblk = octic_colsum_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OCTIC_F32) colsum_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)dy->ptr[0], dy->ld[0], M, c, partials);
+  else if (dtype == OCTIC_BF16) colsum_partial_kernel<bf16><<<nblk, 256, 0, s>>>((const bf16*)dy->ptr[0], dy->ld[0], M, c, partials);
+  else return OCTIC_EDTYPE;
+  colsum_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(partials, nblk, c, out);
+  return launch_status();
+}
+
+}  // extern "C"

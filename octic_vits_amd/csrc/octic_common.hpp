@@ -1,0 +1,102 @@
+// Shared device/host helpers for the gfx950 octic engine.  CDNA4 only (wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/octic_hip.h"
+
+namespace octic {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr float kSqrt2Over4 = 0.35355339059327376220f;
+constexpr float kSqrt1Over2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+
+// A 5-tuple view with compile-time-free helpers.  `c` is the width of a one-dimensional irrep.
+struct View {
+  char* p[5];
+  int64_t ld[5];
+};
+
+template <typename T>
+__host__ __device__ inline View make_view(const octic_view* v) {
+  View r;
+  for (int i = 0; i < 5; ++i) {
+    r.p[i] = (char*)v->ptr[i];
+    r.ld[i] = v->ld[i];
+  }
+  return r;
+}
+
+// Element pointer of logical packed column `e` (0 <= e < 8c, order A1|A2|B1|B2|E0|E1) of token m.
+template <typename T>
+__device__ inline T* view_ptr(const View& v, int64_t m, int e, int c) {
+  if (e < 4 * c) {
+    int g = e / c;
+    return (T*)v.p[g] + m * v.ld[g] + (e - g * c);
+  }
+  return (T*)v.p[4] + m * v.ld[4] + (e - 4 * c);
+}
+
+__device__ inline float bf2f(bf16 x) { return (float)x; }
+__device__ inline bf16 f2bf(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+
+// 8-point D8 Fourier butterflies (reference d8_utils.py:276-344).  Unscaled; callers
+// multiply by (sqrt2/4) once.
+__device__ inline void iso_to_reg(const float x[8], float r[8]) {
+  float a = x[0] + x[1], b = x[0] - x[1], c = x[2] + x[3], d = x[2] - x[3];
+  float e = x[4] + x[5], f = x[4] - x[5], g = x[6] + x[7], h = x[6] - x[7];
+  float apc = a + c, amc = a - c, bpd = b + d, bmd = b - d;
+  float eph = e + h, emh = e - h, fpg = f + g, fmg = f - g;
+  r[0] = apc + eph; r[1] = amc + fmg; r[2] = apc - eph; r[3] = amc - fmg;
+  r[4] = bpd - fpg; r[5] = bmd - emh; r[6] = bpd + fpg; r[7] = bmd + emh;
+}
+__device__ inline void reg_to_iso(const float x[8], float r[8]) {
+  float a = x[0] + x[1], b = x[0] - x[1], c = x[2] + x[3], d = x[2] - x[3];
+  float e = x[4] + x[5], f = x[4] - x[5], g = x[6] + x[7], h = x[6] - x[7];
+  float apc = a + c, cma = c - a, bpd = b + d, bmd = b - d;
+  float epg = e + g, gme = g - e, fph = f + h, fmh = f - h;
+  r[0] = apc + epg; r[1] = apc - epg; r[2] = bpd + fph; r[3] = bpd - fph;
+  r[4] = gme - cma; r[5] = bmd + fmh; r[6] = bmd - fmh; r[7] = gme + cma;
+}
+
+__device__ inline float gelu_exact(float r) { return 0.5f * r * (1.0f + erff(r * kSqrt1Over2)); }
+__device__ inline float gelu_grad(float r) {
+  return 0.5f * (1.0f + erff(r * kSqrt1Over2)) + r * kInvSqrt2Pi * __expf(-0.5f * r * r);
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- host-side argument checks -------------------------------------------------------------
+inline int elem_size(int dtype) { return dtype == OCTIC_BF16 ? 2 : 4; }
+
+inline int check_view(const octic_view* v, int c, int dtype) {
+  if (!v) return OCTIC_ENULL;
+  const int es = elem_size(dtype);
+  for (int i = 0; i < 5; ++i) {
+    if (!v->ptr[i]) return OCTIC_ENULL;
+    if (((uintptr_t)v->ptr[i]) & 15) return OCTIC_EALIGN;
+    if ((v->ld[i] * es) & 15) return OCTIC_EALIGN;
+    if (v->ld[i] < (i < 4 ? c : 4 * c)) return OCTIC_ESHAPE;
+  }
+  return OCTIC_OK;
+}
+
+inline int check_c(int c) { return (c > 0 && (c % 8) == 0) ? OCTIC_OK : OCTIC_ESHAPE; }
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? OCTIC_OK : (int)e;
+}
+
+}  // namespace octic

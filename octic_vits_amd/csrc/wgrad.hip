@@ -1,0 +1,432 @@
+// Weight gradient of the irrep-blocked linear for gfx950:  G_g[n,k] = sum_rows dY_g[row,n] X_g[row,k].
+//
+// The reduction runs over token rows, which are the STRIDED dimension of both operands.  Tiles of
+// X [rows x k-cols] and dY [rows x n-cols] are staged row-major in LDS exactly as they lie in HBM
+// (coalesced 16-byte loads), and the MFMA operands (which need 8 consecutive reduction indices per
+// lane) are fetched with the CDNA4 transposing LDS read ds_read_b64_tr_b16 — no transposed copy of
+// the activations is ever materialised.  f32 uses v_mfma_f32_16x16x4_f32 whose operands are single
+// floats, read with ds_read_b32.
+// D[i=k][j=n] orientation: a lane ends with 4 consecutive k of one n -> 16-byte stores into the
+// [N,K] (nn.Linear) layout.  The row range is split over `splits` workgroup sets writing f32 slabs;
+// the finish kernel sums the slabs in a fixed order (bitwise reproducible), applies the layer-scale
+// chain rule (see octic_hip.h) and writes dW / dcs / dbias.
+#include "octic_common.hpp"
+
+namespace octic {
+
+struct WgGroup {
+  const char* x;   // [rows, K] rows
+  int64_t x_ld;
+  const char* dy;  // [rows, N] rows
+  int64_t dy_ld;
+  int64_t rows;
+  int K, N;
+  int pair;
+  int k_tiles, n_tiles;
+  int tile_begin;
+  int64_t slab_off;  // element offset of this group's [N,K] block inside a slab
+};
+struct WgArgs {
+  WgGroup g[5];
+  int ngroups;
+  int tiles;       // tiles per split
+  int splits;
+  int64_t slab_elems;
+  float* slabs;
+};
+
+template <typename T> struct WElem;
+template <> struct WElem<float> { static constexpr int EPC = 4; static constexpr int BMR = 32; };
+template <> struct WElem<bf16> { static constexpr int EPC = 8; static constexpr int BMR = 64; };
+
+template <typename TIN, int TT>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgArgs args) {
+  constexpr int EPC = WElem<TIN>::EPC;
+  constexpr int BMR = WElem<TIN>::BMR;          // reduction rows per LDS tile
+  constexpr int BW = 32 * TT;                   // tile width in columns (k and n alike)
+  constexpr int CPR = BW / EPC;                 // 16-byte chunks per tile row
+  constexpr int RS = BW * (int)sizeof(TIN) + 16;  // LDS row stride (bytes), +16 B pad
+  constexpr int TILE = BMR * RS;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 stages x (X tile + dY tile)
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // logical id -> (group, split, tile): tiles of one (group, split) are adjacent so they share the
+  // same row panels of X and dY through one XCD's L2.
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (i < args.ngroups && lid >= args.g[i].tile_begin * args.splits) gi = i;
+  const WgGroup& G = args.g[gi];
+  const int gt = G.k_tiles * G.n_tiles;
+  const int rel = lid - G.tile_begin * args.splits;
+  const int split = rel / gt, lt = rel - split * gt;
+  const int kt = lt / G.n_tiles, nt = lt - kt * G.n_tiles;
+  const int k0 = kt * BW, n0 = nt * BW;
+  const int K = G.K, N = G.N;
+  int64_t chunk = (G.rows + args.splits - 1) / args.splits;
+  chunk = (chunk + BMR - 1) / BMR * BMR;
+  const int64_t r0 = (int64_t)split * chunk;
+  const int64_t r1 = r0 + chunk < G.rows ? r0 + chunk : G.rows;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wk = wid & 1, wn = wid >> 1;
+  const int fr = lane & 15, kg = lane >> 4;
+
+  f32x4 acc[TT][TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i)
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  u32x4 rx[TT], ry[TT];
+  auto gload = [&](int64_t rbase) {
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / CPR, cc = q - row * CPR;
+      const int64_t mm = rbase + row;
+      const bool rok = mm < r1;
+      const int64_t xo = G.pair ? (mm >> 1) * G.x_ld + (mm & 1) * (int64_t)K : mm * G.x_ld;
+      const int64_t yo = G.pair ? (mm >> 1) * G.dy_ld + (mm & 1) * (int64_t)N : mm * G.dy_ld;
+      const int kcol = k0 + cc * EPC, ncol = n0 + cc * EPC;
+      rx[i] = (rok && kcol < K) ? *(const u32x4*)((const TIN*)G.x + xo + kcol) : u32x4{0, 0, 0, 0};
+      ry[i] = (rok && ncol < N) ? *(const u32x4*)((const TIN*)G.dy + yo + ncol) : u32x4{0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](int stage) {
+    char* xs = lds + stage * 2 * TILE;
+    char* ys = xs + TILE;
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / CPR, cc = q - row * CPR;
+      *(u32x4*)(xs + row * RS + cc * 16) = rx[i];
+      *(u32x4*)(ys + row * RS + cc * 16) = ry[i];
+    }
+  };
+
+  if (r0 < r1) {
+    const int64_t nrt = (r1 - r0 + BMR - 1) / BMR;
+    gload(r0);
+    lstore(0);
+    __syncthreads();
+    for (int64_t rt = 0; rt < nrt; ++rt) {
+      if (rt + 1 < nrt) gload(r0 + (rt + 1) * BMR);
+      const char* xs = lds + (int)(rt & 1) * 2 * TILE;
+      const char* ys = xs + TILE;
+      if constexpr (sizeof(TIN) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < BMR / 32; ++ks) {
+          bf16x8 af[TT], bfr[TT];
+          // transposing reads: lane fr=4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
+          // 4x16 block and receives column fr of its 4 rows (cdna_hip_programming.md T10)
+          const int rbase = ks * 32 + kg * 8 + (fr >> 2);
+          const int cb = (fr & 3) * 4;
+#pragma unroll
+          for (int i = 0; i < TT; ++i) {
+            const int col = wk * (TT * 16) + i * 16 + cb;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(xs + rbase * RS + col * 2));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(xs + (rbase + 4) * RS + col * 2));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            af[i] = __builtin_bit_cast(bf16x8, v);
+          }
+#pragma unroll
+          for (int j = 0; j < TT; ++j) {
+            const int col = wn * (TT * 16) + j * 16 + cb;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(ys + rbase * RS + col * 2));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(ys + (rbase + 4) * RS + col * 2));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bfr[j] = __builtin_bit_cast(bf16x8, v);
+          }
+#pragma unroll
+          for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s4 = 0; s4 < BMR / 4; ++s4) {
+          float af[TT], bfr[TT];
+          const int row = s4 * 4 + kg;
+#pragma unroll
+          for (int i = 0; i < TT; ++i) af[i] = *(const float*)(xs + row * RS + (wk * (TT * 16) + i * 16 + fr) * 4);
+#pragma unroll
+          for (int j = 0; j < TT; ++j) bfr[j] = *(const float*)(ys + row * RS + (wn * (TT * 16) + j * 16 + fr) * 4);
+#pragma unroll
+          for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (rt + 1 < nrt) lstore((int)((rt + 1) & 1));
+      __syncthreads();
+    }
+  }
+
+  // slab store: lane holds k = kb + kg*4 + (0..3) of row n = nb + fr
+  float* slab = args.slabs + (int64_t)split * args.slab_elems + G.slab_off;
+#pragma unroll
+  for (int j = 0; j < TT; ++j) {
+    const int n = n0 + wn * (TT * 16) + j * 16 + fr;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int k = k0 + wk * (TT * 16) + i * 16 + kg * 4;
+      if (k >= K) continue;
+      *(f32x4*)(slab + (int64_t)n * K + k) = acc[i][j];
+    }
+  }
+}
+
+// One wave per weight row n of a group: G[n,:] = sum_splits slab ; dW = cs[n]*G ; dcs[n] = <W[n,:],G[n,:]> (+ bias term)
+struct FinGroup {
+  int64_t slab_off;
+  int K, N;
+  int row_begin;
+  const float* w32;
+  const float* cs;
+  float* dw;
+  float* dcs;
+};
+struct FinArgs {
+  FinGroup g[5];
+  int ngroups;
+  int rows_total;
+  int splits;
+  int64_t slab_elems;
+  const float* slabs;
+  const float* bias;
+  const float* dysum;
+  float* dbias;
+};
+
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(FinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows_total) return;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (i < a.ngroups && row >= a.g[i].row_begin) gi = i;
+  const FinGroup& G = a.g[gi];
+  const int n = row - G.row_begin;
+  const float s = G.cs ? G.cs[n] : 1.0f;
+  float dot = 0.f;
+  for (int k = lane * 4; k < G.K; k += 256) {
+    f32x4 v = {0, 0, 0, 0};
+    for (int sp = 0; sp < a.splits; ++sp) v += *(const f32x4*)(a.slabs + (int64_t)sp * a.slab_elems + G.slab_off + (int64_t)n * G.K + k);
+    if (G.cs) {
+      const f32x4 w = *(const f32x4*)(G.w32 + (int64_t)n * G.K + k);
+      dot += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+    }
+    if (G.dw) *(f32x4*)(G.dw + (int64_t)n * G.K + k) = v * s;
+  }
+  if (G.cs) {
+    dot = wave_sum(dot);
+    if (lane == 0 && G.dcs) {
+      if (gi == 0 && a.bias && a.dysum) dot += a.bias[n] * a.dysum[n];
+      G.dcs[n] = dot;
+    }
+  }
+  if (gi == 0 && lane == 0 && a.dbias && a.dysum) a.dbias[n] = s * a.dysum[n];
+}
+
+inline int pick_tt(const WgArgs& a) {
+  int best = 2;
+  double best_cost = 1e30;
+  for (int tt = 2; tt <= 5; ++tt) {
+    const int bw = 32 * tt;
+    double cost = 0;
+    for (int i = 0; i < a.ngroups; ++i) {
+      const double kt = (a.g[i].K + bw - 1) / bw, nt = (a.g[i].N + bw - 1) / bw;
+      cost += kt * nt * bw * bw * (double)a.g[i].rows;
+    }
+    if (cost <= best_cost * 1.0001) {
+      best_cost = cost < best_cost ? cost : best_cost;
+      best = tt;
+    }
+  }
+  return best;
+}
+
+template <typename TIN, int TT>
+int launch_wgrad_tt(WgArgs& a, hipStream_t s) {
+  constexpr int BW = 32 * TT;
+  int t = 0;
+  for (int i = 0; i < a.ngroups; ++i) {
+    a.g[i].k_tiles = (a.g[i].K + BW - 1) / BW;
+    a.g[i].n_tiles = (a.g[i].N + BW - 1) / BW;
+    a.g[i].tile_begin = t;
+    t += a.g[i].k_tiles * a.g[i].n_tiles;
+  }
+  a.tiles = t;
+  constexpr size_t smem = (size_t)2 * 2 * WElem<TIN>::BMR * (BW * sizeof(TIN) + 16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<TIN, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  wgrad_kernel<TIN, TT><<<t * a.splits, 256, smem, s>>>(a);
+  return launch_status();
+}
+
+template <typename TIN>
+int launch_wgrad(WgArgs& a, hipStream_t s) {
+  switch (pick_tt(a)) {
+    case 2: return launch_wgrad_tt<TIN, 2>(a, s);
+    case 3: return launch_wgrad_tt<TIN, 3>(a, s);
+    case 4: return launch_wgrad_tt<TIN, 4>(a, s);
+    default: return launch_wgrad_tt<TIN, 5>(a, s);
+  }
+}
+
+inline int64_t linear_slab_elems(int cin, int cout) { return (int64_t)8 * cin * cout; }
+
+}  // namespace octic
+
+using namespace octic;
+
+extern "C" {
+
+int64_t octic_linear_d8_wgrad_workspace_bytes(int cin, int cout, int splits) {
+  return linear_slab_elems(cin, cout) * (int64_t)splits * 4;
+}
+
+int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
+  // enough row-splits to give every CU a couple of workgroups, bounded so the f32 slabs stay a
+  // fraction of the activation bytes the kernel has to read anyway
+  WgArgs a = {};
+  a.ngroups = 5;
+  for (int i = 0; i < 5; ++i) {
+    a.g[i].K = i == 0 ? 2 * cin : cin;
+    a.g[i].N = i == 0 ? 2 * cout : cout;
+    a.g[i].rows = i == 0 ? 2 * M : M;
+  }
+  const int bw = 32 * pick_tt(a);
+  int tiles = 0;
+  for (int i = 0; i < 5; ++i) tiles += ((a.g[i].K + bw - 1) / bw) * ((a.g[i].N + bw - 1) / bw);
+  int s = (512 + tiles - 1) / tiles;
+  const int64_t max_by_rows = (M + 255) / 256;
+  if (s > max_by_rows) s = (int)max_by_rows;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return s;
+}
+
+int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, int cin, int cout, int dtype,
+                          float* workspace, int splits, void* stream) {
+  int e;
+  if ((e = check_c(cin)) || (e = check_c(cout))) return e;
+  if ((e = check_view(x, cin, dtype)) || (e = check_view(dy, cout, dtype))) return e;
+  if (!workspace) return OCTIC_ENULL;
+  if (M <= 0 || splits <= 0) return OCTIC_ESHAPE;
+  WgArgs a = {};
+  a.ngroups = 5;
+  a.splits = splits;
+  a.slab_elems = linear_slab_elems(cin, cout);
+  a.slabs = workspace;
+  // slab layout: [W_A1 | W_A2 | W_B1 | W_B2 | W_E]; launch order E first
+  for (int gidx = 0; gidx < 5; ++gidx) {
+    const int irrep = gidx == 0 ? 4 : gidx - 1;
+    const bool isE = irrep == 4;
+    WgGroup& g = a.g[gidx];
+    g.x = (const char*)x->ptr[irrep];
+    g.x_ld = x->ld[irrep];
+    g.dy = (const char*)dy->ptr[irrep];
+    g.dy_ld = dy->ld[irrep];
+    g.rows = isE ? 2 * M : M;
+    g.K = isE ? 2 * cin : cin;
+    g.N = isE ? 2 * cout : cout;
+    g.pair = isE ? 1 : 0;
+    g.slab_off = isE ? (int64_t)4 * cin * cout : (int64_t)irrep * cin * cout;
+  }
+  if (dtype == OCTIC_F32) return launch_wgrad<float>(a, (hipStream_t)stream);
+  if (dtype == OCTIC_BF16) return launch_wgrad<bf16>(a, (hipStream_t)stream);
+  return OCTIC_EDTYPE;
+}
+
+int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, int cout, const float* const w32[5],
+                                 const float* const cs[5], const float* bias, const float* dysum, float* const dw[5],
+                                 float* const dcs[5], float* dbias, void* stream) {
+  if (!workspace || !dw) return OCTIC_ENULL;
+  if (splits <= 0 || check_c(cin) || check_c(cout)) return OCTIC_ESHAPE;
+  if (cs && (!w32 || !dcs)) return OCTIC_ENULL;
+  FinArgs a = {};
+  a.ngroups = 5;
+  a.splits = splits;
+  a.slab_elems = linear_slab_elems(cin, cout);
+  a.slabs = workspace;
+  a.bias = bias;
+  a.dysum = dysum;
+  a.dbias = dbias;
+  int row = 0;
+  for (int irrep = 0; irrep < 5; ++irrep) {  // group 0 must be A1 (bias terms)
+    const bool isE = irrep == 4;
+    FinGroup& g = a.g[irrep];
+    g.K = isE ? 2 * cin : cin;
+    g.N = isE ? 2 * cout : cout;
+    g.slab_off = isE ? (int64_t)4 * cin * cout : (int64_t)irrep * cin * cout;
+    g.row_begin = row;
+    row += g.N;
+    g.w32 = cs ? w32[irrep] : nullptr;
+    g.cs = cs ? cs[irrep] : nullptr;
+    g.dw = dw[irrep];
+    g.dcs = cs ? dcs[irrep] : nullptr;
+    if (cs && (!g.w32 || !g.cs || !g.dcs)) return OCTIC_ENULL;
+  }
+  a.rows_total = row;
+  wgrad_finish_kernel<<<(row + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+int64_t octic_lift_wgrad_workspace_bytes(int Kpad, int D, int splits) { return (int64_t)Kpad * D * splits * 4; }
+
+int octic_lift_wgrad(const void* patches, const void* dout, float* dw, float* workspace, int splits, int64_t rows,
+                     int Kpad, int D, int dtype, void* stream) {
+  if (!patches || !dout || !dw || !workspace) return OCTIC_ENULL;
+  if (rows <= 0 || splits <= 0 || Kpad <= 0 || (Kpad % 8) || D <= 0 || (D % 8)) return OCTIC_ESHAPE;
+  WgArgs a = {};
+  a.ngroups = 1;
+  a.splits = splits;
+  a.slab_elems = (int64_t)Kpad * D;
+  a.slabs = workspace;
+  WgGroup& g = a.g[0];
+  g.x = (const char*)patches;
+  g.x_ld = Kpad;
+  g.dy = (const char*)dout;
+  g.dy_ld = D;
+  g.rows = rows;
+  g.K = Kpad;
+  g.N = D;
+  g.pair = 0;
+  g.slab_off = 0;
+  int e = dtype == OCTIC_F32 ? launch_wgrad<float>(a, (hipStream_t)stream)
+                             : (dtype == OCTIC_BF16 ? launch_wgrad<bf16>(a, (hipStream_t)stream) : OCTIC_EDTYPE);
+  if (e) return e;
+  FinArgs f = {};
+  f.ngroups = 1;
+  f.splits = splits;
+  f.slab_elems = a.slab_elems;
+  f.slabs = workspace;
+  f.g[0].K = Kpad;
+  f.g[0].N = D;
+  f.g[0].slab_off = 0;
+  f.g[0].row_begin = 0;
+  f.g[0].dw = dw;
+  f.rows_total = D;
+  wgrad_finish_kernel<<<(D + 3) / 4, 256, 0, (hipStream_t)stream>>>(f);
+  return launch_status();
+}
+
+}  // extern "C"

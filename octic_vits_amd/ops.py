@@ -1,0 +1,264 @@
+"""Raw (non-autograd) launches of the HIP engine on torch tensors.
+
+torch is plumbing here: it owns device memory and the current HIP stream; every call goes straight
+through the C ABI (include/octic_hip.h) via ctypes.  Tensors are described to the ABI as
+``octic_view`` (5 base pointers + row strides), so both the reference's 5-tuple of separate tensors
+and the engine's packed ``[B, T, 8c]`` rows are handled by the same kernels without a copy.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, OcticView, PtrArray5, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt_code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"octic engine supports float32 and bfloat16, got {dtype}") from None
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("octic_vits_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+
+
+def pview(t: torch.Tensor, c: int) -> OcticView:
+    """View of a packed tensor [..., 8c] = [A1|A2|B1|B2|E_row0|E_row1]."""
+    _require_cuda(t)
+    if t.shape[-1] != 8 * c or not t.is_contiguous():
+        raise ValueError(f"expected a contiguous packed tensor with last dim {8 * c}, got {tuple(t.shape)}")
+    es, base, D = t.element_size(), t.data_ptr(), 8 * c
+    v = OcticView()
+    for i in range(4):
+        v.ptr[i] = base + i * c * es
+        v.ld[i] = D
+    v.ptr[4] = base + 4 * c * es
+    v.ld[4] = D
+    return v
+
+
+def _rows_ok(t, inner):
+    """t viewed as rows of `inner` contiguous elements with one uniform row stride?"""
+    lead = t.shape[:-len(inner)]
+    st = t.stride()
+    exp = 1
+    for k in range(1, len(inner) + 1):
+        if t.shape[-k] != inner[-k] or (st[-k] != exp and t.shape[-k] != 1):
+            return False
+        exp *= inner[-k]
+    # leading dims must collapse onto a single stride
+    ld = st[len(lead) - 1] if lead else exp
+    acc = ld
+    for k in range(len(lead) - 1, -1, -1):
+        if t.shape[k] != 1 and st[k] != acc:
+            return False
+        acc *= t.shape[k]
+    return True
+
+
+def tview(xs, c: int):
+    """View of a reference-style 5-tuple (A1..B2: [..., c]; E: [..., 2, 2c]).  Returns (view, keepalive)."""
+    keep = []
+    v = OcticView()
+    for i in range(5):
+        t = xs[i]
+        _require_cuda(t)
+        inner = (c,) if i < 4 else (2, 2 * c)
+        if tuple(t.shape[-len(inner):]) != inner:
+            raise ValueError(f"irrep {i}: expected trailing shape {inner}, got {tuple(t.shape)}")
+        if not _rows_ok(t, inner):
+            t = t.contiguous()
+        keep.append(t)
+        nlead = t.dim() - len(inner)
+        v.ptr[i] = t.data_ptr()
+        v.ld[i] = t.stride(nlead - 1) if nlead > 0 else (c if i < 4 else 4 * c)
+    return v, keep
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _arr5(ts):
+    a = PtrArray5()
+    for i in range(5):
+        a[i] = ts[i].data_ptr() if (ts is not None and ts[i] is not None) else 0
+    return a
+
+
+def split_packed(t, c):
+    """The reference's 5-tuple as zero-copy views of a packed [B,T,8c] tensor."""
+    lead = t.shape[:-1]
+    return (t[..., 0:c], t[..., c:2 * c], t[..., 2 * c:3 * c], t[..., 3 * c:4 * c],
+            t[..., 4 * c:].unflatten(-1, (2, 2 * c)))
+
+
+# ------------------------------------------------------------------------------------------ launches
+def gelu_fwd(xv, yv, M, c, dtype, ref):
+    check(lib().octic_gelu_d8_fwd(ctypes.byref(xv), ctypes.byref(yv), M, c, dt_code(dtype), _stream(ref)))
+
+
+def gelu_bwd(gv, xv, ov, M, c, dtype, ref):
+    check(lib().octic_gelu_d8_bwd(ctypes.byref(gv), ctypes.byref(xv), ctypes.byref(ov), M, c, dt_code(dtype), _stream(ref)))
+
+
+def layernorm_fwd(x, alpha5, beta, eps, out_dtype, c, want_stats=True):
+    """x: packed f32 [..., 8c] -> (y packed out_dtype, stats [M,8] f32)."""
+    M = x.numel() // (8 * c)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    stats = torch.empty((M, 8), dtype=torch.float32, device=x.device) if want_stats else None
+    xv, yv = pview(x, c), pview(y, c)
+    check(lib().octic_layernorm_d8_fwd(ctypes.byref(xv), ctypes.byref(yv), _arr5(alpha5), _p(beta), _p(stats), M, c,
+                                       float(eps), dt_code(out_dtype), _stream(x)))
+    return y, stats
+
+
+def layernorm_bwd(g, x, stats, alpha5, dres, c, want_param_grads=True):
+    """Returns (dx f32 packed, dalpha5 or None, dbeta or None).  dx = dres + LN'(g)."""
+    M = x.numel() // (8 * c)
+    dx = torch.empty_like(x)
+    nblk = lib().octic_layernorm_d8_bwd_blocks(M)
+    partials = torch.empty((nblk, 2, 8 * c), dtype=torch.float32, device=x.device)
+    gv, xv, dv = pview(g, c), pview(x, c), pview(dx, c)
+    rv = pview(dres, c) if dres is not None else None
+    check(lib().octic_layernorm_d8_bwd(ctypes.byref(gv), ctypes.byref(xv), _p(stats), _arr5(alpha5),
+                                       ctypes.byref(rv) if rv is not None else None, ctypes.byref(dv), _p(partials),
+                                       M, c, dt_code(g.dtype), _stream(x)))
+    if not want_param_grads or alpha5 is None:
+        return dx, None, None
+    dal = [torch.empty_like(a) for a in alpha5]
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib().octic_layernorm_d8_bwd_finish(_p(partials), nblk, c, _arr5(dal), _p(dbeta), _stream(x)))
+    return dx, dal, dbeta
+
+
+def linear_fwd(xv, w5, bias, yv, M, cin, cout, dtype, out_dtype, ref, resid_v=None, rs=None, rps=1, cs5=None):
+    check(lib().octic_linear_d8_fwd(ctypes.byref(xv), _arr5(w5), _p(bias), ctypes.byref(yv),
+                                    ctypes.byref(resid_v) if resid_v is not None else None, _p(rs), int(rps),
+                                    _arr5(cs5) if cs5 is not None else None, M, cin, cout, dt_code(dtype),
+                                    dt_code(out_dtype), _stream(ref)))
+
+
+def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=None, dysum=None, want_bias=False):
+    """Returns (dw5 [f32], dcs5 or None, dbias or None)."""
+    L = lib()
+    dev = ref.device
+    splits = L.octic_linear_d8_wgrad_splits(M, cin, cout)
+    ws = torch.empty(L.octic_linear_d8_wgrad_workspace_bytes(cin, cout, splits) // 4, dtype=torch.float32, device=dev)
+    check(L.octic_linear_d8_wgrad(ctypes.byref(xv), ctypes.byref(dyv), M, cin, cout, dt_code(dtype), _p(ws), splits,
+                                  _stream(ref)))
+    dw = [torch.empty((cout, cin), dtype=torch.float32, device=dev) for _ in range(4)]
+    dw.append(torch.empty((2 * cout, 2 * cin), dtype=torch.float32, device=dev))
+    dcs = None
+    if cs5 is not None:
+        dcs = [torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(4)]
+        dcs.append(torch.empty(2 * cout, dtype=torch.float32, device=dev))
+    dbias = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+    check(L.octic_linear_d8_wgrad_finish(_p(ws), splits, cin, cout, _arr5(w32) if cs5 is not None else None,
+                                         _arr5(cs5) if cs5 is not None else None, _p(bias), _p(dysum), _arr5(dw),
+                                         _arr5(dcs) if dcs is not None else None, _p(dbias), _stream(ref)))
+    return dw, dcs, dbias
+
+
+def colsum_a1(dyv, M, c, dtype, ref):
+    L = lib()
+    nblk = L.octic_colsum_blocks(M)
+    partials = torch.empty((nblk, c), dtype=torch.float32, device=ref.device)
+    out = torch.empty(c, dtype=torch.float32, device=ref.device)
+    check(L.octic_colsum_a1(ctypes.byref(dyv), M, c, dt_code(dtype), _p(partials), _p(out), _stream(ref)))
+    return out
+
+
+def cast_rowscale(x, rs, rps, out_dtype, c):
+    M = x.numel() // (8 * c)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    xv, yv = pview(x, c), pview(y, c)
+    check(lib().octic_cast_rowscale(ctypes.byref(xv), ctypes.byref(yv), _p(rs), int(rps), M, c, dt_code(out_dtype),
+                                    _stream(x)))
+    return y
+
+
+def pack_heads(x, B, T, H, c, n_s):
+    """x packed [B,T,n_s*8c] -> [n_s,B,H,T,8c/H]"""
+    out = torch.empty((n_s, B, H, T, 8 * c // H), dtype=x.dtype, device=x.device)
+    xv = pview(x, n_s * c)
+    check(lib().octic_attn_pack_heads(ctypes.byref(xv), _p(out), B, T, H, c, n_s, dt_code(x.dtype), _stream(x)))
+    return out
+
+
+def unpack_heads(o, B, T, H, c, n_s):
+    """[n_s,B,H,T,8c/H] -> packed [B,T,n_s*8c]"""
+    if not o.is_contiguous():
+        o = o.contiguous()
+    y = torch.empty((B, T, n_s * 8 * c), dtype=o.dtype, device=o.device)
+    yv = pview(y, n_s * c)
+    check(lib().octic_attn_unpack_heads(_p(o), ctypes.byref(yv), B, T, H, c, n_s, dt_code(o.dtype), _stream(o)))
+    return y
+
+
+def handoff_cat_fwd(x, c, out_dtype):
+    M = x.numel() // (8 * c)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    xv = pview(x, c)
+    check(lib().octic_handoff_cat_fwd(ctypes.byref(xv), _p(y), M, c, dt_code(out_dtype), _stream(x)))
+    return y
+
+
+def handoff_cat_bwd(dd, c):
+    dd = dd.contiguous().float()
+    M = dd.numel() // (8 * c)
+    dx = torch.empty_like(dd)
+    dv = pview(dx, c)
+    check(lib().octic_handoff_cat_bwd(_p(dd), ctypes.byref(dv), M, c, _stream(dd)))
+    return dx
+
+
+def power_spectrum_fwd(x, c, out_dtype):
+    M = x.numel() // (8 * c)
+    y = torch.empty(x.shape[:-1] + (6 * c,), dtype=out_dtype, device=x.device)
+    xv = pview(x, c)
+    check(lib().octic_power_spectrum_fwd(ctypes.byref(xv), _p(y), M, c, dt_code(out_dtype), _stream(x)))
+    return y
+
+
+def power_spectrum_bwd(dd, x, c):
+    dd = dd.contiguous().float()
+    M = x.numel() // (8 * c)
+    dx = torch.empty_like(x)
+    xv, dv = pview(x, c), pview(dx, c)
+    check(lib().octic_power_spectrum_bwd(_p(dd), ctypes.byref(xv), ctypes.byref(dv), M, c, _stream(x)))
+    return dx
+
+
+def im2col(img, p, Kpad, dtype):
+    B, Cin, Hh, Ww = img.shape
+    img = img.contiguous().float()
+    rows = B * (Hh // p) * (Ww // p)
+    out = torch.empty((rows, Kpad), dtype=dtype, device=img.device)
+    check(lib().octic_im2col_patches(_p(img), _p(out), B, Cin, Hh, Ww, p, Kpad, dt_code(dtype), _stream(img)))
+    return out
+
+
+def lift_gemm(patches, w, bias_full, pos, out, B, n_patches, tok0, Kpad, D):
+    check(lib().octic_lift_gemm(_p(patches), _p(w), _p(bias_full), _p(pos), _p(out), B, n_patches, tok0, Kpad, D,
+                                dt_code(patches.dtype), _stream(patches)))
+
+
+def lift_wgrad(patches, dout, Kpad, D):
+    L = lib()
+    rows = patches.shape[0]
+    splits = max(1, min(16, rows // 512))
+    ws = torch.empty(L.octic_lift_wgrad_workspace_bytes(Kpad, D, splits) // 4, dtype=torch.float32, device=patches.device)
+    dw = torch.empty((D, Kpad), dtype=torch.float32, device=patches.device)
+    check(L.octic_lift_wgrad(_p(patches), _p(dout), _p(dw), _p(ws), splits, rows, Kpad, D, dt_code(patches.dtype),
+                             _stream(patches)))
+    return dw

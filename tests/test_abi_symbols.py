@@ -1,0 +1,50 @@
+"""CPU-only: the C-ABI library builds, loads, and exports every symbol include/octic_hip.h declares.
+No compute call is made (there is no GPU here)."""
+import ctypes
+import os
+
+from octic_vits_amd import _lib
+from octic_vits_amd.build import build
+
+
+def test_library_builds_and_exports_header_symbols():
+    path = build()
+    assert os.path.exists(path)
+    declared = _lib.header_symbols()
+    assert len(declared) >= 25
+    L = ctypes.CDLL(path)
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, f"declared in octic_hip.h but not exported: {missing}"
+    # the ctypes prototypes cover exactly the header
+    assert sorted(_lib._PROTOS) == declared
+
+
+def test_loader_checks_abi_version_and_errors_render():
+    L = _lib.lib()
+    assert L.octic_abi_version() == 1
+    assert b"shape" in L.octic_strerror(-1)
+    assert b"align" in L.octic_strerror(-2)
+
+
+def test_argument_validation_without_gpu():
+    """Rejected arguments return negative codes before any launch."""
+    L = _lib.lib()
+    v = _lib.OcticView()
+    for i in range(5):
+        v.ptr[i] = 4096 + 64 * i
+        v.ld[i] = 64
+    # c not a multiple of 8
+    assert L.octic_gelu_d8_fwd(ctypes.byref(v), ctypes.byref(v), 4, 12, _lib.F32, None) == -1
+    # misaligned pointer
+    v.ptr[2] = 4096 + 4
+    assert L.octic_gelu_d8_fwd(ctypes.byref(v), ctypes.byref(v), 4, 8, _lib.F32, None) == -2
+    v.ptr[2] = 0
+    assert L.octic_gelu_d8_fwd(ctypes.byref(v), ctypes.byref(v), 4, 8, _lib.F32, None) == -4
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from octic_vits_amd import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.pview(torch.zeros(2, 3, 64), 8)
