@@ -288,30 +288,43 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* img, T* patche
 constexpr int kColsumRows = 512;  // rows per block
 
 template <typename T>
+__device__ inline void load4e(const T* p, float v[4]);
+template <>
+__device__ inline void load4e<float>(const float* p, float v[4]) {
+  f32x4 a = *(const f32x4*)p;
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+template <>
+__device__ inline void load4e<bf16>(const bf16* p, float v[4]) {
+  bf16x4 a = *(const bf16x4*)p;
+  v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)a[2]; v[3] = (float)a[3];
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* a, int64_t ld, int64_t M, int c, float* partials) {
-  // block b sums rows [b*kColsumRows, ...) of the [M, c] matrix; thread = (row lane, 8-column chunk)
-  __shared__ float red[256 * 8];
-  const int c8 = c >> 3;
-  const int lanes = 256 / c8 > 0 ? 256 / c8 : 1;
-  const int rl = threadIdx.x / c8, cc = threadIdx.x - rl * c8;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // block b sums rows [b*kColsumRows, ...) of the [M, c] matrix; thread = (row lane, 4-column chunk)
+  __shared__ float red[256 * 4];
+  const int c4 = c >> 2;
+  const int lanes = 256 / c4 > 0 ? 256 / c4 : 1;
+  const int rl = threadIdx.x / c4, cc = threadIdx.x - rl * c4;
+  float acc[4] = {0, 0, 0, 0};
   const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
   const int64_t r1 = r0 + kColsumRows < M ? r0 + kColsumRows : M;
   if (rl < lanes) {
     for (int64_t m = r0 + rl; m < r1; m += lanes) {
-      float v[8];
-      load8<T>(a + m * ld + cc * 8, v);
+      float v[4];
+      load4e<T>(a + m * ld + cc * 4, v);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+      for (int i = 0; i < 4; ++i) acc[i] += v[i];
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+  for (int i = 0; i < 4; ++i) red[threadIdx.x * 4 + i] = acc[i];
   __syncthreads();
   for (int col = threadIdx.x; col < c; col += 256) {
-    const int ch = col >> 3, i = col & 7;
+    const int ch = col >> 2, i = col & 3;
     float s = 0.f;
-    for (int l = 0; l < lanes; ++l) s += red[(l * c8 + ch) * 8 + i];
+    for (int l = 0; l < lanes; ++l) s += red[(l * c4 + ch) * 4 + i];
     partials[(int64_t)blockIdx.x * c + col] = s;
   }
 }
@@ -498,9 +511,9 @@ int octic_colsum_blocks(int64_t M) { return (int)((M + kColsumRows - 1) / kColsu
 
 int octic_colsum_a1(const octic_view* dy, int64_t M, int c, int dtype, float* partials, float* out, void* stream) {
   int e;
-  if ((e = check_c(c)) || (e = check_view(dy, c, dtype))) return e;
+  if ((e = check_c_dt(c, dtype)) || (e = check_view(dy, c, dtype))) return e;
   if (!partials || !out) return OCTIC_ENULL;
-  if (M <= 0 || c > 2048) return OCTIC_ESHAPE;
+  if (M <= 0 || c > 1024) return OCTIC_ESHAPE;
   const int nblk = octic_colsum_blocks(M);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OCTIC_F32) colsum_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)dy->ptr[0], dy->ld[0], M, c, partials);

@@ -298,7 +298,7 @@ int octic_linear_d8_fwd(const octic_view* x, const void* const w[5], const float
                         const octic_view* resid, const float* rs, int64_t rows_per_sample, const float* const cs[5],
                         int64_t M, int cin, int cout, int dtype, int out_dtype, void* stream) {
   int e;
-  if ((e = check_c(cin)) || (e = check_c(cout))) return e;
+  if ((e = check_c_dt(cin, dtype)) || (e = check_c_dt(cout, dtype)) || (e = check_c_dt(cout, out_dtype))) return e;
   if ((e = check_view(x, cin, dtype)) || (e = check_view(y, cout, out_dtype))) return e;
   if (resid && (e = check_view(resid, cout, out_dtype))) return e;
   if (!w) return OCTIC_ENULL;

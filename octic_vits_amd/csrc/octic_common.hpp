@@ -93,6 +93,11 @@ inline int check_view(const octic_view* v, int c, int dtype) {
 }
 
 inline int check_c(int c) { return (c > 0 && (c % 8) == 0) ? OCTIC_OK : OCTIC_ESHAPE; }
+// GEMM paths move 16-byte chunks of the compute dtype: f32 only needs c % 4 == 0
+inline int check_c_dt(int c, int dtype) {
+  if (c <= 0) return OCTIC_ESHAPE;
+  return (c % (dtype == OCTIC_F32 ? 4 : 8)) == 0 ? OCTIC_OK : OCTIC_ESHAPE;
+}
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

@@ -327,7 +327,7 @@ int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
 int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, int cin, int cout, int dtype,
                           float* workspace, int splits, void* stream) {
   int e;
-  if ((e = check_c(cin)) || (e = check_c(cout))) return e;
+  if ((e = check_c_dt(cin, dtype)) || (e = check_c_dt(cout, dtype))) return e;
   if ((e = check_view(x, cin, dtype)) || (e = check_view(dy, cout, dtype))) return e;
   if (!workspace) return OCTIC_ENULL;
   if (M <= 0 || splits <= 0) return OCTIC_ESHAPE;
@@ -360,7 +360,7 @@ int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, in
                                  const float* const cs[5], const float* bias, const float* dysum, float* const dw[5],
                                  float* const dcs[5], float* dbias, void* stream) {
   if (!workspace || !dw) return OCTIC_ENULL;
-  if (splits <= 0 || check_c(cin) || check_c(cout)) return OCTIC_ESHAPE;
+  if (splits <= 0 || check_c_dt(cin, OCTIC_F32) || check_c_dt(cout, OCTIC_F32)) return OCTIC_ESHAPE;
   if (cs && (!w32 || !dcs)) return OCTIC_ENULL;
   FinArgs a = {};
   a.ngroups = 5;

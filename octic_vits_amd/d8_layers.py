@@ -1,0 +1,560 @@
+"""HIP-backed octic layers with the reference's names, constructor signatures and state_dict keys
+(reference: octic_vits/d8_layers.py; per-class citations below).  Drop-in at module level: every
+module takes and returns the reference's 5-tuple.  Outputs are ``Octic`` tuples — the same five
+tensors, as views of one packed token-row buffer, which is what lets the next module skip repacking.
+
+What runs where: all octic arithmetic (LayerNormD8, the five-irrep linears incl. their gradients,
+D8-GELU, head packing, layer-scale + drop-path + residual) is HIP (``functional.py``).  torch supplies
+memory, RNG for masks, and the attention core (``F.scaled_dot_product_attention``, as the reference).
+"""
+import collections.abc
+import math
+from itertools import repeat
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as OF
+from .d8_utils import SQRT2, SQRT2_OVER_4, convert_5tuple_to_8tuple, convert_8tuple_to_5tuple, expand_lift_kernel
+from .functional import Octic, as_packed, compute_dtype
+
+
+def _ntuple(n):
+    def parse(x):
+        if isinstance(x, collections.abc.Iterable) and not isinstance(x, str):
+            return tuple(x)
+        return tuple(repeat(x, n))
+    return parse
+
+
+to_2tuple = _ntuple(2)
+
+# test hook: a callable (B, keep_prob, device) -> mask[B]; default draws with torch's RNG on `device`
+drop_path_mask_source = None
+
+
+def _drop_path_mask(B, drop_prob, device, scale_by_keep=True):
+    keep = 1.0 - drop_prob
+    if drop_path_mask_source is not None:
+        m = drop_path_mask_source(B, keep, device)
+    else:
+        m = torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep)
+    if keep > 0.0 and scale_by_keep:
+        m = m / keep
+    return m
+
+
+class DropoutD8(nn.Module):
+    """d8_layers.py:84-96 — independent element masks on each of the five tensors."""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.dropout = nn.Dropout(p=p, inplace=inplace)
+
+    @property
+    def active(self):
+        return self.training and self.dropout.p > 0.0
+
+    def forward(self, xs):
+        if not self.active:
+            return xs
+        return tuple(self.dropout(x) for x in xs[:5])
+
+
+class TritonGeluD8(nn.Module):
+    """d8_gelu.py:480-482 (name kept for drop-in; the kernel is HIP, not Triton)."""
+
+    def forward(self, xs):
+        if isinstance(xs, Octic):
+            return Octic(OF.GeluD8PackedFn.apply(xs.packed, xs.c), xs.c)
+        return OF.GeluD8Function.apply(xs[0], xs[1], xs[2], xs[3], xs[4])
+
+
+class GeluD8(nn.Module):
+    """d8_layers.py:98-102 — 8-tuple in / 8-tuple out."""
+
+    def forward(self, xs):
+        return convert_5tuple_to_8tuple(TritonGeluD8()(convert_8tuple_to_5tuple(xs)))
+
+
+_IRREPS = ("A1", "A2", "B1", "B2", "E")
+
+
+class LinearD8(nn.Module):
+    """d8_layers.py:104-130.  One irrep-blocked MFMA launch instead of five nn.Linear calls; the
+    nn.Linear submodules only hold the parameters (state_dict keys lin_{A1,A2,B1,B2,E}.weight, lin_A1.bias).
+    Optional ``resid/rs/cs`` fuse ``resid + drop_path(gamma * y)`` into the GEMM epilogue."""
+
+    def __init__(self, input_channels, output_channels, bias=True):
+        super().__init__()
+        if input_channels % 8 != 0 or output_channels % 8 != 0:
+            raise ValueError()
+        self.bias = bias
+        self.input_channels, self.output_channels = input_channels, output_channels
+        ci, co = input_channels // 8, output_channels // 8
+        self.lin_A1 = nn.Linear(ci, co, bias=bias)
+        self.lin_A2 = nn.Linear(ci, co, bias=False)
+        self.lin_B1 = nn.Linear(ci, co, bias=False)
+        self.lin_B2 = nn.Linear(ci, co, bias=False)
+        self.lin_E = nn.Linear(2 * ci, 2 * co, bias=False)
+        self._prep = OF.WeightPrep()
+
+    def weights(self):
+        return tuple(getattr(self, "lin_" + n).weight for n in _IRREPS)
+
+    def forward(self, x_batched, resid=None, rs=None, cs=None):
+        assert len(x_batched) == 5, "Input should be a 5-tuple"
+        xp, cin = as_packed(x_batched)
+        if 8 * cin != self.input_channels:
+            raise ValueError(f"LinearD8: expected {self.input_channels} channels, got {8 * cin}")
+        cout = self.output_channels // 8
+        dtype = compute_dtype(xp)
+        rps = xp.shape[-2] if xp.dim() >= 2 else 1
+        cs5 = (None,) * 5 if cs is None else tuple(cs)
+        y = OF.LinearD8Fn.apply(xp, *self.weights(), self.lin_A1.bias, resid, rs, *cs5, cin, cout, rps, dtype, self._prep)
+        return Octic(y, cout)
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.input_channels}, out_features={self.output_channels}, bias={self.bias is not None}"
+
+
+class AffineD8(nn.Module):
+    """d8_layers.py:132-158."""
+
+    def __init__(self, dim, bias=True):
+        super().__init__()
+        if dim % 8 != 0:
+            raise ValueError()
+        self.alpha_A1 = nn.Parameter(torch.ones(dim // 8))
+        self.alpha_A2 = nn.Parameter(torch.ones(dim // 8))
+        self.alpha_B1 = nn.Parameter(torch.ones(dim // 8))
+        self.alpha_B2 = nn.Parameter(torch.ones(dim // 8))
+        self.alpha_E = nn.Parameter(torch.ones(dim // 4))
+        self.beta = nn.Parameter(torch.zeros(dim // 8)) if bias else None
+
+    def alphas(self):
+        return (self.alpha_A1, self.alpha_A2, self.alpha_B1, self.alpha_B2, self.alpha_E)
+
+    def packed_scale(self):
+        return torch.cat(self.alphas() + (self.alpha_E,))
+
+    def forward(self, xs):
+        # stand-alone use (inside blocks the scale is fused into the GEMM epilogue)
+        xp, c = as_packed(xs)
+        y = xp * self.packed_scale().to(xp.dtype)
+        if self.beta is not None:
+            y = torch.cat((y[..., :c] + self.beta.to(y.dtype), y[..., c:]), dim=-1)
+        return Octic(y.contiguous(), c)
+
+
+class LayerScaleD8(nn.Module):
+    """d8_layers.py:189-212."""
+
+    def __init__(self, dim, init_values=1e-5):
+        super().__init__()
+        if dim % 8 != 0:
+            raise ValueError()
+        self.alpha_A1 = nn.Parameter(init_values * torch.ones(dim // 8))
+        self.alpha_A2 = nn.Parameter(init_values * torch.ones(dim // 8))
+        self.alpha_B1 = nn.Parameter(init_values * torch.ones(dim // 8))
+        self.alpha_B2 = nn.Parameter(init_values * torch.ones(dim // 8))
+        self.alpha_E = nn.Parameter(init_values * torch.ones(dim // 4))
+
+    def alphas(self):
+        return (self.alpha_A1, self.alpha_A2, self.alpha_B1, self.alpha_B2, self.alpha_E)
+
+    def forward(self, xs):
+        xp, c = as_packed(xs)
+        return Octic((xp * torch.cat(self.alphas() + (self.alpha_E,)).to(xp.dtype)).contiguous(), c)
+
+
+class LayerNormD8(nn.Module):
+    """d8_layers.py:161-186 (eps inside the root, per-segment means, shared std, AffineD8 on top)."""
+
+    def __init__(self, channels, eps=1e-05, elementwise_affine=True, bias=True):
+        super().__init__()
+        self.scaling = AffineD8(channels, bias=bias) if elementwise_affine else nn.Identity()
+        self.eps = eps
+
+    def forward(self, xs, _out_dtype=None):
+        xp, c = as_packed(xs)
+        out_dtype = _out_dtype or xp.dtype
+        if isinstance(self.scaling, AffineD8):
+            a, beta = self.scaling.alphas(), self.scaling.beta
+        else:
+            a, beta = (None,) * 5, None
+        return Octic(OF.LayerNormD8Fn.apply(xp, *a, beta, self.eps, c, out_dtype), c)
+
+
+class MlpD8(nn.Module):
+    """d8_layers.py:215-247."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=TritonGeluD8, norm_layer=None,
+                 bias=True, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        bias = to_2tuple(bias)
+        drop_probs = to_2tuple(drop)
+        self.fc1 = LinearD8(in_features, hidden_features, bias=bias[0])
+        self.act = act_layer()
+        self.drop1 = DropoutD8(drop_probs[0])
+        self.norm = norm_layer(hidden_features) if norm_layer is not None else nn.Identity()
+        self.fc2 = LinearD8(hidden_features, out_features, bias=bias[1])
+        self.drop2 = DropoutD8(drop_probs[1])
+
+    def forward(self, xs, resid=None, rs=None, cs=None):
+        xs = self.norm(self.drop1(self.act(self.fc1(xs))))
+        if self.drop2.active or resid is None:
+            return _tail(self.drop2(self.fc2(xs)), resid, rs, cs)
+        return self.fc2(xs, resid=resid, rs=rs, cs=cs)
+
+
+def _tail(ys, resid, rs, cs):
+    """Unfused ``resid + rs*cs*y`` (only reached with dropout p>0 or foreign sub-modules)."""
+    if resid is None:
+        return ys
+    yp, c = as_packed(ys)
+    yp = yp.to(resid.dtype)
+    if cs is not None:
+        yp = yp * torch.cat(tuple(cs) + (cs[4],)).to(yp.dtype)
+    if rs is not None:
+        yp = yp * rs.view(-1, *([1] * (yp.dim() - 1))).to(yp.dtype)
+    return Octic((resid + yp).contiguous(), c)
+
+
+def drop_path_d8(xs, drop_prob: float = 0., training: bool = False, scale_by_keep: bool = True):
+    """d8_layers.py:249-271 — one Bernoulli mask per sample, shared by the five tensors."""
+    if drop_prob == 0. or not training:
+        return xs
+    xp, c = as_packed(xs)
+    m = _drop_path_mask(xp.shape[0], drop_prob, xp.device, scale_by_keep)
+    return Octic((xp * m.view(-1, *([1] * (xp.dim() - 1))).to(xp.dtype)).contiguous(), c)
+
+
+class DropPathD8(nn.Module):
+    def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def mask(self, B, device):
+        """Per-sample scale for the fused epilogue, or None when inactive."""
+        if self.drop_prob == 0. or not self.training:
+            return None
+        return _drop_path_mask(B, self.drop_prob, device, self.scale_by_keep)
+
+    def forward(self, xs):
+        return drop_path_d8(xs, self.drop_prob, self.training, self.scale_by_keep)
+
+
+# ------------------------------------------------------------------------------------------ lift
+class LiftIrrepD8Conv2d(nn.Module):
+    """d8_layers.py:284-382.  Holds the learned (p/2)x(p/2) quarter kernel; ``expand_weight`` builds the
+    p x p kernel by symmetry (index gather, see d8_utils.expand_lift_kernel).  The convolution itself is
+    executed by LiftD8 as one GEMM over all irreps."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, bias, irrep="A1"):
+        super().__init__()
+        if irrep not in ["A1", "A2", "B1", "B2", "E"]:
+            raise ValueError("Invalid irrep.")
+        if bias and not (irrep == "A1"):
+            raise ValueError("Bias only ok for A1-irrep.")
+        kernel_size = to_2tuple(kernel_size)
+        if kernel_size[0] != kernel_size[1]:
+            raise NotImplementedError("Non-square kernels not implemented")
+        if kernel_size[0] % 2 != 0 or kernel_size[1] % 2 != 0:
+            raise NotImplementedError("Odd kernel sizes not yet implemented")
+        if (kernel_size[0] == 2 or kernel_size[1] == 2) and irrep in ["A2", "B1"]:
+            raise ValueError(f"No {irrep} irrep in filter kernels of size 2.")
+        self.kernel_size, self.stride, self.irrep = kernel_size, stride, irrep
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size[0] // 2, kernel_size[1] // 2))
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.weight.shape[1] * self.weight.shape[2] * self.weight.shape[3]
+            if fan_in != 0:
+                bound = 1 / math.sqrt(fan_in)
+                nn.init.uniform_(self.bias, -bound, bound)
+
+    def expand_weight(self):
+        return expand_lift_kernel(self.weight, self.irrep)
+
+    def kernels(self):
+        """Full kernel(s) of this conv: one for the 1-D irreps, (K, rot90 K) for E (d8_layers.py:377-381)."""
+        k = self.expand_weight()
+        return (k, k.rot90(k=1, dims=(-2, -1))) if self.irrep == "E" else (k,)
+
+    def forward(self, x):
+        # stand-alone use of a single irrep conv: same GEMM engine with this irrep's rows only
+        ks = self.kernels()
+        w = torch.cat([k.flatten(1) for k in ks], 0)
+        D = w.shape[0]
+        bias = None
+        if self.bias is not None:
+            bias = self.bias
+        p = self.kernel_size[0]
+        if self.stride != p and tuple(to_2tuple(self.stride)) != tuple(self.kernel_size):
+            raise NotImplementedError("lift engine implements stride == kernel_size (patch embedding)")
+        if D % 8:
+            raise ValueError("out_channels must be a multiple of 8 for the HIP lift")
+        out = OF.LiftFn.apply(x, w, bias if bias is None else torch.cat([bias] * len(ks)), None, None, p,
+                              compute_dtype(x))
+        B, _, Hh, Ww = x.shape
+        maps = out.reshape(B, Hh // p, Ww // p, D).permute(0, 3, 1, 2)
+        o = self.weight.shape[0]
+        return (maps[:, :o], maps[:, o:]) if self.irrep == "E" else maps
+
+
+class LiftD8(nn.Module):
+    """d8_layers.py:384-411."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, bias):
+        super().__init__()
+        if out_channels % 8 != 0:
+            raise ValueError()
+        outs = out_channels // 8
+        self.conv_A1 = LiftIrrepD8Conv2d(in_channels, outs, kernel_size, stride, bias=bias, irrep="A1")
+        self.conv_A2 = LiftIrrepD8Conv2d(in_channels, outs, kernel_size, stride, bias=False, irrep="A2")
+        self.conv_B1 = LiftIrrepD8Conv2d(in_channels, outs, kernel_size, stride, bias=False, irrep="B1")
+        self.conv_B2 = LiftIrrepD8Conv2d(in_channels, outs, kernel_size, stride, bias=False, irrep="B2")
+        self.conv_E_left = LiftIrrepD8Conv2d(in_channels, outs, kernel_size, stride, bias=False, irrep="E")
+        self.conv_E_right = LiftIrrepD8Conv2d(in_channels, outs, kernel_size, stride, bias=False, irrep="E")
+
+    def packed_weight(self):
+        """[8c, Cin*p*p] kernel matrix with rows in packed channel order A1|A2|B1|B2|E_row0|E_row1:
+        E_row0 = (E_left K, E_right K), E_row1 = (E_left rot K, E_right rot K)."""
+        el, er = self.conv_E_left.kernels(), self.conv_E_right.kernels()
+        ks = [self.conv_A1.expand_weight(), self.conv_A2.expand_weight(), self.conv_B1.expand_weight(),
+              self.conv_B2.expand_weight(), el[0], er[0], el[1], er[1]]
+        return torch.cat([k.flatten(1) for k in ks], dim=0)
+
+    def packed_bias(self):
+        if self.conv_A1.bias is None:
+            return None
+        c = self.conv_A1.bias.shape[0]
+        return torch.cat((self.conv_A1.bias, self.conv_A1.bias.new_zeros(7 * c)))
+
+    def tokens(self, img, pos=None, cls_row=None):
+        """Packed tokens [B, (1+)G*G, 8c] f32 (+ unfolded positional embedding and cls row, fused)."""
+        p = self.conv_A1.kernel_size[0]
+        return OF.LiftFn.apply(img, self.packed_weight(), self.packed_bias(), pos, cls_row, p, compute_dtype(img))
+
+    def forward(self, img):
+        B, _, Hh, Ww = img.shape
+        p = self.conv_A1.kernel_size[0]
+        out = self.tokens(img)
+        c = out.shape[-1] // 8
+        maps = out.reshape(B, Hh // p, Ww // p, 8 * c).permute(0, 3, 1, 2)
+        a = [maps[:, i * c:(i + 1) * c] for i in range(8)]
+        # packed order is (.., x4|x6, x5|x7): back to the reference's (x4, x5, x6, x7)
+        return (a[0], a[1], a[2], a[3], a[4], a[6], a[5], a[7])
+
+
+class PatchEmbedD8(nn.Module):
+    """d8_layers.py:413-497."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True,
+                 bias=True, strict_img_size=True):
+        super().__init__()
+        self.patch_size = to_2tuple(patch_size)
+        self.img_size, self.grid_size, self.num_patches = self._init_img_size(img_size)
+        if embed_dim % 8 != 0:
+            raise ValueError()
+        self.flatten = flatten
+        self.strict_img_size = strict_img_size
+        self.lift8 = LiftD8(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size, bias=bias)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def _init_img_size(self, img_size):
+        assert self.patch_size
+        if img_size is None:
+            return None, None, None
+        img_size = to_2tuple(img_size)
+        grid_size = tuple([s // p for s, p in zip(img_size, self.patch_size)])
+        return img_size, grid_size, grid_size[0] * grid_size[1]
+
+    def _check(self, x):
+        _, _, H, W = x.shape
+        if self.img_size is not None:
+            if self.strict_img_size:
+                assert H == self.img_size[0], f"Input height ({H}) doesn't match model ({self.img_size[0]})."
+                assert W == self.img_size[1], f"Input width ({W}) doesn't match model ({self.img_size[1]})."
+            else:
+                patch_W, patch_H = self.patch_size
+                assert H % (patch_H * 2) == 0, f"Input image height {H} is not an even multiple of patch height {patch_H}"
+                assert W % (patch_W * 2) == 0, f"Input image width {W} is not an even multiple of patch width: {patch_W}"
+
+    def tokens(self, x, pos=None, cls_row=None):
+        self._check(x)
+        return self.lift8.tokens(x, pos, cls_row)
+
+    def forward(self, x):
+        self._check(x)
+        if not self.flatten:
+            xs = self.lift8(x)
+            return self.norm(convert_8tuple_to_5tuple(xs))
+        t = self.lift8.tokens(x)
+        return self.norm(Octic(t, t.shape[-1] // 8))
+
+    def _init_weights(self):
+        for conv in (self.lift8.conv_A1, self.lift8.conv_A2, self.lift8.conv_B1, self.lift8.conv_B2,
+                     self.lift8.conv_E_left, self.lift8.conv_E_right):
+            w = conv.weight.data
+            torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+
+
+class IsotypicToPatchD8(nn.Module):
+    """d8_layers.py:499-588 — irrep features back to pixel patches (not on the training path; the
+    linear is the HIP LinearD8, the symmetric unfolding is index glue)."""
+
+    def __init__(self, dim, patch_side, out_channels=3, bias=True, reshape_to_image=False):
+        super().__init__()
+        if patch_side % 2 != 0:
+            raise NotImplementedError("Odd patch side not implemented.")
+        self.dim, self.patch_side, self.out_channels = dim, patch_side, out_channels
+        self.reshape_to_image = reshape_to_image
+        self.lin8 = LinearD8(dim, 2 * (patch_side ** 2 * out_channels), bias=bias)
+
+    def forward(self, xs):
+        from .d8_utils import unfold_quarter, unfold_quarter_e_img
+        B, L, _ = xs[0].shape
+        h = self.patch_side // 2
+        q = [0.25 * t.reshape(B, L, h, h, self.out_channels) for t in convert_5tuple_to_8tuple(self.lin8(xs))]
+        out = sum(unfold_quarter(q[i], n, 2, 3) for i, n in enumerate(("A1", "A2", "B1", "B2")))
+        out = out + unfold_quarter_e_img(SQRT2 * q[4]) + unfold_quarter_e_img(SQRT2 * q[5]).rot90(k=1, dims=(2, 3))
+        if self.reshape_to_image:
+            H = W = int(math.sqrt(L))
+            p = self.patch_side
+            out = out.reshape(B, H, W, p, p, self.out_channels).permute(0, 5, 1, 3, 2, 4)
+            return out.reshape(B, self.out_channels, H * p, W * p)
+        return out.reshape(B, L, self.patch_side ** 2 * self.out_channels)
+
+
+# ------------------------------------------------------------------------------------- attention
+class AttentionD8(nn.Module):
+    """d8_layers.py:590-660.  qkv/proj are irrep-blocked GEMMs, head pack/unpack are HIP permutation
+    kernels, the softmax core is torch SDPA exactly as in the reference (scale = SDPA default;
+    ``self.scale`` is stored but unused there too)."""
+
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = True, proj_bias: bool = True,
+                 attn_drop: float = 0.0, proj_drop: float = 0.0, rope=None, qk_scale=None):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        assert (dim // num_heads) % 8 == 0, "dim should be divisible by 8"
+        if rope is not None:
+            raise NotImplementedError("RoPE not implemented")
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = LinearD8(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = LinearD8(dim, dim, bias=proj_bias)
+        self.proj_drop = DropoutD8(proj_drop)
+        self.rope = rope
+        self.att = F.scaled_dot_product_attention
+
+    def forward(self, xs, resid=None, rs=None, cs=None):
+        xp, c = as_packed(xs)
+        if xp.dim() != 3:
+            raise ValueError("AttentionD8 expects [B, N, C] irreps")
+        qkv = self.qkv(xs if isinstance(xs, Octic) else Octic(xp, c))
+        heads = OF.PackHeadsFn.apply(qkv.packed, self.num_heads, c)
+        o = self.att(heads[0], heads[1], heads[2], dropout_p=self.attn_drop.p if self.training else 0.)
+        on = Octic(OF.UnpackHeadsFn.apply(o, c), c)
+        if self.proj_drop.active or resid is None:
+            return _tail(self.proj_drop(self.proj(on)), resid, rs, cs)
+        return self.proj(on, resid=resid, rs=rs, cs=cs)
+
+
+def _branch(norm, fn, xs_packed, c, rs, cs, out_dtype):
+    """x + drop_path(cs * fn(norm(x))) with the tail fused into fn's last GEMM when fn supports it."""
+    x = Octic(xs_packed, c)
+    try:
+        xn = norm(x, _out_dtype=out_dtype)
+    except TypeError:  # foreign norm layer
+        xn = norm(x)
+    try:
+        return fn(xn, resid=xs_packed, rs=rs, cs=cs)
+    except TypeError:  # foreign attention / mlp class: compose
+        return _tail(fn(xn), xs_packed, rs, cs)
+
+
+class Layer_scale_init_BlockD8(nn.Module):
+    """d8_layers.py:665-707 (DeiT-III block; gamma_{1,2} = AffineD8(bias=False), one drop_path module
+    used twice = two independent per-sample masks)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4, qkv_bias=False, qk_scale=None, attn_drop=0., drop=0.,
+                 drop_path=0., act_layer=TritonGeluD8, norm_layer=LayerNormD8, Attention_block=AttentionD8,
+                 Mlp_block=MlpD8, init_values=1e-4):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention_block(dim=dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                    attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPathD8(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp_block(in_features=dim, hidden_features=int(mlp_ratio * dim), act_layer=act_layer, drop=drop)
+        self.gamma_1 = AffineD8(dim, bias=False)
+        self.gamma_2 = AffineD8(dim, bias=False)
+        with torch.no_grad():
+            for p in list(self.gamma_1.parameters()) + list(self.gamma_2.parameters()):
+                p.fill_(init_values)
+
+    def _mask(self, B, device):
+        return self.drop_path.mask(B, device) if isinstance(self.drop_path, DropPathD8) else None
+
+    def forward(self, xs):
+        xp, c = as_packed(xs)
+        dt = compute_dtype(xp)
+        x1 = _branch(self.norm1, self.attn, xp, c, self._mask(xp.shape[0], xp.device), self.gamma_1.alphas(), dt)
+        x2 = _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(), dt)
+        return x2
+
+
+class BlockD8(nn.Module):
+    """d8_layers.py:713-776 (DINOv2 / model-default block; ls{1,2} = LayerScaleD8, drop_path{1,2})."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qkv_bias: bool = False,
+                 proj_bias: bool = True, ffn_bias: bool = True, drop: float = 0.0, attn_drop: float = 0.0,
+                 init_values=None, drop_path: float = 0.0, act_layer=TritonGeluD8, norm_layer=LayerNormD8,
+                 attn_class=AttentionD8, ffn_layer=MlpD8) -> None:
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = attn_class(dim, num_heads=num_heads, qkv_bias=qkv_bias, proj_bias=proj_bias, attn_drop=attn_drop,
+                               proj_drop=drop)
+        self.ls1 = LayerScaleD8(dim, init_values=init_values) if init_values else nn.Identity()
+        self.drop_path1 = DropPathD8(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = ffn_layer(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop,
+                             bias=ffn_bias)
+        self.ls2 = LayerScaleD8(dim, init_values=init_values) if init_values else nn.Identity()
+        self.drop_path2 = DropPathD8(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.sample_drop_ratio = drop_path
+
+    def forward(self, xs):
+        xp, c = as_packed(xs)
+        dt = compute_dtype(xp)
+        B, dev = xp.shape[0], xp.device
+        m1 = self.drop_path1.mask(B, dev) if isinstance(self.drop_path1, DropPathD8) else None
+        cs1 = self.ls1.alphas() if isinstance(self.ls1, LayerScaleD8) else None
+        x1 = _branch(self.norm1, self.attn, xp, c, m1, cs1, dt)
+        m2 = self.drop_path2.mask(B, dev) if isinstance(self.drop_path2, DropPathD8) else None
+        cs2 = self.ls2.alphas() if isinstance(self.ls2, LayerScaleD8) else None
+        return _branch(self.norm2, self.mlp, x1.packed, c, m2, cs2, dt)
+
+
+class NestedTensorBlockD8(BlockD8):
+    """d8_layers.py:780-794 — a list of crops is looped over."""
+
+    def forward_nested(self, x_list):
+        return [super(NestedTensorBlockD8, self).forward(x) for x in x_list]
+
+    def forward(self, x_or_x_list):
+        if isinstance(x_or_x_list, tuple):
+            return super().forward(x_or_x_list)
+        elif isinstance(x_or_x_list, list):
+            return self.forward_nested(x_or_x_list)
+        raise AssertionError

@@ -1,0 +1,224 @@
+"""D8 helpers of the product package (reference: octic_vits/d8_utils.py).
+
+Host-side glue only (tiny tensors: group tables, weight/pos-embed symmetric unfolding).  Unlike the
+reference's chains of rot90/flip/cat, unfolding here is ONE gather with precomputed closed-form
+index/sign tables per (quarter size, irrep) — cached, autograd-friendly, and cheap enough to run every
+step for the 6 quarter kernels and 6 positional grids.
+"""
+import math
+from functools import lru_cache
+
+import torch
+
+SQRT2 = math.sqrt(2)
+SQRT2_OVER_2 = 0.5 * SQRT2
+SQRT2_OVER_4 = 0.5 * SQRT2_OVER_2
+
+group_elements = ("e", "r", "rr", "rrr", "m", "mr", "mrr", "mrrr")
+irreps = ("A1", "A2", "B1", "B2", "E11", "E21", "E21", "E22")
+
+# --------------------------------------------------------------------------------------------
+# Group actions as (source index, sign) tables, generated from the two generators
+#   r: iso (x0,x1,-x2,-x3,-x5,x4,-x7,x6)   reg (x1,x2,x3,x0,x7,x4,x5,x6)      (d8_utils.py:99-109,182-192)
+#   m: iso (x0,-x1,x2,-x3,-x4,x5,-x6,x7)   reg (x4,x5,x6,x7,x0,x1,x2,x3)      (d8_utils.py:132-142,215-225)
+# "m r^k" = r applied k times, then m.
+# --------------------------------------------------------------------------------------------
+_GEN = {
+    "iso": {"r": ((0, 1, 2, 3, 5, 4, 7, 6), (1, 1, -1, -1, -1, 1, -1, 1)),
+            "m": ((0, 1, 2, 3, 4, 5, 6, 7), (1, -1, 1, -1, -1, 1, -1, 1))},
+    "reg": {"r": ((1, 2, 3, 0, 7, 4, 5, 6), (1,) * 8),
+            "m": ((4, 5, 6, 7, 0, 1, 2, 3), (1,) * 8)},
+}
+
+
+def _compose(first, then):
+    """table of: apply `first`, then `then`."""
+    (p1, s1), (p2, s2) = first, then
+    return tuple(p1[p2[i]] for i in range(8)), tuple(s2[i] * s1[p2[i]] for i in range(8))
+
+
+def _build_tables(kind):
+    ident = (tuple(range(8)), (1,) * 8)
+    tabs = {}
+    for g in group_elements:
+        t = ident
+        for _ in range(g.count("r")):
+            t = _compose(t, _GEN[kind]["r"])
+        if g.startswith("m"):
+            t = _compose(t, _GEN[kind]["m"])
+        tabs[g] = t
+    return tabs
+
+
+_ISO, _REG = _build_tables("iso"), _build_tables("reg")
+
+
+def _apply_table(tab, g, xs):
+    if g not in tab:
+        raise ValueError("Invalid group element")
+    perm, sign = tab[g]
+    return tuple(xs[p] if s > 0 else -xs[p] for p, s in zip(perm, sign))
+
+
+def isotypic_group_action(group_element, xs):
+    return _apply_table(_ISO, group_element, xs)
+
+
+def regular_group_action(group_element, xs):
+    return _apply_table(_REG, group_element, xs)
+
+
+def image_space_group_action(group_element, img):
+    if group_element not in group_elements:
+        raise ValueError("Invalid group element")
+    k = group_element.count("r")
+    if k:
+        img = img.rot90(k=k, dims=(-2, -1))
+    return img.flip(-1) if group_element.startswith("m") else img
+
+
+def spatial_and_isotypic_group_action(group_element, xs):
+    B, L, C = xs[0].shape
+    H = W = int(math.sqrt(L))
+    return isotypic_group_action(group_element, tuple(
+        image_space_group_action(group_element, x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
+        for x in xs))
+
+
+def _mult_table():
+    inv = {v[0]: k for k, v in _REG.items()}
+    return [[g1, g2, inv[_compose(_REG[g2], _REG[g1])[0]]] for g1 in group_elements[1:] for g2 in group_elements[1:]]
+
+
+mult_table = _mult_table()
+
+# --------------------------------------------------------------------------------------------
+# Fourier transform between isotypic and regular coordinates (d8_utils.py:276-356)
+# --------------------------------------------------------------------------------------------
+_S_ISO2REG = (
+    (1, 1, 1, 1, 1, 1, 1, -1), (1, 1, -1, -1, 1, -1, -1, -1), (1, 1, 1, 1, -1, -1, -1, 1), (1, 1, -1, -1, -1, 1, 1, 1),
+    (1, -1, 1, -1, -1, 1, -1, -1), (1, -1, -1, 1, -1, -1, 1, -1), (1, -1, 1, -1, 1, -1, 1, 1), (1, -1, -1, 1, 1, 1, -1, 1))
+
+
+def _signed_sum(rows, xs):
+    out = []
+    for row in rows:
+        acc = None
+        for s, x in zip(row, xs):
+            acc = (x if s > 0 else -x) if acc is None else (acc + x if s > 0 else acc - x)
+        out.append(SQRT2_OVER_4 * acc)
+    return tuple(out)
+
+
+def isotypic_to_regular_D8(xs):
+    return _signed_sum(_S_ISO2REG, xs)
+
+
+def regular_to_isotypic_D8(xs):
+    return _signed_sum(tuple(zip(*_S_ISO2REG)), xs)
+
+
+def convert_8tuple_to_5tuple(xs):
+    return (xs[0], xs[1], xs[2], xs[3],
+            torch.stack((torch.cat((xs[4], xs[6]), dim=-1), torch.cat((xs[5], xs[7]), dim=-1)), dim=-2))
+
+
+def convert_5tuple_to_8tuple(xs):
+    e = xs[4]
+    c = e.shape[-1] // 2
+    return (xs[0], xs[1], xs[2], xs[3], e[..., 0, :c], e[..., 1, :c], e[..., 0, c:], e[..., 1, c:])
+
+
+# --------------------------------------------------------------------------------------------
+# Symmetric unfolding of a quarter [h,h] to the full [2h,2h] grid as gather tables.
+# With P = 2h and W the quadrant assembly (top-left q, bottom-left s*rot90(q), top-right s*rot270(q),
+# bottom-right rot180(q); s = -1 for B1/B2):
+#     W[i,j] = q[i,j] | s q[j,P-1-i] | s q[P-1-j,i] | q[P-1-i,P-1-j]       (by quadrant)
+#     A1,B1: full = W + W[:, ::-1]      A2,B2: full = W - W[:, ::-1]          (d8_layers.py:338-373)
+#     E:     full[i,j] = t q[i',j'],  i' = i or P-1-i,  j' = j or P-1-j,  t = -1 on the right half
+# --------------------------------------------------------------------------------------------
+@lru_cache(maxsize=None)
+def _unfold_tables(h: int, kind: str):
+    P = 2 * h
+    i = torch.arange(P).view(P, 1).expand(P, P)
+    j = torch.arange(P).view(1, P).expand(P, P)
+
+    def quadrant(i, j, s):
+        top, left = i < h, j < h
+        si = torch.where(top & left, i, torch.where(~top & left, j, torch.where(top & ~left, P - 1 - j, P - 1 - i)))
+        sj = torch.where(top & left, j, torch.where(~top & left, P - 1 - i, torch.where(top & ~left, i, P - 1 - j)))
+        sg = torch.where(top ^ left, torch.full_like(i, s), torch.ones_like(i))
+        return si * h + sj, sg
+
+    if kind == "E":
+        si = torch.where(i < h, i, P - 1 - i)
+        sj = torch.where(j < h, j, P - 1 - j)
+        sg = torch.where(j < h, torch.ones_like(i), -torch.ones_like(i))
+        return (si * h + sj).flatten(), sg.flatten().float(), None, None
+    s = -1 if kind in ("B1", "B2") else 1
+    ia, sa = quadrant(i, j, s)
+    ib, sb = quadrant(i, P - 1 - j, s)
+    if kind in ("A2", "B2"):
+        sb = -sb
+    return ia.flatten(), sa.flatten().float(), ib.flatten(), sb.flatten().float()
+
+
+def _gather_unfold(flat, dim, h, kind):
+    """flat: tensor whose dimension `dim` enumerates the h*h quarter; returns it with (2h)^2 entries."""
+    ia, sa, ib, sb = _unfold_tables(h, kind)
+    dev = flat.device
+    shape = [1] * flat.dim()
+    shape[dim] = -1
+    out = flat.index_select(dim, ia.to(dev)) * sa.to(dev, flat.dtype).view(shape)
+    if ib is not None:
+        out = out + flat.index_select(dim, ib.to(dev)) * sb.to(dev, flat.dtype).view(shape)
+    return out
+
+
+def unfold_quarter(q, kind, d0, d1):
+    """Unfold dims (d0, d1=d0+1) of q from [h,h] to [2h,2h] (no scaling)."""
+    d0 = d0 % q.dim()
+    assert d1 % q.dim() == d0 + 1 and q.shape[d0] == q.shape[d0 + 1]
+    h = q.shape[d0]
+    full = _gather_unfold(q.flatten(d0, d0 + 1), d0, h, kind)
+    return full.unflatten(d0, (2 * h, 2 * h))
+
+
+def unfold_quarter_e_img(t):
+    """IsotypicToPatchD8's E assembly over dims (2,3) (d8_layers.py:561-567) — the same table as the lift's E."""
+    return unfold_quarter(t, "E", 2, 3)
+
+
+def expand_lift_kernel(weight, irrep):
+    """LiftIrrepD8Conv2d.expand_weight (d8_layers.py:329-373): [o,i,h,h] -> [o,i,2h,2h]."""
+    scale = 0.5 if irrep == "E" else SQRT2_OVER_4
+    return unfold_quarter(scale * weight, irrep, -2, -1)
+
+
+def isotypic_dim_interpolation(xs, dim: int = 0):
+    """d8_utils.py:388-451: 6 quarter grids [.., G/2, G/2, c] -> 8 full grids [.., G, G, c]."""
+    d0, d1 = dim, dim + 1
+    el, er = unfold_quarter(xs[4], "E", d0, d1), unfold_quarter(xs[5], "E", d0, d1)
+    return (unfold_quarter(xs[0], "A1", d0, d1), unfold_quarter(xs[1], "A2", d0, d1),
+            unfold_quarter(xs[2], "B1", d0, d1), unfold_quarter(xs[3], "B2", d0, d1),
+            el, el.rot90(dims=(d0, d1)), er, er.rot90(dims=(d0, d1)))
+
+
+def packed_pos_embed(pos_params):
+    """Unfolded positional embedding as packed rows [G*G, 8c] (order A1|A2|B1|B2|x4|x6|x5|x7)."""
+    a = isotypic_dim_interpolation(tuple(pos_params), dim=0)
+    return torch.cat([t.flatten(0, 1) for t in (a[0], a[1], a[2], a[3], a[4], a[6], a[5], a[7])], dim=-1)
+
+
+def interpolate_spatial_tuple(xs, interpolant, h: int, w: int, patch_size):
+    """d8_utils.py:453-499.  Native resolution: returned untouched.  (The reference's resize branch raises
+    TypeError as shipped because patch_size is a tuple; the integer-side intent is implemented.)"""
+    n_native = interpolant[0].shape[0] ** 2
+    if xs[0].shape[1] == n_native and w == h:
+        return interpolant
+    p = patch_size[0] if isinstance(patch_size, (tuple, list)) else patch_size
+    stacked = torch.stack([t.float().reshape(t.shape[0], t.shape[1], -1) for t in interpolant], 0)
+    out = torch.nn.functional.interpolate(stacked.permute(0, 3, 1, 2), size=(h // p, w // p), mode="bicubic",
+                                          antialias=False).permute(0, 2, 3, 1)
+    return [out[i].reshape(out.shape[1], out.shape[2], *interpolant[i].shape[2:]).to(xs[0].dtype)
+            for i in range(len(interpolant))]

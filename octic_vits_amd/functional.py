@@ -1,0 +1,290 @@
+"""Autograd wrappers of the HIP engine (the PyTorch-ROCm custom-op surface).
+
+Every hot op of the octic block is one ``torch.autograd.Function`` whose forward AND backward are
+launches of hand-written gfx950 kernels through the C ABI (``ops.py`` → ``liboctic_hip.so``).
+The engine's native tensor is the *packed* token row ``[B, T, 8c] = [A1|A2|B1|B2|E_row0|E_row1]``;
+``Octic`` wraps it as the reference's 5-tuple (zero-copy views) so modules stay drop-in.
+
+Precision follows the caller like the reference does: plain fp32 tensors run the exact-f32 MFMA
+path (used for the reference's fp32 equivariance tolerances); under
+``torch.autocast('cuda', dtype=torch.bfloat16)`` linears/GELU/attention run in bf16 with f32
+accumulation while the residual stream, LayerNorm statistics and parameter gradients stay f32
+(that is what autocast does to the reference).
+"""
+import torch
+
+from . import ops
+
+
+class Octic(tuple):
+    """The reference's 5-tuple (A1,A2,B1,B2:[B,T,c]; E:[B,T,2,2c]) as views of one packed tensor."""
+
+    def __new__(cls, packed: torch.Tensor, c: int):
+        self = super().__new__(cls, ops.split_packed(packed, c))
+        self.packed, self.c = packed, c
+        return self
+
+
+def as_packed(xs):
+    """Packed [.., 8c] tensor of an Octic (free) or of any reference-style 5-tuple (one torch.cat)."""
+    if isinstance(xs, Octic):
+        return xs.packed, xs.c
+    if len(xs) != 5:
+        raise AssertionError("Input should be a 5-tuple")
+    c = xs[0].shape[-1]
+    if xs[4].shape[-2:] != (2, 2 * c):
+        raise ValueError(f"E irrep must be [..., 2, {2 * c}], got {tuple(xs[4].shape)}")
+    return torch.cat([xs[0], xs[1], xs[2], xs[3], xs[4].flatten(-2)], dim=-1), c
+
+
+def compute_dtype(t: torch.Tensor):
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if dt != torch.bfloat16:
+            raise NotImplementedError("octic engine: autocast is supported with dtype=torch.bfloat16 only")
+        return dt
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"octic engine supports float32 / bfloat16, got {t.dtype}")
+    return t.dtype
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------- GELU
+class GeluD8PackedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        x = _c(x)
+        y = torch.empty_like(x)
+        M = x.numel() // (8 * c)
+        ops.gelu_fwd(ops.pview(x, c), ops.pview(y, c), M, c, x.dtype, x)
+        ctx.save_for_backward(x)
+        ctx.c = c
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        c = ctx.c
+        g = _c(g.to(x.dtype))
+        gi = torch.empty_like(x)
+        ops.gelu_bwd(ops.pview(g, c), ops.pview(x, c), ops.pview(gi, c), x.numel() // (8 * c), c, x.dtype, x)
+        return gi, None
+
+
+class GeluD8Function(torch.autograd.Function):
+    """Drop-in for the reference's one custom-op boundary ``TritonGeluD8Function`` (d8_gelu.py:456-478):
+    five separate tensors in, five out; strides are handed to the kernel, nothing is repacked."""
+
+    @staticmethod
+    def forward(ctx, x_A1, x_A2, x_B1, x_B2, x_2d):
+        xs = tuple(_c(t) for t in (x_A1, x_A2, x_B1, x_B2, x_2d))
+        c = xs[0].shape[-1]
+        ys = tuple(torch.empty_like(t) for t in xs)
+        M = xs[0].numel() // c
+        xv, k1 = ops.tview(xs, c)
+        yv, k2 = ops.tview(ys, c)
+        ops.gelu_fwd(xv, yv, M, c, xs[0].dtype, xs[0])
+        ctx.save_for_backward(*xs)
+        return ys
+
+    @staticmethod
+    def backward(ctx, *gs):
+        xs = ctx.saved_tensors
+        c = xs[0].shape[-1]
+        gs = tuple(_c(g.to(xs[0].dtype)) for g in gs)
+        outs = tuple(torch.empty_like(t) for t in xs)
+        gv, k1 = ops.tview(gs, c)
+        xv, k2 = ops.tview(xs, c)
+        ov, k3 = ops.tview(outs, c)
+        ops.gelu_bwd(gv, xv, ov, xs[0].numel() // c, c, xs[0].dtype, xs[0])
+        return outs
+
+
+# ------------------------------------------------------------------------------------- LayerNorm
+class LayerNormD8Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a1, a2, b1, b2, ae, beta, eps, c, out_dtype):
+        x = _c(x.float())
+        alpha = None if a1 is None else [_c(t.float()) for t in (a1, a2, b1, b2, ae)]
+        y, stats = ops.layernorm_fwd(x, alpha, None if beta is None else _c(beta.float()), eps, out_dtype, c)
+        ctx.save_for_backward(x, stats, *(alpha or []))
+        ctx.c, ctx.has_affine, ctx.has_beta = c, alpha is not None, beta is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats, *alpha = ctx.saved_tensors
+        alpha = alpha if ctx.has_affine else None
+        dx, dal, dbeta = ops.layernorm_bwd(_c(g), x, stats, alpha, None, ctx.c, want_param_grads=ctx.has_affine)
+        if dal is None:
+            dal = [None] * 5
+        return (dx, *dal, dbeta if ctx.has_beta else None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------- Linear
+class WeightPrep:
+    """Compute-dtype copies of a LinearD8's weights: ``wb`` for the forward GEMM and ``wt`` — transposed,
+    with the layer-scale folded in — for the input-gradient GEMM (dX = dY·diag(cs)·W)."""
+
+    def __init__(self):
+        self.key = None
+        self.wb = self.wt = None
+
+    def get(self, w5, cs5, dtype):
+        key = (dtype, tuple((w.data_ptr(), w._version) for w in w5),
+               None if cs5 is None else tuple((s.data_ptr(), s._version) for s in cs5))
+        if key != self.key:
+            with torch.no_grad():
+                self.wb = [_c(w.detach().to(dtype)) for w in w5]
+                if cs5 is None:
+                    self.wt = [_c(w.detach().t().to(dtype)) for w in w5]
+                else:
+                    self.wt = [_c((w.detach() * s.detach()[:, None]).t().to(dtype)) for w, s in zip(w5, cs5)]
+            self.key = key
+        return self.wb, self.wt
+
+
+class LinearD8Fn(torch.autograd.Function):
+    """y = resid + rs*cs*(x W^T + b)   (resid / rs / cs optional).  See octic_hip.h for the math."""
+
+    @staticmethod
+    def forward(ctx, x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps, dtype, prep):
+        w5 = (wA1, wA2, wB1, wB2, wE)
+        cs5 = None if sA1 is None else (sA1, sA2, sB1, sB2, sE)
+        fused = resid is not None
+        out_dtype = resid.dtype if fused else dtype
+        x_in_dtype = x.dtype
+        if x.dtype != dtype:
+            x = ops.cast_rowscale(_c(x.float()), None, 1, dtype, cin)
+        x = _c(x)
+        wb, wt = prep.get(w5, cs5, dtype)
+        lead = x.shape[:-1]
+        M = x.numel() // (8 * cin)
+        y = torch.empty(lead + (8 * cout,), dtype=out_dtype, device=x.device)
+        b32 = None if bias is None else _c(bias.detach().float())
+        cs32 = None if cs5 is None else [_c(s.detach().float()) for s in cs5]
+        rs32 = None if rs is None else _c(rs.float())
+        rv = ops.pview(_c(resid), cout) if fused else None
+        ops.linear_fwd(ops.pview(x, cin), wb, b32, ops.pview(y, cout), M, cin, cout, dtype, out_dtype, x,
+                       resid_v=rv, rs=rs32, rps=rps, cs5=cs32)
+        ctx.save_for_backward(x, rs32, b32, *w5, *(cs32 or []))
+        ctx.meta = (cin, cout, rps, dtype, fused, cs5 is not None, bias is not None, x_in_dtype, wt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cin, cout, rps, dtype, fused, has_cs, has_bias, x_in_dtype, wt = ctx.meta
+        x, rs32, b32, *rest = ctx.saved_tensors
+        w5, cs32 = rest[:5], (rest[5:] if has_cs else None)
+        M = x.numel() // (8 * cin)
+        dy = _c(dy)
+        if fused or rs32 is not None or dy.dtype != dtype:
+            g = ops.cast_rowscale(_c(dy.float()), rs32, rps, dtype, cout)  # cotangent of the branch
+        else:
+            g = dy
+        gv, xv = ops.pview(g, cout), ops.pview(x, cin)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=dtype, device=x.device)
+            ops.linear_fwd(gv, wt, None, ops.pview(dx, cin), M, cout, cin, dtype, dtype, x)
+            if dx.dtype != x_in_dtype:
+                dx = dx.to(x_in_dtype)
+        dysum = ops.colsum_a1(gv, M, cout, dtype, x) if has_bias else None
+        w32 = [_c(w.detach().float()) for w in w5] if has_cs else None
+        dw, dcs, dbias = ops.linear_wgrad(xv, gv, M, cin, cout, dtype, x, w32=w32, cs5=cs32, bias=b32, dysum=dysum,
+                                          want_bias=has_bias)
+        dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
+        dcs = dcs if has_cs else [None] * 5
+        return (dx, *dw, dbias, dy if fused else None, None, *dcs, None, None, None, None, None)
+
+
+# --------------------------------------------------------------------------------- head packing
+class PackHeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, H, c):
+        B, T = qkv.shape[0], qkv.shape[1]
+        ctx.meta = (B, T, H, c)
+        return ops.pack_heads(_c(qkv), B, T, H, c, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, H, c = ctx.meta
+        return ops.unpack_heads(_c(g), B, T, H, c, 3), None, None
+
+
+class UnpackHeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o, c):
+        B, H, T, _ = o.shape
+        ctx.meta = (B, T, H, c)
+        return ops.unpack_heads(_c(o), B, T, H, c, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, H, c = ctx.meta
+        return ops.pack_heads(_c(g), B, T, H, c, 1)[0], None
+
+
+# -------------------------------------------------------------------------------------- hand-off
+class HandoffCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c, out_dtype):
+        ctx.c, ctx.in_dtype = c, x.dtype
+        return ops.handoff_cat_fwd(_c(x.float()), c, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.handoff_cat_bwd(g, ctx.c).to(ctx.in_dtype), None, None
+
+
+class PowerSpectrumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c, out_dtype):
+        x = _c(x.float())
+        ctx.save_for_backward(x)
+        ctx.c = c
+        return ops.power_spectrum_fwd(x, c, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.power_spectrum_bwd(g, x, ctx.c), None, None
+
+
+# ------------------------------------------------------------------------------------------ lift
+class LiftFn(torch.autograd.Function):
+    """tokens[b, tok0+n, :] = patches(img)[b,n,:] @ Wfull^T + bias_full + pos[n,:] ; tokens[b, :tok0] = cls."""
+
+    @staticmethod
+    def forward(ctx, img, wfull, bias_full, pos, cls_row, p, dtype):
+        B, Cin, Hh, Ww = img.shape
+        D, K = wfull.shape
+        Kpad = (K + 7) // 8 * 8
+        n_p = (Hh // p) * (Ww // p)
+        tok0 = 0 if cls_row is None else 1
+        patches = ops.im2col(img, p, Kpad, dtype)
+        wpad = torch.zeros((D, Kpad), dtype=dtype, device=img.device)
+        wpad[:, :K] = wfull.detach()
+        out = torch.empty((B, tok0 + n_p, D), dtype=torch.float32, device=img.device)
+        ops.lift_gemm(patches, wpad, None if bias_full is None else _c(bias_full.detach().float()),
+                      None if pos is None else _c(pos.detach().float()), out, B, n_p, tok0, Kpad, D)
+        if tok0:
+            out[:, 0] = cls_row.detach().float()
+        ctx.save_for_backward(patches)
+        ctx.meta = (B, n_p, tok0, K, Kpad, D, dtype, bias_full is not None, pos is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (patches,) = ctx.saved_tensors
+        B, n_p, tok0, K, Kpad, D, dtype, has_bias, has_pos = ctx.meta
+        dtok = dout[:, tok0:]
+        dcompact = _c(dtok.to(dtype)).reshape(B * n_p, D)
+        dw = ops.lift_wgrad(patches, dcompact, Kpad, D)[:, :K]
+        dpos = dtok.sum(0) if (has_pos or has_bias) else None
+        dbias = dpos.sum(0) if has_bias else None
+        dcls = dout[:, 0].sum(0) if tok0 else None
+        return None, dw, dbias, dpos if has_pos else None, dcls, None, None

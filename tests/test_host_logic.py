@@ -1,0 +1,92 @@
+"""CPU-only checks of the product's host logic (no GPU compute): index-table unfolding, group tables,
+transforms, invariants' composite maps, model construction / state_dict compatibility."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from octic_vits_amd import d8_utils as U
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class _NS:
+    """product namespace for the function-level cases (expand_weight needs the conv class)"""
+    pass
+
+
+def _product_ns():
+    import octic_vits_amd.d8_layers as L
+    ns = _NS()
+    for mod in (U, L):
+        for k, v in vars(mod).items():
+            if not k.startswith("_"):
+                setattr(ns, k, v)
+    return ns
+
+
+@pytest.mark.parametrize("name", ["transforms", "pos_unfold", "expand_weight", "converters", "group_actions"])
+def test_function_cases_match_reference_golden(name):
+    got = cases.run_func_case(_product_ns(), name)
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    assert set(got) == set(want.files)
+    for k in want.files:
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-6, atol=1e-6, err_msg=f"{name}:{k}")
+
+
+def test_mult_table_known_answers():
+    t = {(a, b): c for a, b, c in U.mult_table}
+    assert len(t) == 49
+    assert t[("r", "m")] == "mrrr" and t[("m", "r")] == "mr" and t[("mr", "mr")] == "e" and t[("rrr", "mrrr")] == "m"
+
+
+@pytest.mark.parametrize("name", ["inv_linear", "inv_polynomial", "inv_thirdorder", "inv_maxfilter", "inv_canonization",
+                                  "inv_noninvariant"])
+def test_composite_invariants_match_reference_golden(name):
+    import octic_vits_amd.d8_invariantization as I
+    got = cases.run_module_case(I, name)
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    tol = 1e-3 if name == "inv_polynomial" else 1e-4
+    for k in want.files:
+        np.testing.assert_allclose(got[k], want[k], rtol=tol, atol=tol, err_msg=f"{name}:{k}")
+
+
+def test_model_facts_and_state_dict_keys():
+    from octic_vits_amd.deit_models import create_model
+    facts = np.load(os.path.join(GOLD, "model_facts.npz"))
+    for mname in ("hybrid_deit_huge_patch14", "d8_inv_early_deit_huge_patch14",
+                  "hybrid_deit_large_patch16", "d8_inv_early_deit_large_patch16"):
+        with torch.device("meta"):
+            m = create_model(mname, num_classes=1000)
+        assert sum(p.numel() for p in m.parameters()) == int(facts[mname + ".params"][0])
+        assert len(list(m.parameters())) == int(facts[mname + ".tensors"][0])
+        keys = sorted(m.state_dict().keys())
+        assert zlib.crc32("\n".join(keys).encode()) == int(facts[mname + ".keys_crc"][0])
+
+
+def test_constructor_errors_match_reference():
+    import octic_vits_amd.d8_layers as L
+    with pytest.raises(ValueError):
+        L.LinearD8(60, 64)
+    with pytest.raises(ValueError):
+        L.AffineD8(12)
+    with pytest.raises(AssertionError):
+        L.AttentionD8(dim=64, num_heads=3)
+    with pytest.raises(NotImplementedError):
+        L.AttentionD8(dim=64, num_heads=2, rope=object())
+    with pytest.raises(NotImplementedError):
+        L.LiftIrrepD8Conv2d(3, 8, 5, 5, bias=False)
+    with pytest.raises(ValueError):
+        L.LiftIrrepD8Conv2d(3, 8, 2, 2, bias=False, irrep="A2")
+
+
+def test_product_refuses_cpu_execution():
+    """No CPU fallback: running a hot op on CPU tensors fails loudly."""
+    import octic_vits_amd.d8_layers as L
+    lin = L.LinearD8(64, 64)
+    xs = cases.tuple5("cpu", 2, 3, 8)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        lin(xs)

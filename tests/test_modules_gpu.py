@@ -1,0 +1,150 @@
+"""GPU parity of the HIP-backed modules against the golden vectors generated from the REAL reference
+(tests/golden/*.npz) — same class names, same ctor kwargs, same name-keyed parameters, same seeded inputs.
+
+fp32 path: exact-f32 MFMA + f32 everywhere -> rtol/atol 1e-4 of the output scale (models: 1e-3; the
+BASELINE north star asks forward <= 1e-3 rel).  bf16 autocast path: documented looser tolerance (5e-2 of
+scale on block outputs with O(1) layer-scale; bf16 has 8 mantissa bits)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def product_ns():
+    import octic_vits_amd.d8_invariantization as I
+    import octic_vits_amd.d8_layers as L
+    import octic_vits_amd.d8_utils as U
+    import octic_vits_amd.model as M
+    import octic_vits_amd.vit as V
+    ns = types.SimpleNamespace()
+    for mod in (U, I, L, M):
+        for k, v in vars(mod).items():
+            if not k.startswith("_"):
+                setattr(ns, k, v)
+    ns.Layer_scale_init_Block = V.Layer_scale_init_Block
+    return ns
+
+
+@pytest.fixture(autouse=True)
+def _reference_drop_path_stream():
+    """Draw drop-path masks exactly like the reference does on CPU (new_empty(B,1,1).bernoulli_) so the seeded
+    golden cases are reproducible on the GPU."""
+    import octic_vits_amd.d8_layers as L
+    L.drop_path_mask_source = lambda B, keep, device: torch.empty((B, 1, 1)).bernoulli_(keep).flatten().to(device)
+    yield
+    L.drop_path_mask_source = None
+
+
+def _check(name, got, want, rtol, atol, grad_tol=None):
+    assert set(got) == set(want.files), sorted(set(got) ^ set(want.files))
+    worst = 0.0
+    for k in want.files:
+        if grad_tol is not None and not k.startswith("out."):
+            rtol = atol = grad_tol
+        w = want[k].astype(np.float64)
+        g = got[k].astype(np.float64)
+        scale = max(1.0, float(np.abs(w).max()))
+        err = float(np.abs(g - w).max())
+        worst = max(worst, err / scale)
+        assert np.allclose(g, w, rtol=rtol, atol=atol * scale), f"{name}:{k} max err {err:.3e} scale {scale:.3g}"
+    return worst
+
+
+SKIP_HIP = {"inv_linear", "inv_polynomial", "inv_thirdorder", "inv_maxfilter", "inv_canonization", "inv_noninvariant"}
+
+
+@pytest.mark.parametrize("name", [n for n in cases.CASES if n not in SKIP_HIP])
+def test_fp32_matches_reference_golden(name):
+    got = cases.run_module_case(product_ns(), name, device="cuda")
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    tol = 1e-3 if (name.startswith("model") or name.startswith("vit_")) else 1e-4
+    _check(name, got, want, tol, tol)
+
+
+class _Autocast(torch.nn.Module):
+    def __init__(self, mod):
+        super().__init__()
+        self.mod = mod
+
+    def named_parameters(self, *a, **k):  # keep the reference's parameter names in the result dict
+        return self.mod.named_parameters(*a, **k)
+
+    def forward(self, x):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return self.mod(x)
+
+
+BF16_CASES = ["linear_bias", "layernorm", "gelu", "mlp", "attention", "block_deit", "block_deit_droppath", "block_dino",
+              "patch_embed", "model_hybrid", "model_invariant"]
+
+
+@pytest.mark.parametrize("name", BF16_CASES)
+def test_bf16_autocast_close_to_reference_golden(name):
+    got = cases.run_module_case(product_ns(), name, device="cuda", to_module=_Autocast)
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    if not name.startswith("model"):
+        _check(name, got, want, 5e-2, 5e-2)
+        return
+    # whole models: outputs elementwise at 5e-2 of scale.  Gradients are compared in relative L2 (<= 0.2):
+    # bf16 rounding moves activations by ~1e-2, which flips sign(x) at the |.| kinks of PowerSpectrum / the
+    # GELU slope for individual elements, so a few entries of a weight gradient can move by O(their size)
+    # while the tensor as a whole stays within a few percent (the fp32 path pins the same gradients to 1e-3).
+    assert set(got) == set(want.files)
+    for k in want.files:
+        g, w = got[k].astype(np.float64), want[k].astype(np.float64)
+        if k.startswith("out."):
+            scale = max(1.0, float(np.abs(w).max()))
+            assert np.allclose(g, w, rtol=5e-2, atol=5e-2 * scale), f"{name}:{k}"
+        elif k.startswith("gpar_norm."):
+            assert abs(g[0] - w[0]) <= 0.2 * max(w[0], 1e-3), f"{name}:{k} {g[0]} vs {w[0]}"
+        else:
+            rel = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3)
+            assert rel <= 0.2, f"{name}:{k} rel L2 err {rel:.3f}"
+
+
+def test_gelu_function_is_a_drop_in_for_the_reference_custom_op():
+    """TritonGeluD8Function.apply(x_A1, x_A2, x_B1, x_B2, x_2d) -> 5 tensors (d8_gelu.py:456-478)."""
+    from octic_vits_amd.functional import GeluD8Function
+    from oracle import octic_ref as R
+    xs = tuple(t.cuda().requires_grad_(True) for t in cases.tuple5("dropin", 3, 11, 24))
+    ys = GeluD8Function.apply(*xs)
+    ref_in = tuple(t.detach().cpu().requires_grad_(True) for t in xs)
+    yr = R.TritonGeluD8()(ref_in)
+    for a, b in zip(ys, yr):
+        assert a.shape == b.shape and torch.allclose(a.cpu(), b, atol=2e-6, rtol=1e-5)
+    cot = [cases.randn(f"dropin.cot{i}", *y.shape) for i, y in enumerate(yr)]
+    torch.autograd.backward(ys, [c.cuda() for c in cot])
+    torch.autograd.backward(yr, cot)
+    for a, b in zip(xs, ref_in):
+        assert torch.allclose(a.grad.cpu(), b.grad, atol=2e-6, rtol=1e-5)
+
+
+def test_reference_state_dict_loads_into_product_model():
+    """Drop-in checkpoint surface: an oracle (== reference-keyed) state_dict loads strictly and gives the same logits."""
+    from octic_vits_amd.deit_models import create_model
+    from oracle import octic_ref as R
+    kw = dict(img_size=32, num_classes=7)
+    ref = cases.fill_parameters(R.OcticVisionTransformer(patch_size=4, embed_dim=128, depth=4, num_heads=4, qkv_bias=True,
+                                                         octic_block_layers=R.Layer_scale_init_BlockD8,
+                                                         standard_block_layers=R.Layer_scale_init_Block,
+                                                         init_scale=0.1, **kw)).eval()
+    from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.vit import Layer_scale_init_Block
+    mine = OcticVisionTransformer(patch_size=4, embed_dim=128, depth=4, num_heads=4, qkv_bias=True,
+                                  octic_block_layers=Layer_scale_init_BlockD8,
+                                  standard_block_layers=Layer_scale_init_Block, **kw)
+    sd = {("_orig_mod." + k if False else k): v for k, v in ref.state_dict().items()}
+    mine.load_state_dict(sd, strict=True)
+    mine = mine.cuda().eval()
+    img = cases.randn("sd.img", 2, 3, 32, 32)
+    with torch.no_grad():
+        a, b = mine(img.cuda()).cpu(), ref(img)
+    assert torch.allclose(a, b, atol=1e-3 * float(b.abs().max()), rtol=1e-3)
