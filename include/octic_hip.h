@@ -103,6 +103,16 @@ int octic_linear_d8_fwd(const octic_view* x, const void* const w[5], const float
                         const float* const cs[5], int64_t M, int cin, int cout, int dtype, int out_dtype,
                         void* stream);
 
+/* Compute-dtype copies of the f32 master weights in ONE launch per layer: wb = [W_A1|W_A2|W_B1|W_B2|W_E]
+ * (forward), wt = each matrix transposed with the layer-scale folded in, wt_g[k][n] = cs_g[n] W_g[n][k]
+ * (input gradient dX = dY diag(cs) W).  Either output may be NULL; cs may be NULL.                 */
+int octic_linear_d8_prep(const float* const w32[5], const float* const cs[5], int cin, int cout, void* wb, void* wt,
+                         int dtype, void* stream);
+
+/* Output-tile width (32*NT) the launcher picks for this problem; the kernel instantiation that runs is
+ * linear_d8_kernel<TIN, TOUT, NT> — exposed so profilers/benchmarks can name it.                 */
+int octic_linear_d8_tile_n(int64_t M, int cin, int cout);
+
 /* Weight gradient  G_g[n,k] = sum_rows dy_g[row,n] x_g[row,k]  (E: both rows).  Reduction over the
  * M (2M) rows is split over `splits` row ranges whose f32 partial slabs go to `workspace`
  * (octic_linear_d8_wgrad_workspace_bytes).  The finish kernel sums the slabs in a fixed order
@@ -114,6 +124,7 @@ int octic_linear_d8_fwd(const octic_view* x, const void* const w[5], const float
  * w32 (f32 master weights) and bias are only read when cs != NULL.                            */
 int64_t octic_linear_d8_wgrad_workspace_bytes(int cin, int cout, int splits);
 int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout);
+int octic_linear_d8_wgrad_tile(int64_t M, int cin, int cout);   /* tile width 32*TT of wgrad_kernel<TIN, TT> */
 int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, int cin, int cout, int dtype,
                           float* workspace, int splits, void* stream);
 int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, int cout,
@@ -134,10 +145,12 @@ int octic_cast_rowscale(const octic_view* x, const octic_view* y, const float* r
 /* ---- attention head packing (d8_layers.py:631-643, 650-656) ------------------------------------
  * pack:  qkv view (3*8c channels: per irrep [q|k|v] thirds) -> q,k,v  [B,H,T,8w], w = c/H, per-head
  *        vector [A1 w|A2 w|B1 w|B2 w|E_row0 2w|E_row1 2w].  qkv_out = 3 consecutive [B,H,T,8w] arrays.
- * unpack: o [B,H,T,8w] -> view with 8c channels.  Each is the other's adjoint (n_s = 3 / 1).    */
-int octic_attn_pack_heads(const octic_view* qkv, void* qkv_out, int64_t B, int64_t T, int H, int c, int n_s,
+ * unpack: o [B,H,T,8w] -> view with 8c channels.  Each is the other's adjoint (n_s = 3 / 1).
+ * heads[s] (s < n_s) are n_s separately allocated [B,H,T,8w] arrays (q, k, v — or their gradients, which
+ * autograd hands back as three unrelated tensors).                                              */
+int octic_attn_pack_heads(const octic_view* qkv, void* const heads[3], int64_t B, int64_t T, int H, int c, int n_s,
                           int dtype, void* stream);
-int octic_attn_unpack_heads(const void* o, const octic_view* y, int64_t B, int64_t T, int H, int c, int n_s,
+int octic_attn_unpack_heads(void* const heads[3], const octic_view* y, int64_t B, int64_t T, int H, int c, int n_s,
                             int dtype, void* stream);
 
 /* ---- octic -> standard hand-off (model.py:196-200) ---------------------------------------------
@@ -169,6 +182,22 @@ int octic_lift_gemm(const void* patches, const void* w, const float* bias, const
 int64_t octic_lift_wgrad_workspace_bytes(int Kpad, int D, int splits);
 int octic_lift_wgrad(const void* patches, const void* dout, float* dw, float* workspace, int splits, int64_t rows,
                      int Kpad, int D, int dtype, void* stream);
+
+/* ---- fused multi-tensor LAMB + EMA ----------------------------------------------------------------
+ * One optimizer step of the reference recipe (apex FusedLAMB via timm create_optimizer 'fusedlamb',
+ * experiments/train_deit.py:42; timm ModelEma, deit/main.py:344-351) over ALL tensors in five launches:
+ * global grad-norm clip to max_grad_norm, Adam moments with bias correction, + wd*p, per-tensor trust ratio
+ * |p|/|u| (only where wd != 0), p -= lr*ratio*u, ema += (1-decay)(p-ema).  The gradient buffers are
+ * overwritten (they hold the update between the two passes).  Tables are device arrays: per-tensor
+ * pointers p,g,m,v,ema (ema may be NULL), per-tensor weight decay, and a chunk list
+ * (tensor id, element offset, length) with tensor_chunk_begin[ntensors+1] giving each tensor's chunk
+ * range.  workspace: octic_lamb_workspace_floats() f32; workspace[1] holds the global grad norm after the
+ * call (the number deit/engine.py:84 logs).                                                        */
+int64_t octic_lamb_workspace_floats(int ntensors, int nchunks);
+int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
+                    const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
+                    const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
+                    float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* stream);
 
 #ifdef __cplusplus
 }

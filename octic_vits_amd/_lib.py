@@ -35,14 +35,20 @@ _PROTOS = {
     "octic_layernorm_d8_bwd_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "octic_linear_d8_fwd": (c_int, [VP, c_void_p, c_void_p, VP, VP, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int,
                                     c_int, c_int, c_void_p]),
+    "octic_linear_d8_tile_n": (c_int, [c_i64, c_int, c_int]),
+    "octic_linear_d8_wgrad_tile": (c_int, [c_i64, c_int, c_int]),
     "octic_linear_d8_wgrad_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "octic_linear_d8_wgrad_splits": (c_int, [c_i64, c_int, c_int]),
     "octic_linear_d8_wgrad": (c_int, [VP, VP, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "octic_linear_d8_wgrad_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octic_lamb_workspace_floats": (c_i64, [c_int, c_int]),
+    "octic_lamb_step": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float,
+                                                  c_int, c_float, c_void_p]),
     "octic_colsum_blocks": (c_int, [c_i64]),
     "octic_colsum_a1": (c_int, [VP, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "octic_cast_rowscale": (c_int, [VP, VP, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p]),
+    "octic_linear_d8_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "octic_attn_pack_heads": (c_int, [VP, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "octic_attn_unpack_heads": (c_int, [c_void_p, VP, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "octic_handoff_cat_fwd": (c_int, [VP, c_void_p, c_i64, c_int, c_int, c_void_p]),

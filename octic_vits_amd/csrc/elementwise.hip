@@ -131,37 +131,113 @@ __global__ __launch_bounds__(256) void cast_rowscale_kernel(View x, View y, cons
   }
 }
 
-// Head packing.  DIR 0: view -> heads, DIR 1: heads -> view.  V consecutive elements per thread
-// (V divides w).  heads layout [n_s][B][H][T][8w]; the view has n_s*8c channels.
-template <typename T, int V, int DIR>
-__global__ __launch_bounds__(256) void heads_permute_kernel(View v, T* heads, int64_t B, int64_t T_, int H, int c,
-                                                            int n_s) {
-  const int w = c / H;
-  const int hdv = (8 * w) / V;
-  const int64_t total = (int64_t)n_s * B * H * T_ * hdv;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    int64_t r = idx;
-    const int ev = (int)(r % hdv); r /= hdv;
-    const int64_t t = r % T_; r /= T_;
-    const int h = (int)(r % H); r /= H;
-    const int64_t b = r % B; r /= B;
-    const int s = (int)r;
-    const int e = ev * V;
-    const int64_t m = b * T_ + t;
-    T* q;
-    if (e < 4 * w) {
-      const int g = e / w, jj = e - g * w;
-      q = (T*)v.p[g] + m * v.ld[g] + s * c + h * w + jj;
-    } else {
-      const int rr = (e - 4 * w) / (2 * w), jj = (e - 4 * w) - rr * 2 * w;
-      q = (T*)v.p[4] + m * v.ld[4] + rr * (2 * n_s * c) + s * 2 * c + h * 2 * w + jj;
+// Head packing.  DIR 0: view -> heads, DIR 1: heads -> view.  heads[s] is a [B][H][T][8w] array; the view has
+// n_s*8c channels.  A workgroup moves a tile of TT consecutive tokens of one sample through LDS: token rows
+// are read/written as whole coalesced rows (16 B per lane), head vectors as runs of TT*8w contiguous
+// elements per (s, head) — the per-head vector interleaves six irrep pieces of w / 2w elements (w = 10 at
+// ViT-H: 20-byte pieces), which is why this cannot be a plain strided copy.  V = elements per LDS<->global
+// access on the head side (V divides w).
+struct HeadPtrs {
+  char* p[3];
+};
+
+// Per-lane constants of one head-side access slot: the lane moves V elements of token r at head-vector
+// position e; their packed column is col = a + s*cs + h*ch (see the kernel comment).
+struct HeadSlot {
+  int lds;   // element offset inside the LDS tile for (s,h) = (0,0):  r*row_elems + a
+  int cs;    // column stride per s
+  int ch;    // column stride per head
+  int glb;   // element offset inside the (s,h) run of the heads array: r*hd + e
+};
+
+template <typename T, int V, int DIR, int SLOTS>
+__global__ __launch_bounds__(256) void heads_permute_kernel(View v, HeadPtrs heads, int64_t B, int64_t T_, int H, int c,
+                                                            int n_s, int TT) {
+  extern __shared__ __attribute__((aligned(16))) char hsm[];
+  T* tile = (T*)hsm;  // [TT][n_s*8c] token rows in packed order
+  const int w = c / H, hd = 8 * w;
+  const int row_elems = n_s * 8 * c;
+  const int tiles_per_b = (int)((T_ + TT - 1) / TT);
+  const int64_t b = blockIdx.x / tiles_per_b;
+  const int64_t t0 = (int64_t)(blockIdx.x - b * tiles_per_b) * TT;
+  const int nt = (int)((T_ - t0) < TT ? (T_ - t0) : TT);
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cpr = row_elems / EPC;  // 16-byte chunks per token row
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+  auto row_phase = [&](bool load) {
+    // whole token rows, 16 B per lane, coalesced; packed column e -> (tensor, offset); a chunk never straddles
+    // a segment because c % 8 == 0
+    const int cv = n_s * c;
+    for (int q = threadIdx.x; q < nt * cpr; q += 256) {
+      const int r = q / cpr, e = (q - r * cpr) * EPC;
+      const int64_t m = b * T_ + t0 + r;
+      T* gp;
+      if (e < 4 * cv) {
+        const int g = e / cv;
+        gp = (T*)v.p[g] + m * v.ld[g] + (e - g * cv);
+      } else {
+        gp = (T*)v.p[4] + m * v.ld[4] + (e - 4 * cv);
+      }
+      u32x4* lp = (u32x4*)(tile + (size_t)r * row_elems + e);
+      if (load) *lp = *(const u32x4*)gp;
+      else *(u32x4*)gp = *lp;
     }
-    T* hp = heads + idx * V;
+  };
+
+  // head side: for a fixed (s,h) the TT head vectors are ONE contiguous run of TT*hd elements.  Slot k of a lane
+  // covers run element (lane + 64k)*V; everything that does not depend on (s,h) is computed once here.
+  HeadSlot sl[SLOTS];
+  const int run = nt * hd;  // valid elements of the run (last tile of a sample may be short)
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      if (DIR == 0) hp[i] = q[i];
-      else q[i] = hp[i];
+  for (int k = 0; k < SLOTS; ++k) {
+    const int idx = (lane + 64 * k) * V;
+    const int r = idx / hd, e = idx - r * hd;
+    int a, cs, ch;
+    if (e < 4 * w) {
+      const int g = e / w;
+      a = g * (n_s * c) + (e - g * w); cs = c; ch = w;
+    } else {
+      const int rr = (e - 4 * w) / (2 * w);
+      a = 4 * n_s * c + rr * (2 * n_s * c) + (e - 4 * w - rr * 2 * w); cs = 2 * c; ch = 2 * w;
     }
+    sl[k].lds = idx < run ? r * row_elems + a : -1;
+    sl[k].cs = cs; sl[k].ch = ch; sl[k].glb = idx;
+  }
+  auto head_phase = [&](bool to_heads) {
+#pragma unroll 4
+    for (int sh = wid; sh < n_s * H; sh += 4) {      // one wave per (s, head)
+      const int s = sh / H, h = sh - s * H;
+      T* gbase = (T*)heads.p[s] + ((b * H + h) * T_ + t0) * hd;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        if (sl[k].lds >= 0) {
+          T* lp = tile + sl[k].lds + s * sl[k].cs + h * sl[k].ch;
+          T* gp = gbase + sl[k].glb;
+          if (V * sizeof(T) == 4) {
+            if (to_heads) *(unsigned*)gp = *(const unsigned*)lp; else *(unsigned*)lp = *(const unsigned*)gp;
+          } else if (V * sizeof(T) == 8) {
+            if (to_heads) *(uint2*)gp = *(const uint2*)lp; else *(uint2*)lp = *(const uint2*)gp;
+          } else if (V * sizeof(T) == 16) {
+            if (to_heads) *(u32x4*)gp = *(const u32x4*)lp; else *(u32x4*)lp = *(const u32x4*)gp;
+          } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+              if (to_heads) gp[i] = lp[i]; else lp[i] = gp[i];
+            }
+          }
+        }
+      }
+    }
+  };
+  if (DIR == 0) {
+    row_phase(true);
+    __syncthreads();
+    head_phase(true);
+  } else {
+    head_phase(false);
+    __syncthreads();
+    row_phase(false);
   }
 }
 
@@ -285,7 +361,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* img, T* patche
   }
 }
 
-constexpr int kColsumRows = 512;  // rows per block
+constexpr int kColsumRows = 128;  // rows per block
 
 template <typename T>
 __device__ inline void load4e(const T* p, float v[4]);
@@ -337,35 +413,93 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* partial
   out[col] = s;
 }
 
+// Compute-dtype copies of a LinearD8's f32 master weights, one launch per layer:
+//   wb = [W_A1|W_A2|W_B1|W_B2|W_E] as they are (forward GEMM), wt = each matrix transposed with the
+//   layer-scale folded in, wt_g[k][n] = cs_g[n] * W_g[n][k]  (input-gradient GEMM dX = dY diag(cs) W).
+struct PrepArgs {
+  const float* w[5];
+  const float* cs[5];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void linear_prep_kernel(PrepArgs a, T* wb, T* wt, int cin, int cout) {
+  const int64_t small = (int64_t)cin * cout;
+  const int64_t total = 8 * small;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int g = idx < 4 * small ? (int)(idx / small) : 4;
+    const int64_t base = g < 4 ? g * small : 4 * small;
+    const int K = g < 4 ? cin : 2 * cin, N = g < 4 ? cout : 2 * cout;
+    const int64_t loc = idx - base;
+    const int n = (int)(loc / K), k = (int)(loc - (int64_t)n * K);
+    const float v = a.w[g][loc];
+    if (wb) wb[idx] = (T)v;
+    if (wt) wt[base + (int64_t)k * N + n] = (T)(a.cs[g] ? a.cs[g][n] * v : v);
+  }
+}
+
 inline int grid_for(int64_t total) {
   int64_t g = (total + 255) / 256;
   const int64_t cap = 256 * 16;  // 16 blocks per CU, grid-stride beyond
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-template <typename T, int DIR>
-static int heads_dispatch(const octic_view* v, T* heads, int64_t B, int64_t T_, int H, int c, int n_s, void* stream) {
-  View vv = make_view<void>(v);
-  const int w = c / H;
-  const int V = (w % 8 == 0) ? 8 : (w % 4 == 0) ? 4 : (w % 2 == 0) ? 2 : 1;
-  const int64_t total = (int64_t)n_s * B * H * T_ * (8 * w / V);
-  const int grid = grid_for(total);
-  hipStream_t s = (hipStream_t)stream;
-  switch (V) {
-    case 8: heads_permute_kernel<T, 8, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
-    case 4: heads_permute_kernel<T, 4, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
-    case 2: heads_permute_kernel<T, 2, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
-    default: heads_permute_kernel<T, 1, DIR><<<grid, 256, 0, s>>>(vv, heads, B, T_, H, c, n_s); break;
-  }
+template <typename T, int V, int DIR>
+static int heads_launch(View vv, HeadPtrs hp, int64_t B, int64_t T_, int H, int c, int n_s, hipStream_t s) {
+  const int w = c / H, hd = 8 * w;
+  const size_t row_bytes = (size_t)n_s * 8 * c * sizeof(T);
+  int TT = 8;
+  while (TT > 1 && TT * row_bytes > 64 * 1024) TT >>= 1;
+  if (TT * row_bytes > 160 * 1024) return OCTIC_ESHAPE;
+  const size_t smem = TT * row_bytes;
+  const int grid = (int)(B * ((T_ + TT - 1) / TT));
+  const int slots = (TT * hd / V + 63) / 64;
+#define OCTIC_HEADS_LAUNCH(SL)                                                                                          \
+  do {                                                                                                                  \
+    if (smem > 64 * 1024)                                                                                               \
+      (void)hipFuncSetAttribute((const void*)heads_permute_kernel<T, V, DIR, SL>,                                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                \
+    heads_permute_kernel<T, V, DIR, SL><<<grid, 256, smem, s>>>(vv, hp, B, T_, H, c, n_s, TT);                          \
+  } while (0)
+  if (slots <= 1) OCTIC_HEADS_LAUNCH(1);
+  else if (slots <= 2) OCTIC_HEADS_LAUNCH(2);
+  else if (slots <= 4) OCTIC_HEADS_LAUNCH(4);
+  else if (slots <= 5) OCTIC_HEADS_LAUNCH(5);
+  else if (slots <= 8) OCTIC_HEADS_LAUNCH(8);
+  else if (slots <= 16) OCTIC_HEADS_LAUNCH(16);
+  else return OCTIC_ESHAPE;
+#undef OCTIC_HEADS_LAUNCH
   return launch_status();
 }
 
-static int heads_check(const octic_view* v, const void* heads, int64_t B, int64_t T_, int H, int c, int n_s, int dtype) {
+template <typename T, int DIR>
+static int heads_dispatch(const octic_view* v, void* const heads[3], int64_t B, int64_t T_, int H, int c, int n_s,
+                          void* stream) {
+  View vv = make_view<void>(v);
+  HeadPtrs hp;
+  for (int i = 0; i < 3; ++i) hp.p[i] = (char*)(i < n_s ? heads[i] : nullptr);
+  const int w = c / H;
+  hipStream_t s = (hipStream_t)stream;
+  // V elements per head-side access: must divide w (pieces are w / 2w long) and stay <= 16 bytes
+  const int vmax = 16 / (int)sizeof(T);
+  int V = 1;
+  while (V * 2 <= vmax && (w % (V * 2)) == 0) V *= 2;
+  switch (V) {
+    case 8: return heads_launch<T, 8, DIR>(vv, hp, B, T_, H, c, n_s, s);
+    case 4: return heads_launch<T, 4, DIR>(vv, hp, B, T_, H, c, n_s, s);
+    case 2: return heads_launch<T, 2, DIR>(vv, hp, B, T_, H, c, n_s, s);
+    default: return heads_launch<T, 1, DIR>(vv, hp, B, T_, H, c, n_s, s);
+  }
+}
+
+static int heads_check(const octic_view* v, void* const heads[3], int64_t B, int64_t T_, int H, int c, int n_s, int dtype) {
   int e;
   if ((e = check_c(c))) return e;
   if (B <= 0 || T_ <= 0 || H <= 0 || (c % H) != 0 || (n_s != 1 && n_s != 3)) return OCTIC_ESHAPE;
   if ((e = check_view(v, n_s * c, dtype))) return e;
   if (!heads) return OCTIC_ENULL;
+  for (int i = 0; i < n_s; ++i) {
+    if (!heads[i]) return OCTIC_ENULL;
+    if (((uintptr_t)heads[i]) & 15) return OCTIC_EALIGN;
+  }
   if (dtype != OCTIC_F32 && dtype != OCTIC_BF16) return OCTIC_EDTYPE;
   return OCTIC_OK;
 }
@@ -432,20 +566,37 @@ int octic_cast_rowscale(const octic_view* x, const octic_view* y, const float* r
   return launch_status();
 }
 
-int octic_attn_pack_heads(const octic_view* qkv, void* out, int64_t B, int64_t T_, int H, int c, int n_s, int dtype,
-                          void* stream) {
-  int e = heads_check(qkv, out, B, T_, H, c, n_s, dtype);
+int octic_attn_pack_heads(const octic_view* qkv, void* const heads[3], int64_t B, int64_t T_, int H, int c, int n_s,
+                          int dtype, void* stream) {
+  int e = heads_check(qkv, heads, B, T_, H, c, n_s, dtype);
   if (e) return e;
-  return dtype == OCTIC_F32 ? heads_dispatch<float, 0>(qkv, (float*)out, B, T_, H, c, n_s, stream)
-                            : heads_dispatch<bf16, 0>(qkv, (bf16*)out, B, T_, H, c, n_s, stream);
+  return dtype == OCTIC_F32 ? heads_dispatch<float, 0>(qkv, heads, B, T_, H, c, n_s, stream)
+                            : heads_dispatch<bf16, 0>(qkv, heads, B, T_, H, c, n_s, stream);
 }
 
-int octic_attn_unpack_heads(const void* o, const octic_view* y, int64_t B, int64_t T_, int H, int c, int n_s, int dtype,
-                            void* stream) {
-  int e = heads_check(y, o, B, T_, H, c, n_s, dtype);
+int octic_attn_unpack_heads(void* const heads[3], const octic_view* y, int64_t B, int64_t T_, int H, int c, int n_s,
+                            int dtype, void* stream) {
+  int e = heads_check(y, heads, B, T_, H, c, n_s, dtype);
   if (e) return e;
-  return dtype == OCTIC_F32 ? heads_dispatch<float, 1>(y, (float*)o, B, T_, H, c, n_s, stream)
-                            : heads_dispatch<bf16, 1>(y, (bf16*)o, B, T_, H, c, n_s, stream);
+  return dtype == OCTIC_F32 ? heads_dispatch<float, 1>(y, heads, B, T_, H, c, n_s, stream)
+                            : heads_dispatch<bf16, 1>(y, heads, B, T_, H, c, n_s, stream);
+}
+
+int octic_linear_d8_prep(const float* const w32[5], const float* const cs[5], int cin, int cout, void* wb, void* wt,
+                         int dtype, void* stream) {
+  if (!w32 || (!wb && !wt)) return OCTIC_ENULL;
+  if (cin <= 0 || cout <= 0) return OCTIC_ESHAPE;
+  PrepArgs a;
+  for (int i = 0; i < 5; ++i) {
+    if (!w32[i]) return OCTIC_ENULL;
+    a.w[i] = w32[i];
+    a.cs[i] = cs ? cs[i] : nullptr;
+  }
+  const int grid = grid_for((int64_t)8 * cin * cout);
+  if (dtype == OCTIC_F32) linear_prep_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(a, (float*)wb, (float*)wt, cin, cout);
+  else if (dtype == OCTIC_BF16) linear_prep_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(a, (bf16*)wb, (bf16*)wt, cin, cout);
+  else return OCTIC_EDTYPE;
+  return launch_status();
 }
 
 int octic_handoff_cat_fwd(const octic_view* x, void* dense, int64_t M, int c, int out_dtype, void* stream) {

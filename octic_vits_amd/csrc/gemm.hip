@@ -13,6 +13,7 @@
 // ViT-H), so the kernel is bound by HBM/epilogue traffic, not MFMA issue; see DESIGN.md §kernels.
 // bf16: v_mfma_f32_16x16x32_bf16.  f32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain) for the
 // reference's fp32 tolerances.
+#include <stdlib.h>
 #include "octic_common.hpp"
 
 namespace octic {
@@ -31,7 +32,8 @@ struct GemmGroup {
   int K, N;
   int pair;           // 1: row mm -> token mm>>1, half mm&1 (adjacent halves of width K / N)
   int n_tiles, m_tiles;
-  int tile_begin;     // first linear tile id of this group
+  int chunk, n_chunks;  // n-tiles walked by one block, number of such chunks
+  int tile_begin;     // first linear work-item id of this group
 };
 
 struct GemmArgs {
@@ -43,6 +45,7 @@ struct GemmArgs {
   // lift mode: output row = (row / lift_np) * (lift_np + lift_tok0) + lift_tok0 + row % lift_np ; resid row = row % lift_np
   int64_t lift_np;
   int lift_tok0;
+  int dbg;  // ablation bits (OCTIC_GEMM_DBG env, timing only): 1 = no global loads after step 0, 2 = no MFMA, 4 = no epilogue stores
 };
 
 template <typename T> struct Elem;
@@ -81,8 +84,22 @@ __device__ inline f32x4 mfma_step(f32x4 a, f32x4 b, f32x4 c) {
 
 constexpr int kBM = 128;
 
+// Zero a staged chunk without a branch (loads are always issued from a clamped, valid address).
+__device__ inline u32x4 keep_if(u32x4 v, bool ok) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = ok ? v[i] : 0u;
+  return r;
+}
+
+// The kernel is written so that the per-step instruction stream is almost only {9 global loads, 9 LDS
+// writes, 18 LDS reads, 40 MFMAs}: every address is a per-lane constant plus an immediate, the (n-tile,
+// k-tile) position is tracked with counters (no divisions), row offsets / drop-path scales are computed once
+// per block, and zero-filling of tile tails is only compiled into the path of blocks that have a tail.
+// (An ablation with loads, MFMAs and stores disabled showed the first version spent 1.25 us per step on
+// address arithmetic alone — see DESIGN.md.)
 template <typename TIN, typename TOUT, int NT>
-__global__ __launch_bounds__(256) void linear_d8_kernel(GemmArgs args) {
+__global__ __launch_bounds__(256, 2) void linear_d8_kernel(GemmArgs args) {
   constexpr int EPC = Elem<TIN>::EPC;   // elements per 16-byte chunk
   constexpr int BKE = 8 * EPC;          // K elements per tile (128 B rows)
   constexpr int BN = 32 * NT;
@@ -91,8 +108,7 @@ __global__ __launch_bounds__(256) void linear_d8_kernel(GemmArgs args) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 stages x (BM + BN) rows x 128 B
   constexpr int STAGE = (kBM + BN) * 128;
 
-  // ---- XCD-aware, bijective block remap: blocks that share an XCD (bid % 8) get a contiguous range
-  // of tiles, so the n-tiles that re-read one token panel hit the same L2.
+  // ---- XCD-aware, bijective block remap
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -103,54 +119,81 @@ __global__ __launch_bounds__(256) void linear_d8_kernel(GemmArgs args) {
     if (i < args.ngroups && tile >= args.g[i].tile_begin) gi = i;
   const GemmGroup& G = args.g[gi];
   const int lt = tile - G.tile_begin;
-  const int mt = lt / G.n_tiles, nt = lt - mt * G.n_tiles;
+  const int mt = lt / G.n_chunks, nc = lt - mt * G.n_chunks;
   const int64_t m0 = (int64_t)mt * kBM;
-  const int n0 = nt * BN;
+  const int nt_begin = nc * G.chunk;
+  const int nt_count = (G.n_tiles - nt_begin) < G.chunk ? (G.n_tiles - nt_begin) : G.chunk;
   const int K = G.K, N = G.N;
+  const int nkt = (K + BKE - 1) / BKE;
+  const int steps = nt_count * nkt;
+  const int k_rem = K - (nkt - 1) * BKE;                       // valid K elements in the last k-tile
+  const bool last_half_only = k_rem <= 4 * EPC;                // second 4-chunk half of the last k-tile is empty
+  // does this block touch any partial tile?  (wave-uniform)
+  const bool tails = (m0 + kBM > G.rows) || ((nt_begin + nt_count) * BN > N) || (k_rem != BKE && (k_rem % (4 * EPC)) != 0);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid & 1, wm = wid >> 1;
+  const int fr = lane & 15, kg = lane >> 4;
 
-  // ---- staging assignment: thread owns chunk column kc of rows (tid>>3) + 32*i
+  // ---- staging constants: thread owns chunk column kc of rows r_in + 32*i
   const int kc = tid & 7, r_in = tid >> 3;
-  const TIN* xrow[4];
-  bool xok[4];
+  const int kcol = kc * EPC;                                   // element offset of the chunk inside a k-tile
+  const int st_off = r_in * 128 + ((kc ^ (r_in & 7)) << 4);    // LDS byte offset (+ i*4096 per 32 rows)
+  const TIN* xp[4];
+  unsigned xmask = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t mm = m0 + r_in + 32 * i;
-    xok[i] = mm < G.rows;
+    int64_t mm = m0 + r_in + 32 * i;
+    if (mm < G.rows) xmask |= 1u << i;
+    mm = mm < G.rows ? mm : G.rows - 1;
     const int64_t off = G.pair ? (mm >> 1) * G.a_ld + (mm & 1) * (int64_t)K : mm * G.a_ld;
-    xrow[i] = (const TIN*)G.a + (xok[i] ? off : 0);
+    xp[i] = (const TIN*)G.a + off;
   }
-  const TIN* wrow[NT];
-  bool wok[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int n = n0 + r_in + 32 * i;
-    wok[i] = n < N;
-    wrow[i] = (const TIN*)G.w + (wok[i] ? (int64_t)n * K : 0);
-  }
-  u32x4 rx[4], rw[NT];
-  auto gload = [&](int k0) {
-    const int k = k0 + kc * EPC;
-    const bool kok = k < K;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rx[i] = (xok[i] && kok) ? *(const u32x4*)(xrow[i] + k) : u32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < NT; ++i) rw[i] = (wok[i] && kok) ? *(const u32x4*)(wrow[i] + k) : u32x4{0, 0, 0, 0};
-  };
-  auto lstore = [&](int stage) {
-    char* xs = lds + stage * STAGE;
-    char* ws = xs + kBM * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = r_in + 32 * i;
-      *(u32x4*)(xs + row * 128 + ((kc ^ (row & 7)) << 4)) = rx[i];
-    }
+  // load-stream position (runs two steps ahead of the compute stream)
+  int l_nt = nt_begin, l_kt = 0;
+  const TIN* wp[NT];
+  unsigned wmask = 0;
+  auto set_w = [&](int nt) {
+    wmask = 0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int row = r_in + 32 * i;
-      *(u32x4*)(ws + row * 128 + ((kc ^ (row & 7)) << 4)) = rw[i];
+      int n = nt * BN + r_in + 32 * i;
+      if (n < N) wmask |= 1u << i;
+      n = n < N ? n : N - 1;
+      wp[i] = (const TIN*)G.w + (int64_t)n * K;
+    }
+  };
+  set_w(l_nt);
+
+  // a register set = 9 chunks + the validity mask that goes with them (only consulted when `tails`)
+  auto gload = [&](u32x4 (&rx)[4], u32x4 (&rw)[NT], unsigned& mask) {
+    int k = l_kt * BKE + kcol;
+    const bool kok = k < K;
+    k = kok ? k : 0;
+    mask = kok ? (xmask | (wmask << 4)) : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rx[i] = *(const u32x4*)(xp[i] + k);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) rw[i] = *(const u32x4*)(wp[i] + k);
+    if (++l_kt == nkt) {
+      l_kt = 0;
+      ++l_nt;
+      if (l_nt < nt_begin + nt_count) set_w(l_nt);
+    }
+  };
+  auto lstore = [&](int stage, const u32x4 (&rx)[4], const u32x4 (&rw)[NT], unsigned mask) {
+    char* xs = lds + stage * STAGE + st_off;
+    char* ws = xs + kBM * 128;
+    if (!tails) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(u32x4*)(xs + i * 4096) = rx[i];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) *(u32x4*)(ws + i * 4096) = rw[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(u32x4*)(xs + i * 4096) = keep_if(rx[i], (mask >> i) & 1u);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) *(u32x4*)(ws + i * 4096) = keep_if(rw[i], (mask >> (4 + i)) & 1u);
     }
   };
 
@@ -160,73 +203,113 @@ __global__ __launch_bounds__(256) void linear_d8_kernel(GemmArgs args) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  const int nkt = (K + BKE - 1) / BKE;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int fr = lane & 15, kg = lane >> 4;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) gload((kt + 1) * BKE);
-    const char* xs = lds + (kt & 1) * STAGE;
-    const char* ws = xs + kBM * 128;
+  // fragment read offsets: row = base + 16*i + fr  =>  (row & 7) == (fr & 7); tile rows advance by immediates
+  const int sw = fr & 7;
+  const int rd_w = kBM * 128 + (wn * (NT * 16) + fr) * 128;    // + i*2048
+  const int rd_x = (wm * 64 + fr) * 128;                       // + j*2048
+  const int ch0 = (kg ^ sw) << 4, ch1 = ((4 + kg) ^ sw) << 4;
+  int c_kt = 0;                                                // k-tile of the compute stream
+  auto compute = [&](int stage) {
+    const char* base = lds + stage * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (kt * BKE + ks * 4 * EPC < K) {  // wave-uniform: skip an all-zero half tile
-        const int ch = ks * 4 + kg;
-        frag af[NT], bfr[MT];
+      if (ks == 1 && last_half_only && c_kt == nkt - 1) break;  // wave-uniform: skip an all-zero half tile
+      const int ch = ks ? ch1 : ch0;
+      frag af[NT], bfr[MT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          const int row = wn * (NT * 16) + i * 16 + fr;
-          af[i] = *(const frag*)(ws + row * 128 + ((ch ^ (row & 7)) << 4));
-        }
+      for (int i = 0; i < NT; ++i) af[i] = *(const frag*)(base + rd_w + i * 2048 + ch);
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const int row = wm * 64 + j * 16 + fr;
-          bfr[j] = *(const frag*)(xs + row * 128 + ((ch ^ (row & 7)) << 4));
-        }
+      for (int j = 0; j < MT; ++j) bfr[j] = *(const frag*)(base + rd_x + j * 2048 + ch);
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-          for (int j = 0; j < MT; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
-      }
+        for (int j = 0; j < MT; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
     }
-    if (kt + 1 < nkt) lstore((kt + 1) & 1);
-    __syncthreads();
-  }
+  };
 
-  // ---- epilogue: lane holds outputs n..n+3 of token row mm for each (i,j) tile
+  // ---- epilogue constants (once per block): per-j output row offset, residual row offset, drop-path scale
+  int64_t yoff[MT], roff[MT];
+  float rsv[MT];
+  unsigned rowok = 0;
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int64_t mm = m0 + wm * 64 + j * 16 + fr;
-    if (mm >= G.rows) continue;
-    const int64_t token = G.pair ? (mm >> 1) : mm;
-    int64_t yoff, roff;
+    const bool ok = mm < G.rows;
+    if (ok) rowok |= 1u << j;
+    const int64_t mc = ok ? mm : 0;
+    const int64_t token = G.pair ? (mc >> 1) : mc;
     if (args.lift_np > 0) {
-      const int64_t b = mm / args.lift_np, p = mm - b * args.lift_np;
-      yoff = (b * (args.lift_np + args.lift_tok0) + args.lift_tok0 + p) * G.y_ld;
-      roff = p * G.r_ld;
+      const int64_t b = mc / args.lift_np, p = mc - b * args.lift_np;
+      yoff[j] = (b * (args.lift_np + args.lift_tok0) + args.lift_tok0 + p) * G.y_ld;
+      roff[j] = p * G.r_ld;
     } else {
-      yoff = G.pair ? (mm >> 1) * G.y_ld + (mm & 1) * (int64_t)N : mm * G.y_ld;
-      roff = G.pair ? (mm >> 1) * G.r_ld + (mm & 1) * (int64_t)N : mm * G.r_ld;
+      yoff[j] = G.pair ? (mc >> 1) * G.y_ld + (mc & 1) * (int64_t)N : mc * G.y_ld;
+      roff[j] = G.pair ? (mc >> 1) * G.r_ld + (mc & 1) * (int64_t)N : mc * G.r_ld;
     }
-    const float rsv = args.rs ? args.rs[token / args.rps] : 1.0f;
+    rsv[j] = args.rs ? args.rs[token / args.rps] : 1.0f;
+  }
+  const int n_lane = wn * (NT * 16) + kg * 4;                  // + i*16 + n0
+  const bool has_bias = G.bias != nullptr, has_cs = G.cs != nullptr, has_rs = args.rs != nullptr,
+             has_res = G.resid != nullptr;
+  int e_nt = nt_begin;
+  auto epilogue = [&]() {
+    const int n0 = e_nt * BN + n_lane;
+    ++e_nt;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int n = n0 + wn * (NT * 16) + i * 16 + kg * 4;
-      if (n >= N) continue;
-      f32x4 v = acc[i][j];
-      if (G.bias) {
-        const f32x4 b = *(const f32x4*)(G.bias + n);
-        v += b;
+      const int n = n0 + i * 16;
+      if (n < N) {
+        f32x4 bv = {0, 0, 0, 0}, sv = {1, 1, 1, 1};
+        if (has_bias) bv = *(const f32x4*)(G.bias + n);
+        if (has_cs) sv = *(const f32x4*)(G.cs + n);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          if ((rowok >> j) & 1u) {
+            f32x4 v = acc[i][j];
+            if (has_bias) v += bv;
+            if (has_cs) v *= sv;
+            if (has_rs) v *= rsv[j];
+            if (has_res) v += load_out4<TOUT>((const TOUT*)G.resid + roff[j] + n);
+            if (!(args.dbg & 4)) store_out4<TOUT>((TOUT*)G.y + yoff[j] + n, v);
+          }
+        }
       }
-      if (G.cs) {
-        const f32x4 s = *(const f32x4*)(G.cs + n);
-        v *= s;
-      }
-      if (args.rs) v *= rsv;
-      if (G.resid) v += load_out4<TOUT>((const TOUT*)G.resid + roff + n);
-      store_out4<TOUT>((TOUT*)G.y + yoff + n, v);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     }
+  };
+
+  // ---- main pipeline.  Two register sets: while step s is computed from LDS, the loads of step s+1 are
+  // landing in one set and the loads of step s+2 are issued into the other (issue early / write late; the
+  // sched_barriers keep hipcc from hoisting the vmcnt wait + LDS writes above the MFMA block).
+  u32x4 rxA[4], rwA[NT], rxB[4], rwB[NT];
+  unsigned mA = 0, mB = 0;
+  gload(rxA, rwA, mA);
+  if (steps > 1) gload(rxB, rwB, mB);
+  lstore(0, rxA, rwA, mA);
+  __syncthreads();
+  for (int s = 0; s < steps; s += 2) {
+    if (s + 2 < steps && !(args.dbg & 1)) gload(rxA, rwA, mA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(args.dbg & 2)) compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++c_kt == nkt) {
+      c_kt = 0;
+      if (!(args.dbg & 32)) epilogue();
+    }
+    if (s + 1 < steps && !(args.dbg & 8)) lstore(1, rxB, rwB, mB);
+    if (!(args.dbg & 16)) __syncthreads();
+    if (s + 1 >= steps) break;
+    if (s + 3 < steps && !(args.dbg & 1)) gload(rxB, rwB, mB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(args.dbg & 2)) compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++c_kt == nkt) {
+      c_kt = 0;
+      if (!(args.dbg & 32)) epilogue();
+    }
+    if (s + 2 < steps && !(args.dbg & 8)) lstore(0, rxA, rwA, mA);
+    if (!(args.dbg & 16)) __syncthreads();
   }
 }
 
@@ -257,8 +340,17 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
   for (int i = 0; i < a.ngroups; ++i) {
     a.g[i].n_tiles = (a.g[i].N + bn - 1) / bn;
     a.g[i].m_tiles = (int)((a.g[i].rows + kBM - 1) / kBM);
+    // ~16 pipeline steps per block: long enough to amortise pipeline fill/drain, short enough to balance
+    const int bke = 128 / (int)sizeof(TIN);
+    const int nkt = (a.g[i].K + bke - 1) / bke;
+    // pipeline steps per workgroup; 1 = one output tile per workgroup (measured best in situ on MI355X)
+    static const int target_steps = getenv("OCTIC_GEMM_STEPS") ? atoi(getenv("OCTIC_GEMM_STEPS")) : 1;
+    int chunk = target_steps / nkt;
+    chunk = chunk < 1 ? 1 : (chunk > a.g[i].n_tiles ? a.g[i].n_tiles : chunk);
+    a.g[i].chunk = chunk;
+    a.g[i].n_chunks = (a.g[i].n_tiles + chunk - 1) / chunk;
     a.g[i].tile_begin = t;
-    t += a.g[i].n_tiles * a.g[i].m_tiles;
+    t += a.g[i].n_chunks * a.g[i].m_tiles;
   }
   a.total_tiles = t;
   const size_t smem = (size_t)2 * (kBM + bn) * 128;
@@ -282,6 +374,8 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
 }
 
 inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
+  static const int dbg = getenv("OCTIC_GEMM_DBG") ? atoi(getenv("OCTIC_GEMM_DBG")) : 0;
+  a.dbg = dbg;
   if (dtype == OCTIC_F32 && out_dtype == OCTIC_F32) return launch_gemm<float, float>(a, s);
   if (dtype == OCTIC_BF16 && out_dtype == OCTIC_BF16) return launch_gemm<bf16, bf16>(a, s);
   if (dtype == OCTIC_BF16 && out_dtype == OCTIC_F32) return launch_gemm<bf16, float>(a, s);
@@ -305,6 +399,9 @@ int octic_linear_d8_fwd(const octic_view* x, const void* const w[5], const float
   for (int i = 0; i < 5; ++i)
     if (!w[i] || (((uintptr_t)w[i]) & 15)) return w[i] ? OCTIC_EALIGN : OCTIC_ENULL;
   if (M <= 0 || (rs && rows_per_sample <= 0)) return OCTIC_ESHAPE;
+  if (cs)
+    for (int i = 0; i < 5; ++i)
+      if (!cs[i]) return OCTIC_ENULL;
   GemmArgs a = {};
   a.ngroups = 5;
   a.rs = rs;
@@ -334,6 +431,17 @@ int octic_linear_d8_fwd(const octic_view* x, const void* const w[5], const float
     for (int i = 0; i < 5; ++i)
       if (!cs[i]) return OCTIC_ENULL;
   return dispatch_gemm(a, dtype, out_dtype, (hipStream_t)stream);
+}
+
+int octic_linear_d8_tile_n(int64_t M, int cin, int cout) {
+  GemmArgs a = {};
+  a.ngroups = 5;
+  for (int i = 0; i < 5; ++i) {
+    a.g[i].rows = i == 0 ? 2 * M : M;
+    a.g[i].K = i == 0 ? 2 * cin : cin;
+    a.g[i].N = i == 0 ? 2 * cout : cout;
+  }
+  return 32 * pick_nt(a);
 }
 
 int octic_lift_gemm(const void* patches, const void* w, const float* bias, const float* pos, float* out, int64_t B,

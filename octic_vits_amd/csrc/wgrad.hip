@@ -303,6 +303,17 @@ int64_t octic_linear_d8_wgrad_workspace_bytes(int cin, int cout, int splits) {
   return linear_slab_elems(cin, cout) * (int64_t)splits * 4;
 }
 
+int octic_linear_d8_wgrad_tile(int64_t M, int cin, int cout) {
+  WgArgs a = {};
+  a.ngroups = 5;
+  for (int i = 0; i < 5; ++i) {
+    a.g[i].K = i == 0 ? 2 * cin : cin;
+    a.g[i].N = i == 0 ? 2 * cout : cout;
+    a.g[i].rows = i == 0 ? 2 * M : M;
+  }
+  return 32 * pick_tt(a);
+}
+
 int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
   // enough row-splits to give every CU a couple of workgroups, bounded so the f32 slabs stay a
   // fraction of the activation bytes the kernel has to read anyway

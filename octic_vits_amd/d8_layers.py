@@ -462,8 +462,8 @@ class AttentionD8(nn.Module):
         if xp.dim() != 3:
             raise ValueError("AttentionD8 expects [B, N, C] irreps")
         qkv = self.qkv(xs if isinstance(xs, Octic) else Octic(xp, c))
-        heads = OF.PackHeadsFn.apply(qkv.packed, self.num_heads, c)
-        o = self.att(heads[0], heads[1], heads[2], dropout_p=self.attn_drop.p if self.training else 0.)
+        q, k, v = OF.PackHeadsFn.apply(qkv.packed, self.num_heads, c)
+        o = self.att(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.)
         on = Octic(OF.UnpackHeadsFn.apply(o, c), c)
         if self.proj_drop.active or resid is None:
             return _tail(self.proj_drop(self.proj(on)), resid, rs, cs)

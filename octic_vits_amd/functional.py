@@ -133,16 +133,15 @@ class WeightPrep:
         self.key = None
         self.wb = self.wt = None
 
-    def get(self, w5, cs5, dtype):
+    def get(self, w5, cs5, dtype, cin, cout):
         key = (dtype, tuple((w.data_ptr(), w._version) for w in w5),
                None if cs5 is None else tuple((s.data_ptr(), s._version) for s in cs5))
         if key != self.key:
             with torch.no_grad():
-                self.wb = [_c(w.detach().to(dtype)) for w in w5]
-                if cs5 is None:
-                    self.wt = [_c(w.detach().t().to(dtype)) for w in w5]
-                else:
-                    self.wt = [_c((w.detach() * s.detach()[:, None]).t().to(dtype)) for w, s in zip(w5, cs5)]
+                w32 = [_c(w.detach().float()) for w in w5]
+                cs32 = None if cs5 is None else [_c(s.detach().float()) for s in cs5]
+                wb, self.wt = ops.linear_prep(w32, cs32, cin, cout, dtype, want_wb=(dtype != torch.float32))
+                self.wb = wb if wb is not None else w32   # f32: the master weights are the forward operand
             self.key = key
         return self.wb, self.wt
 
@@ -154,13 +153,14 @@ class LinearD8Fn(torch.autograd.Function):
     def forward(ctx, x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps, dtype, prep):
         w5 = (wA1, wA2, wB1, wB2, wE)
         cs5 = None if sA1 is None else (sA1, sA2, sB1, sB2, sE)
+        ops._require_cuda(x)
         fused = resid is not None
         out_dtype = resid.dtype if fused else dtype
         x_in_dtype = x.dtype
         if x.dtype != dtype:
             x = ops.cast_rowscale(_c(x.float()), None, 1, dtype, cin)
         x = _c(x)
-        wb, wt = prep.get(w5, cs5, dtype)
+        wb, wt = prep.get(w5, cs5, dtype, cin, cout)
         lead = x.shape[:-1]
         M = x.numel() // (8 * cin)
         y = torch.empty(lead + (8 * cout,), dtype=out_dtype, device=x.device)
@@ -203,16 +203,20 @@ class LinearD8Fn(torch.autograd.Function):
 
 # --------------------------------------------------------------------------------- head packing
 class PackHeadsFn(torch.autograd.Function):
+    """packed qkv [B,T,3*8c] -> (q, k, v) each [B,H,T,8c/H].  Three separate outputs so autograd hands the three
+    SDPA gradients straight back (no zero-fill + add of a stacked [3,...] tensor)."""
+
     @staticmethod
     def forward(ctx, qkv, H, c):
         B, T = qkv.shape[0], qkv.shape[1]
         ctx.meta = (B, T, H, c)
-        return ops.pack_heads(_c(qkv), B, T, H, c, 3)
+        q, k, v = ops.pack_heads(_c(qkv), B, T, H, c, 3)
+        return q, k, v
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, gq, gk, gv):
         B, T, H, c = ctx.meta
-        return ops.unpack_heads(_c(g), B, T, H, c, 3), None, None
+        return ops.unpack_heads([gq, gk, gv], B, T, H, c), None, None
 
 
 class UnpackHeadsFn(torch.autograd.Function):
@@ -220,7 +224,7 @@ class UnpackHeadsFn(torch.autograd.Function):
     def forward(ctx, o, c):
         B, H, T, _ = o.shape
         ctx.meta = (B, T, H, c)
-        return ops.unpack_heads(_c(o), B, T, H, c, 1)
+        return ops.unpack_heads([o], B, T, H, c)
 
     @staticmethod
     def backward(ctx, g):

@@ -13,6 +13,64 @@ from . import _lib
 from ._lib import BF16, F32, OcticView, PtrArray5, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DTN = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the stream the kernels are launched on (torch's current
+    stream).  Disabled by default: zero overhead.  bench.py enables it over the timed steps to report the
+    dominant kernel's achieved bytes/s against the HBM roofline."""
+
+    def __init__(self):
+        self.on = False
+        self.records = []
+
+    def enable(self):
+        self.on, self.records = True, []
+
+    def disable(self):
+        self.on = False
+
+    def start(self):
+        if not self.on:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, e0, name, alg_bytes, flops=0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((name, e0, e1, alg_bytes, flops))
+
+    def _agg(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, b, f in self.records:
+            a = agg.setdefault(name, {"name": name, "launches": 0, "total_us": 0.0, "bytes": 0.0, "flops": 0.0})
+            a["launches"] += 1
+            a["total_us"] += e0.elapsed_time(e1) * 1e3
+            a["bytes"] += b
+            a["flops"] += f
+        for a in agg.values():
+            a["avg_us"] = a["total_us"] / a["launches"]
+            a["alg_bytes_per_launch"] = a["bytes"] / a["launches"]
+            a["flops_per_launch"] = a["flops"] / a["launches"]
+        return agg
+
+    def dominant(self):
+        agg = self._agg()
+        return max(agg.values(), key=lambda a: a["total_us"]) if agg else None
+
+    def summary(self):
+        return {k: {"launches": a["launches"], "total_us": round(a["total_us"], 1), "avg_us": round(a["avg_us"], 2),
+                    "GBps": round(a["alg_bytes_per_launch"] / a["avg_us"] / 1e3, 1)}
+                for k, a in sorted(self._agg().items(), key=lambda kv: -kv[1]["total_us"])}
+
+
+KERNEL_TIMER = KernelTimer()
 
 
 def dt_code(dtype):
@@ -104,11 +162,15 @@ def split_packed(t, c):
 
 # ------------------------------------------------------------------------------------------ launches
 def gelu_fwd(xv, yv, M, c, dtype, ref):
+    t = KERNEL_TIMER.start()
     check(lib().octic_gelu_d8_fwd(ctypes.byref(xv), ctypes.byref(yv), M, c, dt_code(dtype), _stream(ref)))
+    KERNEL_TIMER.stop(t, f"gelu_fwd_kernel<{_DTN[dtype]}>", 2 * M * 8 * c * ref.element_size())
 
 
 def gelu_bwd(gv, xv, ov, M, c, dtype, ref):
+    t = KERNEL_TIMER.start()
     check(lib().octic_gelu_d8_bwd(ctypes.byref(gv), ctypes.byref(xv), ctypes.byref(ov), M, c, dt_code(dtype), _stream(ref)))
+    KERNEL_TIMER.stop(t, f"gelu_bwd_kernel<{_DTN[dtype]}>", 3 * M * 8 * c * ref.element_size())
 
 
 def layernorm_fwd(x, alpha5, beta, eps, out_dtype, c, want_stats=True):
@@ -117,8 +179,10 @@ def layernorm_fwd(x, alpha5, beta, eps, out_dtype, c, want_stats=True):
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     stats = torch.empty((M, 8), dtype=torch.float32, device=x.device) if want_stats else None
     xv, yv = pview(x, c), pview(y, c)
+    t = KERNEL_TIMER.start()
     check(lib().octic_layernorm_d8_fwd(ctypes.byref(xv), ctypes.byref(yv), _arr5(alpha5), _p(beta), _p(stats), M, c,
                                        float(eps), dt_code(out_dtype), _stream(x)))
+    KERNEL_TIMER.stop(t, f"ln_fwd_kernel<{_DTN[out_dtype]}>", M * 8 * c * (4 + y.element_size()))
     return y, stats
 
 
@@ -130,9 +194,11 @@ def layernorm_bwd(g, x, stats, alpha5, dres, c, want_param_grads=True):
     partials = torch.empty((nblk, 2, 8 * c), dtype=torch.float32, device=x.device)
     gv, xv, dv = pview(g, c), pview(x, c), pview(dx, c)
     rv = pview(dres, c) if dres is not None else None
+    t = KERNEL_TIMER.start()
     check(lib().octic_layernorm_d8_bwd(ctypes.byref(gv), ctypes.byref(xv), _p(stats), _arr5(alpha5),
                                        ctypes.byref(rv) if rv is not None else None, ctypes.byref(dv), _p(partials),
                                        M, c, dt_code(g.dtype), _stream(x)))
+    KERNEL_TIMER.stop(t, f"ln_bwd_kernel<{_DTN[g.dtype]}>", M * 8 * c * (g.element_size() + 8 + (4 if dres is not None else 0)))
     if not want_param_grads or alpha5 is None:
         return dx, None, None
     dal = [torch.empty_like(a) for a in alpha5]
@@ -142,10 +208,16 @@ def layernorm_bwd(g, x, stats, alpha5, dres, c, want_param_grads=True):
 
 
 def linear_fwd(xv, w5, bias, yv, M, cin, cout, dtype, out_dtype, ref, resid_v=None, rs=None, rps=1, cs5=None):
+    t = KERNEL_TIMER.start()
     check(lib().octic_linear_d8_fwd(ctypes.byref(xv), _arr5(w5), _p(bias), ctypes.byref(yv),
                                     ctypes.byref(resid_v) if resid_v is not None else None, _p(rs), int(rps),
                                     _arr5(cs5) if cs5 is not None else None, M, cin, cout, dt_code(dtype),
                                     dt_code(out_dtype), _stream(ref)))
+    if t is not None:
+        es, eo = (2 if dtype == torch.bfloat16 else 4), (2 if out_dtype == torch.bfloat16 else 4)
+        nt = lib().octic_linear_d8_tile_n(M, cin, cout) // 32
+        nbytes = M * 8 * cin * es + M * 8 * cout * eo * (2 if resid_v is not None else 1) + 8 * cin * cout * es
+        KERNEL_TIMER.stop(t, f"linear_d8_kernel<{_DTN[dtype]},{_DTN[out_dtype]},{nt}>", nbytes, 24.0 * M * cin * cout)
 
 
 def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=None, dysum=None, want_bias=False):
@@ -154,8 +226,14 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
     dev = ref.device
     splits = L.octic_linear_d8_wgrad_splits(M, cin, cout)
     ws = torch.empty(L.octic_linear_d8_wgrad_workspace_bytes(cin, cout, splits) // 4, dtype=torch.float32, device=dev)
+    t = KERNEL_TIMER.start()
     check(L.octic_linear_d8_wgrad(ctypes.byref(xv), ctypes.byref(dyv), M, cin, cout, dt_code(dtype), _p(ws), splits,
                                   _stream(ref)))
+    if t is not None:
+        es = 2 if dtype == torch.bfloat16 else 4
+        tt = L.octic_linear_d8_wgrad_tile(M, cin, cout) // 32
+        KERNEL_TIMER.stop(t, f"wgrad_kernel<{_DTN[dtype]},{tt}>", M * 8 * (cin + cout) * es + splits * 8 * cin * cout * 4,
+                          24.0 * M * cin * cout)
     dw = [torch.empty((cout, cin), dtype=torch.float32, device=dev) for _ in range(4)]
     dw.append(torch.empty((2 * cout, 2 * cin), dtype=torch.float32, device=dev))
     dcs = None
@@ -182,27 +260,60 @@ def cast_rowscale(x, rs, rps, out_dtype, c):
     M = x.numel() // (8 * c)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     xv, yv = pview(x, c), pview(y, c)
+    t = KERNEL_TIMER.start()
     check(lib().octic_cast_rowscale(ctypes.byref(xv), ctypes.byref(yv), _p(rs), int(rps), M, c, dt_code(out_dtype),
                                     _stream(x)))
+    KERNEL_TIMER.stop(t, f"cast_rowscale_kernel<{_DTN[out_dtype]}>", M * 8 * c * (4 + y.element_size()))
     return y
+
+
+def _arr3(ts):
+    a = (ctypes.c_void_p * 3)()
+    for i in range(3):
+        a[i] = ts[i].data_ptr() if i < len(ts) else 0
+    return a
 
 
 def pack_heads(x, B, T, H, c, n_s):
-    """x packed [B,T,n_s*8c] -> [n_s,B,H,T,8c/H]"""
-    out = torch.empty((n_s, B, H, T, 8 * c // H), dtype=x.dtype, device=x.device)
+    """x packed [B,T,n_s*8c] -> n_s separate tensors [B,H,T,8c/H]"""
+    outs = [torch.empty((B, H, T, 8 * c // H), dtype=x.dtype, device=x.device) for _ in range(n_s)]
     xv = pview(x, n_s * c)
-    check(lib().octic_attn_pack_heads(ctypes.byref(xv), _p(out), B, T, H, c, n_s, dt_code(x.dtype), _stream(x)))
-    return out
+    t = KERNEL_TIMER.start()
+    check(lib().octic_attn_pack_heads(ctypes.byref(xv), _arr3(outs), B, T, H, c, n_s, dt_code(x.dtype), _stream(x)))
+    KERNEL_TIMER.stop(t, f"heads_permute_kernel<{_DTN[x.dtype]},pack>", 2 * x.numel() * x.element_size())
+    return outs
 
 
-def unpack_heads(o, B, T, H, c, n_s):
-    """[n_s,B,H,T,8c/H] -> packed [B,T,n_s*8c]"""
-    if not o.is_contiguous():
-        o = o.contiguous()
-    y = torch.empty((B, T, n_s * 8 * c), dtype=o.dtype, device=o.device)
+def unpack_heads(heads, B, T, H, c):
+    """list of n_s tensors [B,H,T,8c/H] -> packed [B,T,n_s*8c]"""
+    heads = [h if h.is_contiguous() else h.contiguous() for h in heads]
+    n_s = len(heads)
+    y = torch.empty((B, T, n_s * 8 * c), dtype=heads[0].dtype, device=heads[0].device)
     yv = pview(y, n_s * c)
-    check(lib().octic_attn_unpack_heads(_p(o), ctypes.byref(yv), B, T, H, c, n_s, dt_code(o.dtype), _stream(o)))
+    t = KERNEL_TIMER.start()
+    check(lib().octic_attn_unpack_heads(_arr3(heads), ctypes.byref(yv), B, T, H, c, n_s, dt_code(y.dtype), _stream(y)))
+    KERNEL_TIMER.stop(t, f"heads_permute_kernel<{_DTN[y.dtype]},unpack>", 2 * y.numel() * y.element_size())
     return y
+
+
+def linear_prep(w5, cs5, cin, cout, dtype, want_wb=True):
+    """One launch: (wb list of 5 views | None, wt list of 5 views) in `dtype` (see octic_linear_d8_prep)."""
+    dev = w5[0].device
+    n = 8 * cin * cout
+    wb = torch.empty(n, dtype=dtype, device=dev) if want_wb else None
+    wt = torch.empty(n, dtype=dtype, device=dev)
+    check(lib().octic_linear_d8_prep(_arr5(w5), _arr5(cs5) if cs5 is not None else None, cin, cout, _p(wb), _p(wt),
+                                     dt_code(dtype), _stream(w5[0])))
+    small = cin * cout
+
+    def views(flat, transposed):
+        if flat is None:
+            return None
+        out = [flat[i * small:(i + 1) * small].view((cin, cout) if transposed else (cout, cin)) for i in range(4)]
+        out.append(flat[4 * small:].view((2 * cin, 2 * cout) if transposed else (2 * cout, 2 * cin)))
+        return out
+
+    return views(wb, False), views(wt, True)
 
 
 def handoff_cat_fwd(x, c, out_dtype):

@@ -1,0 +1,255 @@
+"""DeiT-III-style training step on synthetic batches (the path the BASELINE metric times).
+
+Mirrors the reference's per-iteration body (deit/engine.py:43-87) and set-up (deit/main.py:340-381 with the
+recipe of experiments/train_deit.py:31-51): model.train -> bf16 autocast forward -> BCEWithLogits on multi-hot
+targets -> backward (gradients all-reduced over RCCL by DDP bucket hooks, overlapped with backward) -> LAMB step
+(lr 3e-3, wd 0.02) -> EMA update -> gradient norm.  Differences, all stated in DESIGN.md:
+  * autocast dtype is bf16 (BASELINE.json) instead of the reference's fp16 + loss scaler;
+  * the non-finite-loss check (engine.py:67-71) reads the PREVIOUS step's loss so the host never blocks on
+    the current step (the reference calls loss.item() and torch.cuda.synchronize() every iteration);
+  * the logged gradient norm is the one LAMB computes anyway (the reference makes a second pass,
+    engine.py:84).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class Lamb(torch.optim.Optimizer):
+    """LAMB as used by the reference recipe (timm/apex 'fusedlamb': grad-norm clipping to 1.0, bias-corrected
+    Adam update + weight decay, per-tensor trust ratio).  Multi-tensor (torch._foreach) implementation."""
+
+    def __init__(self, params, lr=3e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.02, max_grad_norm=1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm))
+        self.last_grad_norm = None
+
+    @torch.no_grad()
+    def step(self):
+        grads_all = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        norms = torch._foreach_norm(grads_all)
+        gnorm = torch.linalg.vector_norm(torch.stack(norms))
+        self.last_grad_norm = gnorm
+        mg = self.param_groups[0]["max_grad_norm"]
+        clip = torch.clamp(gnorm / mg, min=1.0) if mg is not None else None
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            grads = [p.grad for p in params]
+            if clip is not None:
+                grads = torch._foreach_div(grads, clip)
+            b1, b2 = group["betas"]
+            for p in params:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+            group["step"] = group.get("step", 0) + 1
+            t = group["step"]
+            m = [self.state[p]["exp_avg"] for p in params]
+            v = [self.state[p]["exp_avg_sq"] for p in params]
+            torch._foreach_lerp_(m, grads, 1 - b1)
+            torch._foreach_mul_(v, b2)
+            torch._foreach_addcmul_(v, grads, grads, 1 - b2)
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            denom = torch._foreach_sqrt(v)
+            torch._foreach_div_(denom, math.sqrt(bc2))
+            torch._foreach_add_(denom, group["eps"])
+            upd = torch._foreach_div(m, denom)
+            torch._foreach_div_(upd, bc1)
+            wd = group["weight_decay"]
+            if wd != 0:
+                torch._foreach_add_(upd, params, alpha=wd)
+                wn = torch._foreach_norm(params)
+                un = torch._foreach_norm(upd)
+                wn_t, un_t = torch.stack(wn), torch.stack(un)
+                ratio = torch.where((wn_t > 0) & (un_t > 0), wn_t / un_t, torch.ones_like(wn_t))
+                torch._foreach_mul_(upd, list(ratio.unbind(0)))
+            torch._foreach_add_(params, upd, alpha=-group["lr"])
+
+
+class FusedLamb:
+    """LAMB + EMA as ONE fused multi-tensor HIP step (octic_lamb_step, csrc/lamb.hip): same math as ``Lamb`` /
+    ``ModelEma`` above, 5 launches per step instead of ~100 foreach kernels, 52 B/param of HBM traffic.
+    Gradients are consumed (overwritten) by the step."""
+
+    CHUNK = 65536
+
+    def __init__(self, param_groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0, ema_decay=None):
+        from . import _lib
+        self._lib = _lib
+        self.lr, self.betas, self.eps, self.max_grad_norm, self.ema_decay = lr, betas, eps, max_grad_norm, ema_decay
+        self.params, wds = [], []
+        for g in param_groups:
+            for p in g["params"]:
+                if p.requires_grad:
+                    self.params.append(p)
+                    wds.append(float(g.get("weight_decay", 0.0)))
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedLamb runs on the GPU only")
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned in the flat state
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.ema = None
+        if ema_decay:
+            self.ema = torch.zeros(total, dtype=torch.float32, device=dev)
+            for p, o in zip(self.params, offs):
+                self.ema[o:o + p.numel()].copy_(p.detach().flatten())
+        self._offs = offs
+        ct, co, cl, tb = [], [], [], [0]
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            for o in range(0, n, self.CHUNK):
+                ct.append(i); co.append(o); cl.append(min(self.CHUNK, n - o))
+            tb.append(len(ct))
+        i32, i64 = torch.int32, torch.int64
+        self.chunk_tensor = torch.tensor(ct, dtype=i32, device=dev)
+        self.chunk_off = torch.tensor(co, dtype=i64, device=dev)
+        self.chunk_len = torch.tensor(cl, dtype=i32, device=dev)
+        self.tensor_chunk_begin = torch.tensor(tb, dtype=i32, device=dev)
+        self.wd = torch.tensor(wds, dtype=torch.float32, device=dev)
+        base = lambda t: [t.data_ptr() + 4 * o for o in offs]
+        self.p_ptrs = torch.tensor([p.data_ptr() for p in self.params], dtype=i64, device=dev)
+        self.m_ptrs = torch.tensor(base(self.m), dtype=i64, device=dev)
+        self.v_ptrs = torch.tensor(base(self.v), dtype=i64, device=dev)
+        self.e_ptrs = torch.tensor(base(self.ema), dtype=i64, device=dev) if self.ema is not None else None
+        self.g_ptrs = torch.zeros(len(self.params), dtype=i64, device=dev)
+        self._g_key = None
+        self.ntensors, self.nchunks = len(self.params), len(ct)
+        self.ws = torch.zeros(int(_lib.lib().octic_lamb_workspace_floats(self.ntensors, self.nchunks)),
+                              dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    @property
+    def last_grad_norm(self):
+        return self.ws[1]
+
+    def ema_state(self):
+        """EMA weights as {param index: tensor view} (same order as the parameters)."""
+        return [self.ema[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self._offs)]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        import ctypes
+        grads = []
+        for p in self.params:
+            if p.grad is None:
+                raise RuntimeError("FusedLamb: a trainable parameter received no gradient")
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = p.grad = g.float().contiguous()
+            grads.append(g)
+        key = tuple(g.data_ptr() for g in grads)
+        if key != self._g_key:
+            self.g_ptrs.copy_(torch.tensor(key, dtype=torch.int64), non_blocking=False)
+            self._g_key = key
+        self.step_count += 1
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.m.device).cuda_stream)
+        self._lib.check(self._lib.lib().octic_lamb_step(
+            vp(self.p_ptrs), vp(self.g_ptrs), vp(self.m_ptrs), vp(self.v_ptrs), vp(self.e_ptrs), vp(self.wd),
+            vp(self.chunk_tensor), vp(self.chunk_off), vp(self.chunk_len), vp(self.tensor_chunk_begin),
+            self.ntensors, self.nchunks, vp(self.ws), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+            float(self.eps), float(self.max_grad_norm or 0.0), self.step_count, float(self.ema_decay or 0.0), stream))
+
+
+def param_groups_weight_decay(model, weight_decay, no_decay_names=()):
+    """timm's rule: no weight decay for 1-D tensors, biases and the model's no_weight_decay() names."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim <= 1 or name.endswith(".bias") or name in no_decay_names:
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+class ModelEma:
+    """Exponential moving average of the parameters (timm ModelEma, decay 0.99996: deit/main.py:344-351)."""
+
+    def __init__(self, model, decay=0.99996):
+        self.decay = decay
+        self.params = [p.detach().clone() for p in model.parameters()]
+
+    @torch.no_grad()
+    def update(self, model):
+        torch._foreach_lerp_(self.params, [p.detach() for p in model.parameters()], 1.0 - self.decay)
+
+
+def synthetic_batch(batch, num_classes, device, seed, img_size=224):
+    """samples ~ randn like the reference's own benchmark (experiments/complexity.py:70); targets = multi-hot
+    (1-2 classes per row) as after Mixup + targets.gt(0) (deit/engine.py:47-54)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    samples = torch.randn(batch, 3, img_size, img_size, generator=g)
+    targets = torch.zeros(batch, num_classes)
+    idx = torch.randint(0, num_classes, (batch, 2), generator=g)
+    targets.scatter_(1, idx, 1.0)
+    return samples.to(device), targets.to(device)
+
+
+class Trainer:
+    def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
+                 fused_optimizer=True):
+        self.raw_model = model
+        self.model = model
+        if distributed:
+            # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)
+            self.model = nn.parallel.DistributedDataParallel(
+                model, device_ids=[local_rank], bucket_cap_mb=128, gradient_as_bucket_view=True,
+                find_unused_parameters=False, static_graph=False)
+        groups = param_groups_weight_decay(model, weight_decay, model.no_weight_decay())
+        if fused_optimizer:
+            self.optimizer = FusedLamb(groups, lr=lr, ema_decay=ema_decay)   # LAMB and EMA in one fused step
+            self.ema = None
+        else:
+            self.optimizer = Lamb(groups, lr=lr, weight_decay=weight_decay)
+            self.ema = ModelEma(model, ema_decay) if ema_decay else None
+        self.criterion = nn.BCEWithLogitsLoss()
+        self._pending_loss = None
+
+    def step(self, samples, targets):
+        self.model.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outputs = self.model(samples)
+            loss = self.criterion(outputs.float(), targets)
+        if self._pending_loss is not None and not math.isfinite(self._pending_loss.item()):
+            raise FloatingPointError("Loss is not finite, stopping training")   # engine.py:67-71, one step late
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        if self.ema is not None:
+            self.ema.update(self.raw_model)
+        self._pending_loss = loss.detach()
+        return loss
+
+
+def init_distributed():
+    """One process per GPU, RCCL via torch.distributed (backend name 'nccl' on ROCm)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local_rank

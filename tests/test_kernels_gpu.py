@@ -259,11 +259,26 @@ def test_pack_unpack_heads(B, T, H, c, dtype):
     got = o.pack_heads(pack(qkvs).to(DEV), B, T, H, c, 3)
     for i, w in enumerate((q, k, v)):
         assert torch.equal(got[i].cpu(), w), f"pack s={i}"
-    # unpack is the exact inverse (n_s = 3) and matches the oracle for n_s = 1
-    back = o.unpack_heads(got, B, T, H, c, 3)
+    # unpack is the exact inverse (n_s = 3, three separately allocated tensors) and matches the oracle for n_s = 1
+    back = o.unpack_heads([g.clone() for g in got], B, T, H, c)
     assert torch.equal(back.cpu(), pack(qkvs))
-    out = o.unpack_heads(got[0:1].contiguous(), B, T, H, c, 1)
+    out = o.unpack_heads([got[0]], B, T, H, c)
     assert torch.equal(out.cpu(), pack(R.unpack_heads(q)))
+
+
+def test_linear_prep_matches_torch():
+    o = ops()
+    cin, cout = 48, 144
+    lin = cases.fill_parameters(R.LinearD8(8 * cin, 8 * cout, bias=False))
+    w = [getattr(lin, "lin_" + n).weight.detach().to(DEV).contiguous() for n in ("A1", "A2", "B1", "B2", "E")]
+    cs = [(0.5 + 0.2 * cases.randn(f"prep.cs{i}", cout if i < 4 else 2 * cout)).to(DEV) for i in range(5)]
+    for dtype in (torch.float32, torch.bfloat16):
+        wb, wt = o.linear_prep(w, cs, cin, cout, dtype)
+        for i in range(5):
+            assert torch.equal(wb[i], w[i].to(dtype))
+            assert torch.equal(wt[i], (w[i] * cs[i][:, None]).t().to(dtype))
+        wb2, wt2 = o.linear_prep(w, None, cin, cout, dtype)
+        assert all(torch.equal(a, b.t().to(dtype)) for a, b in zip(wt2, w))
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
