@@ -37,15 +37,16 @@ def usable_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(batch=2, steps=1):
+def cpu_baseline(batch=4, steps=2):
     """The oracle (CPU restatement of the reference, pinned by tests/golden) on the host cores: same model,
     fp32, fwd + bwd + LAMB step, bounded sample."""
     from oracle import octic_ref as R
     from octic_vits_amd.train import Lamb, param_groups_weight_decay, synthetic_batch
     torch.manual_seed(0)
-    # torch's CPU ops stop scaling (and then collapse) far below this box's 256 hardware threads; 32 is
-    # the measured sweet spot region for this op mix.  `cores` reports the threads actually used.
-    cores = min(usable_cores(), int(os.environ.get("OCTIC_CPU_THREADS", "32")))
+    # torch's CPU ops scale NEGATIVELY on the 256-thread GPU host for this op mix (measured: 16 threads
+    # 0.84 img/s, 32 -> 0.60, 64 -> 0.33, all 256 did not finish in 40 min), so the baseline uses 16.
+    # `cores` reports the threads actually used.
+    cores = min(usable_cores(), int(os.environ.get("OCTIC_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     log(f"cpu_baseline: {cores} usable cores (os.cpu_count()={os.cpu_count()}), batch {batch}")
     model = R.create_model("hybrid_deit_huge_patch14", num_classes=1000, drop_path_rate=0.5, img_size=224).train()
