@@ -313,6 +313,492 @@ __global__ __launch_bounds__(256, 2) void linear_d8_kernel(GemmArgs args) {
   }
 }
 
+// ================================================================================================
+// LDS-DMA ring variant (the fast path).  Same math and epilogue as linear_d8_kernel, different data movement:
+//   * tiles go HBM/L2 -> LDS with global_load_lds (16 B per lane, 1 KiB per wave-instruction, no VGPR staging,
+//     no ds_write); the XOR swizzle is applied on the per-lane SOURCE address (the LDS image of a DMA is
+//     lane-linear), the reads use the same involution;
+//   * a 3-stage ring keeps TWO k-tiles in flight behind the one being multiplied; completion is tracked with
+//     counted `s_waitcnt vmcnt(N)` (N = this wave's DMA instructions per tile) and raw `s_barrier`s, so
+//     nothing drains the queue inside the loop (PMC on the register-staged kernel: 51 % of wave cycles in
+//     SQ_WAIT_ANY, ~1 tile in flight);
+//   * tile 128 rows x 80 outputs, 4 waves each owning 32 rows x 80 columns (5 x 2 MFMA tiles): each wave DMAs
+//     exactly the X rows it consumes plus a share of the W rows; 3 x 26 KiB of LDS -> 2 workgroups per CU.
+// Requirements (else the register-staged kernel runs): K a multiple of one MFMA k-step (32 bf16 / 16 f32) so a
+// partially valid k-step never has to be zero-filled — out-of-range ROWS are simply clamped (a garbage row only
+// feeds outputs that are never stored).
+// ================================================================================================
+constexpr int kRingBN = 80;
+constexpr int kRingS = 3;
+constexpr int kRingStage = (kBM + kRingBN) * 128;
+
+// Sink for the stores of out-of-range lanes: every epilogue store instruction is executed by the whole wave
+// (exact vmcnt bookkeeping needs a fixed number of VMEM instructions per epilogue), lanes that have nothing to
+// write are pointed here.
+__device__ char g_store_sink[64 * 16 * 2];
+
+__device__ inline void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt needs an immediate
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <typename TIN, typename TOUT, int EPI>
+__global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
+  constexpr int EPC = Elem<TIN>::EPC;
+  constexpr int BKE = 8 * EPC;
+  constexpr int NT = 5, MT = 2;
+  constexpr int NSTORE = NT * MT;             // store instructions per wave per epilogue
+  typedef typename Elem<TIN>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // kRingS stages x (128 + 80) rows x 128 B
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (i < args.ngroups && tile >= args.g[i].tile_begin) gi = i;
+  const GemmGroup& G = args.g[gi];
+  // work item = (m-tile, chunk of consecutive n-tiles); the DMA ring runs continuously over its (n-tile, k-tile) steps
+  const int lt = tile - G.tile_begin;
+  const int mt = lt / G.n_chunks, nc = lt - mt * G.n_chunks;
+  const int64_t m0 = (int64_t)mt * kBM;
+  const int nt_begin = nc * G.chunk;
+  const int nt_count = (G.n_tiles - nt_begin) < G.chunk ? (G.n_tiles - nt_begin) : G.chunk;
+  const int K = G.K, N = G.N;
+  const int nkt = (K + BKE - 1) / BKE;
+  const int steps = nt_count * nkt;
+  const bool last_half_only = (K - (nkt - 1) * BKE) <= 4 * EPC;
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, kg = lane >> 4;
+
+  // ---- DMA sources.  A wave-instruction fills 8 LDS rows: lane -> row (lane>>3), chunk position (lane&7), which
+  // must hold source chunk (lane&7) ^ (row&7) = (lane&7) ^ (lane>>3).
+  const int drow = lane >> 3;
+  const int dkc = (lane & 7) ^ drow;
+  const char* xsrc[4];   // this wave's 32 X rows: instruction q covers rows 32*wid + 8q .. +7
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int64_t mm = m0 + wid * 32 + q * 8 + drow;
+    mm = mm < G.rows ? mm : G.rows - 1;
+    const int64_t off = G.pair ? (mm >> 1) * G.a_ld + (mm & 1) * (int64_t)K : mm * G.a_ld;
+    xsrc[q] = G.a + off * (int64_t)sizeof(TIN);
+  }
+  // W rows: 10 instructions over 4 waves: waves 0,1 take 3, waves 2,3 take 2
+  const int w_first = wid < 2 ? wid * 3 : 6 + (wid - 2) * 2;
+  const int w_cnt = wid < 2 ? 3 : 2;
+  const int dma_cnt = 4 + w_cnt;              // this wave's DMA instructions per step
+  const char* wsrc[3];
+  auto set_w = [&](int nt) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      int n = nt * kRingBN + (w_first + q) * 8 + drow;
+      n = n < N ? n : N - 1;
+      wsrc[q] = G.w + (int64_t)n * K * (int64_t)sizeof(TIN);
+    }
+  };
+  int l_nt = nt_begin, l_kt = 0, l_stage = 0;   // DMA stream position
+  set_w(l_nt);
+  auto issue = [&]() {
+    int k = l_kt * BKE + dkc * EPC;
+    k = k < K ? k : 0;                        // chunks past K belong to a skipped k-step: any valid address
+    const int kb = k * (int)sizeof(TIN);
+    char* st = lds + l_stage * kRingStage;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[q] + kb),
+                                       (__attribute__((address_space(3))) void*)(st + (wid * 4 + q) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < w_cnt)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + kb),
+                                         (__attribute__((address_space(3))) void*)(st + kBM * 128 + (w_first + q) * 1024),
+                                         16, 0, 0);
+    l_stage = l_stage == kRingS - 1 ? 0 : l_stage + 1;
+    if (++l_kt == nkt) {
+      l_kt = 0;
+      ++l_nt;
+      if (l_nt < nt_begin + nt_count) set_w(l_nt);
+    }
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  const int sw = fr & 7;
+  const int rd_w = kBM * 128 + fr * 128;                // + i*2048
+  const int rd_x = (wid * 32 + fr) * 128;               // + j*2048
+  const int ch0 = (kg ^ sw) << 4, ch1 = ((4 + kg) ^ sw) << 4;
+
+  // ---- epilogue constants (per workgroup): output row base pointers (or the sink), residual rows, drop-path scale
+  TOUT* ybase[MT];
+  const TOUT* rbase[MT];
+  float rsv[MT];
+  bool rok[MT];
+  TOUT* const sink = (TOUT*)(g_store_sink + lane * 16);
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int64_t mm = m0 + wid * 32 + j * 16 + fr;
+    rok[j] = mm < G.rows;
+    const int64_t mc = rok[j] ? mm : 0;
+    const int64_t token = G.pair ? (mc >> 1) : mc;
+    int64_t yoff, roff;
+    if (args.lift_np > 0) {
+      const int64_t b = mc / args.lift_np, p = mc - b * args.lift_np;
+      yoff = (b * (args.lift_np + args.lift_tok0) + args.lift_tok0 + p) * G.y_ld;
+      roff = p * G.r_ld;
+    } else {
+      yoff = G.pair ? (mc >> 1) * G.y_ld + (mc & 1) * (int64_t)N : mc * G.y_ld;
+      roff = G.pair ? (mc >> 1) * G.r_ld + (mc & 1) * (int64_t)N : mc * G.r_ld;
+    }
+    ybase[j] = (TOUT*)G.y + yoff;
+    rbase[j] = (const TOUT*)G.resid + roff;
+    rsv[j] = (EPI == 1 && args.rs) ? args.rs[token / args.rps] : 1.0f;
+  }
+  const bool has_bias = G.bias != nullptr;
+  const bool has_cs = EPI == 1 && G.cs != nullptr, has_rs = EPI == 1 && args.rs != nullptr,
+             has_res = EPI == 1 && G.resid != nullptr;
+  int e_nt = nt_begin;
+  auto epilogue = [&]() {
+    const int nb = e_nt * kRingBN + kg * 4;
+    ++e_nt;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = nb + i * 16;
+      const bool nok = n < N;
+      const int nc2 = nok ? n : 0;
+      f32x4 bv = {0, 0, 0, 0}, sv = {1, 1, 1, 1};
+      if (has_bias) bv = *(const f32x4*)(G.bias + nc2);
+      if (has_cs) sv = *(const f32x4*)(G.cs + nc2);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const bool ok = nok && rok[j];
+        f32x4 v = acc[i][j];
+        if (has_bias) v += bv;
+        if (has_cs) v *= sv;
+        if (has_rs) v *= rsv[j];
+        if (has_res) v += load_out4<TOUT>(ok ? rbase[j] + n : (const TOUT*)sink);
+        store_out4<TOUT>(ok ? ybase[j] + n : sink, v);     // always issued: exactly NSTORE stores per epilogue
+        acc[i][j] = f32x4{0, 0, 0, 0};
+      }
+    }
+  };
+
+  // ---- ring.  VMEM program order per step s:  [wait tile s][barrier] DMA(s+2)  compute(s)  [stores if n-tile done]
+  // so the ops younger than DMA(s) at the wait of step s are: stores(s-2)?, DMA(s+1), stores(s-1)?.
+  issue();
+  if (steps > 1) issue();
+  int c_kt = 0, c_stage = 0;
+  int st1 = 0, st2 = 0;   // store instructions issued in step s-1 / s-2
+  for (int s = 0; s < steps; ++s) {
+    if (has_res) wait_vmcnt(0);               // residual loads have VGPR destinations: keep hipcc's own waits exact
+    else wait_vmcnt(s + 1 < steps ? dma_cnt + st1 + st2 : 0);
+    __builtin_amdgcn_s_barrier();             // every wave's share of tile s has landed; the stage of tile s-1 is free
+    if (s + 2 < steps) issue();
+    const char* base = lds + c_stage * kRingStage;
+    c_stage = c_stage == kRingS - 1 ? 0 : c_stage + 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1 && last_half_only && c_kt == nkt - 1) break;
+      const int ch = ks ? ch1 : ch0;
+      frag af[NT], bfr[MT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) af[i] = *(const frag*)(base + rd_w + i * 2048 + ch);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) bfr[j] = *(const frag*)(base + rd_x + j * 2048 + ch);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+    }
+    st2 = st1;
+    st1 = 0;
+    if (++c_kt == nkt) {
+      c_kt = 0;
+      epilogue();
+      st1 = NSTORE;
+    }
+  }
+}
+
+// ================================================================================================
+// X-stationary variant for the short-K problems (K = 32*KSTEPS <= 320: qkv, proj, fc1 and the input gradient of
+// fc2 at ViT-H) — bf16 only.  Measured motivation: with a 128x80 tile the ring kernel pulls 877 MB through the
+// L1s for a 210 MB (fc1) problem, 560 MB of it X k-tiles re-read once per 80-column n-tile; L2->CU delivers
+// ~70 GB/s per CU, so operand re-fetch, not HBM, bounds it.  Here every wave loads the MFMA operand fragments
+// of ITS 32 token rows for the whole K once (<= 80 VGPRs) and keeps them while the workgroup walks all its
+// n-tiles; only W tiles [80 x 64k] stream through a 3-stage LDS-DMA ring (30 KiB LDS -> 3 workgroups per CU).
+// L2->CU traffic for fc1: 42 MB (X once) + 316 MB (W per 128-row block) = 358 MB.
+// ================================================================================================
+constexpr int kXStage = kRingBN * 128;   // one W tile: 80 rows x 128 B
+
+template <typename TOUT, int EPI, int KSTEPS>
+__global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
+  constexpr int NT = 5, MT = 2;
+  constexpr int NKT = (KSTEPS + 1) / 2;      // 64-wide W tiles per n-tile
+  constexpr int NSTORE = NT * MT;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // kRingS stages x 80 rows x 128 B
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (i < args.ngroups && tile >= args.g[i].tile_begin) gi = i;
+  const GemmGroup& G = args.g[gi];
+  const int lt = tile - G.tile_begin;
+  const int mt = lt / G.n_chunks, nc = lt - mt * G.n_chunks;
+  const int64_t m0 = (int64_t)mt * kBM;
+  const int nt_begin = nc * G.chunk;
+  const int nt_count = (G.n_tiles - nt_begin) < G.chunk ? (G.n_tiles - nt_begin) : G.chunk;
+  const int K = G.K, N = G.N;
+  const int ksteps = K >> 5;                 // 32-wide MFMA k-steps of THIS group (<= KSTEPS; E has twice the 1-D count)
+  const int nkt = (ksteps + 1) >> 1;         // 64-wide W tiles per n-tile
+  const int steps = nt_count * nkt;
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, kg = lane >> 4;
+
+  // ---- W DMA sources (as in the ring kernel): 10 wave-instructions per tile, waves 0,1 take 3, waves 2,3 take 2
+  const int drow = lane >> 3;
+  const int dkc = (lane & 7) ^ drow;
+  const int w_first = wid < 2 ? wid * 3 : 6 + (wid - 2) * 2;
+  const int w_cnt = wid < 2 ? 3 : 2;
+  const char* wsrc[3];
+  auto set_w = [&](int nt) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      int n = nt * kRingBN + (w_first + q) * 8 + drow;
+      n = n < N ? n : N - 1;
+      wsrc[q] = G.w + (int64_t)n * K * 2;
+    }
+  };
+  int l_nt = nt_begin, l_kt = 0, l_stage = 0;
+  set_w(l_nt);
+  auto issue = [&]() {
+    int k = l_kt * 64 + dkc * 8;
+    k = k < K ? k : 0;
+    char* st = lds + l_stage * kXStage;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < w_cnt)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + k * 2),
+                                         (__attribute__((address_space(3))) void*)(st + (w_first + q) * 1024), 16, 0, 0);
+    l_stage = l_stage == kRingS - 1 ? 0 : l_stage + 1;
+    if (++l_kt == nkt) {
+      l_kt = 0;
+      ++l_nt;
+      if (l_nt < nt_begin + nt_count) set_w(l_nt);
+    }
+  };
+  // the W stream starts first so it overlaps the X fragment loads below
+  issue();
+  if (steps > 1) issue();
+
+  // ---- X fragments of this wave's 32 rows for the whole K: lane (fr,kg) holds X[row fr][32 ks + 8 kg .. +7]
+  bf16x8 xf[KSTEPS][MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    int64_t mm = m0 + wid * 32 + j * 16 + fr;
+    mm = mm < G.rows ? mm : G.rows - 1;          // clamped rows feed outputs that go to the sink
+    const int64_t off = G.pair ? (mm >> 1) * G.a_ld + (mm & 1) * (int64_t)K : mm * G.a_ld;
+    const bf16* xr = (const bf16*)G.a + off + kg * 8;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+      if (ks < ksteps) xf[ks][j] = *(const bf16x8*)(xr + ks * 32);   // wave-uniform guard
+  }
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  const int sw = fr & 7;
+  const int rd_w = fr * 128;                            // + i*2048
+  const int ch0 = (kg ^ sw) << 4, ch1 = ((4 + kg) ^ sw) << 4;
+
+  // ---- epilogue constants
+  TOUT* ybase[MT];
+  const TOUT* rbase[MT];
+  float rsv[MT];
+  bool rok[MT];
+  TOUT* const sink = (TOUT*)(g_store_sink + lane * 16);
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int64_t mm = m0 + wid * 32 + j * 16 + fr;
+    rok[j] = mm < G.rows;
+    const int64_t mc = rok[j] ? mm : 0;
+    const int64_t token = G.pair ? (mc >> 1) : mc;
+    const int64_t yoff = G.pair ? (mc >> 1) * G.y_ld + (mc & 1) * (int64_t)N : mc * G.y_ld;
+    const int64_t roff = G.pair ? (mc >> 1) * G.r_ld + (mc & 1) * (int64_t)N : mc * G.r_ld;
+    ybase[j] = (TOUT*)G.y + yoff;
+    rbase[j] = (const TOUT*)G.resid + roff;
+    rsv[j] = (EPI == 1 && args.rs) ? args.rs[token / args.rps] : 1.0f;
+  }
+  const bool has_bias = G.bias != nullptr;
+  const bool has_cs = EPI == 1 && G.cs != nullptr, has_rs = EPI == 1 && args.rs != nullptr,
+             has_res = EPI == 1 && G.resid != nullptr;
+  int e_nt = nt_begin;
+  auto epilogue = [&]() {
+    const int nb = e_nt * kRingBN + kg * 4;
+    ++e_nt;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = nb + i * 16;
+      const bool nok = n < N;
+      const int nc2 = nok ? n : 0;
+      f32x4 bv = {0, 0, 0, 0}, sv = {1, 1, 1, 1};
+      if (has_bias) bv = *(const f32x4*)(G.bias + nc2);
+      if (has_cs) sv = *(const f32x4*)(G.cs + nc2);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const bool ok = nok && rok[j];
+        f32x4 v = acc[i][j];
+        if (has_bias) v += bv;
+        if (has_cs) v *= sv;
+        if (has_rs) v *= rsv[j];
+        if (has_res) v += load_out4<TOUT>(ok ? rbase[j] + n : (const TOUT*)sink);
+        store_out4<TOUT>(ok ? ybase[j] + n : sink, v);
+        acc[i][j] = f32x4{0, 0, 0, 0};
+      }
+    }
+  };
+
+  // ---- ring over (n-tile, k-tile) steps; only W moves
+  const bool plain_waits = !(has_res || has_bias || has_cs);   // VGPR-destination loads in the epilogue: drain instead
+  int c_stage = 0, st1 = 0, st2 = 0;
+  for (int nt_i = 0; nt_i < nt_count; ++nt_i) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt >= nkt) break;                    // wave-uniform
+      const int s = nt_i * nkt + kt;
+      if (plain_waits) wait_vmcnt(s + 1 < steps ? w_cnt + st1 + st2 : 0);
+      else wait_vmcnt(0);
+      __builtin_amdgcn_s_barrier();
+      if (s + 2 < steps) issue();
+      const char* base = lds + c_stage * kXStage + rd_w;
+      c_stage = c_stage == kRingS - 1 ? 0 : c_stage + 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (kt * 2 + ks < ksteps) {
+          const int ch = ks ? ch1 : ch0;
+          bf16x8 af[NT];
+#pragma unroll
+          for (int i = 0; i < NT; ++i) af[i] = *(const bf16x8*)(base + i * 2048 + ch);
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], xf[kt * 2 + ks][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      st2 = st1;
+      st1 = 0;
+    }
+    epilogue();
+    st1 = NSTORE;
+  }
+}
+
+template <typename TOUT, int KSTEPS>
+int launch_xreg_k(GemmArgs& a, bool fused, int t, hipStream_t s) {
+  const size_t smem = (size_t)kRingS * kXStage;
+  if (fused) linear_d8_xreg_kernel<TOUT, 1, KSTEPS><<<t, 256, smem, s>>>(a);
+  else linear_d8_xreg_kernel<TOUT, 0, KSTEPS><<<t, 256, smem, s>>>(a);
+  return launch_status();
+}
+
+// returns -100 when the problem does not qualify (caller falls through to the ring kernel)
+template <typename TOUT>
+int launch_xreg(GemmArgs& a, hipStream_t s) {
+  static const int use = getenv("OCTIC_GEMM_XREG") ? atoi(getenv("OCTIC_GEMM_XREG")) : 1;
+  if (!use || a.lift_np > 0) return -100;
+  int kmax = 0;
+  for (int i = 0; i < a.ngroups; ++i) {
+    if (a.g[i].K % 32) return -100;
+    kmax = a.g[i].K / 32 > kmax ? a.g[i].K / 32 : kmax;
+  }
+  if (kmax > 10) return -100;
+  int t = 0;
+  bool fused = a.rs != nullptr;
+  // n-tiles walked per workgroup: sized so the launch has ~2000 workgroups (measured sweet spot on MI355X: fewer,
+  // longer workgroups lose to imbalance, more of them re-load the X fragments too often)
+  static const int force_tiles = getenv("OCTIC_XREG_TILES") ? atoi(getenv("OCTIC_XREG_TILES")) : 0;
+  int64_t items = 0;
+  for (int i = 0; i < a.ngroups; ++i)
+    items += ((a.g[i].rows + kBM - 1) / kBM) * ((a.g[i].N + kRingBN - 1) / kRingBN);
+  int max_tiles = force_tiles ? force_tiles : (int)((items + 1024) / 2048);
+  max_tiles = max_tiles < 1 ? 1 : max_tiles;
+  for (int i = 0; i < a.ngroups; ++i) {
+    a.g[i].n_tiles = (a.g[i].N + kRingBN - 1) / kRingBN;
+    a.g[i].m_tiles = (int)((a.g[i].rows + kBM - 1) / kBM);
+    const int chunk = a.g[i].n_tiles < max_tiles ? a.g[i].n_tiles : max_tiles;
+    a.g[i].chunk = chunk;
+    a.g[i].n_chunks = (a.g[i].n_tiles + chunk - 1) / chunk;
+    a.g[i].tile_begin = t;
+    t += a.g[i].n_chunks * a.g[i].m_tiles;
+    fused = fused || a.g[i].cs || a.g[i].resid;
+  }
+  if (kmax <= 4) return launch_xreg_k<TOUT, 4>(a, fused, t, s);
+  if (kmax <= 6) return launch_xreg_k<TOUT, 6>(a, fused, t, s);
+  return launch_xreg_k<TOUT, 10>(a, fused, t, s);
+}
+
+template <typename TIN, typename TOUT>
+int launch_ring(GemmArgs& a, hipStream_t s) {
+  int t = 0;
+  bool fused = a.rs != nullptr || a.lift_np > 0;
+  for (int i = 0; i < a.ngroups; ++i) {
+    a.g[i].n_tiles = (a.g[i].N + kRingBN - 1) / kRingBN;
+    a.g[i].m_tiles = (int)((a.g[i].rows + kBM - 1) / kBM);
+    static const int target_steps = getenv("OCTIC_RING_STEPS") ? atoi(getenv("OCTIC_RING_STEPS")) : 1;
+    const int bke = 128 / (int)sizeof(TIN);
+    const int nkt = (a.g[i].K + bke - 1) / bke;
+    int chunk = target_steps / nkt;
+    chunk = chunk < 1 ? 1 : (chunk > a.g[i].n_tiles ? a.g[i].n_tiles : chunk);
+    a.g[i].chunk = chunk;
+    a.g[i].n_chunks = (a.g[i].n_tiles + chunk - 1) / chunk;
+    a.g[i].tile_begin = t;
+    t += a.g[i].n_chunks * a.g[i].m_tiles;
+    fused = fused || a.g[i].cs || a.g[i].resid;
+  }
+  a.total_tiles = t;
+  const size_t smem = (size_t)kRingS * kRingStage;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  if (fused) linear_d8_ring_kernel<TIN, TOUT, 1><<<t, 256, smem, s>>>(a);
+  else linear_d8_ring_kernel<TIN, TOUT, 0><<<t, 256, smem, s>>>(a);
+  return launch_status();
+}
+
+inline bool ring_ok(const GemmArgs& a, int dtype) {
+  static const int use_ring = getenv("OCTIC_GEMM_RING") ? atoi(getenv("OCTIC_GEMM_RING")) : 1;
+  if (!use_ring) return false;
+  const int kstep = dtype == OCTIC_BF16 ? 32 : 16;
+  for (int i = 0; i < a.ngroups; ++i)
+    if (a.g[i].K % kstep) return false;
+  return true;
+}
+
 inline int pick_nt(const GemmArgs& a) {
   // minimise padded work; prefer the wider tile on ties (fewer re-reads of the token panel)
   int best = 2;
@@ -376,6 +862,16 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
 inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
   static const int dbg = getenv("OCTIC_GEMM_DBG") ? atoi(getenv("OCTIC_GEMM_DBG")) : 0;
   a.dbg = dbg;
+  if (dtype == OCTIC_BF16) {
+    const int r = out_dtype == OCTIC_BF16 ? launch_xreg<bf16>(a, s) : (out_dtype == OCTIC_F32 ? launch_xreg<float>(a, s) : -100);
+    if (r != -100) return r;
+  }
+  if (ring_ok(a, dtype)) {
+    if (dtype == OCTIC_F32 && out_dtype == OCTIC_F32) return launch_ring<float, float>(a, s);
+    if (dtype == OCTIC_BF16 && out_dtype == OCTIC_BF16) return launch_ring<bf16, bf16>(a, s);
+    if (dtype == OCTIC_BF16 && out_dtype == OCTIC_F32) return launch_ring<bf16, float>(a, s);
+    return OCTIC_EDTYPE;
+  }
   if (dtype == OCTIC_F32 && out_dtype == OCTIC_F32) return launch_gemm<float, float>(a, s);
   if (dtype == OCTIC_BF16 && out_dtype == OCTIC_BF16) return launch_gemm<bf16, bf16>(a, s);
   if (dtype == OCTIC_BF16 && out_dtype == OCTIC_F32) return launch_gemm<bf16, float>(a, s);

@@ -215,9 +215,20 @@ def linear_fwd(xv, w5, bias, yv, M, cin, cout, dtype, out_dtype, ref, resid_v=No
                                     dt_code(out_dtype), _stream(ref)))
     if t is not None:
         es, eo = (2 if dtype == torch.bfloat16 else 4), (2 if out_dtype == torch.bfloat16 else 4)
-        nt = lib().octic_linear_d8_tile_n(M, cin, cout) // 32
         nbytes = M * 8 * cin * es + M * 8 * cout * eo * (2 if resid_v is not None else 1) + 8 * cin * cout * es
-        KERNEL_TIMER.stop(t, f"linear_d8_kernel<{_DTN[dtype]},{_DTN[out_dtype]},{nt}>", nbytes, 24.0 * M * cin * cout)
+        fused = int(resid_v is not None or rs is not None or cs5 is not None)
+        KERNEL_TIMER.stop(t, linear_kernel_name(cin, dtype, out_dtype, fused), nbytes, 24.0 * M * cin * cout)
+
+
+def linear_kernel_name(cin, dtype, out_dtype, fused):
+    """Name of the kernel instantiation octic_linear_d8_fwd dispatches to (mirrors dispatch_gemm in csrc/gemm.hip)."""
+    if dtype == torch.bfloat16 and (2 * cin) % 32 == 0 and cin % 32 == 0 and 2 * cin // 32 <= 10:
+        ks = 2 * cin // 32
+        return f"linear_d8_xreg_kernel<{_DTN[out_dtype]},{fused},{4 if ks <= 4 else (6 if ks <= 6 else 10)}>"
+    kstep = 32 if dtype == torch.bfloat16 else 16
+    if cin % kstep == 0:
+        return f"linear_d8_ring_kernel<{_DTN[dtype]},{_DTN[out_dtype]},{fused}>"
+    return f"linear_d8_kernel<{_DTN[dtype]},{_DTN[out_dtype]}>"
 
 
 def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=None, dysum=None, want_bias=False):
