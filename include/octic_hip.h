@@ -153,6 +153,23 @@ int octic_attn_pack_heads(const octic_view* qkv, void* const heads[3], int64_t B
 int octic_attn_unpack_heads(void* const heads[3], const octic_view* y, int64_t B, int64_t T, int H, int c, int n_s,
                             int dtype, void* stream);
 
+/* ---- attention core (bf16) ---------------------------------------------------------------------
+ * o = softmax(scale * q k^T) v per (batch, head); replaces F.scaled_dot_product_attention in AttentionD8
+ * (d8_layers.py:645-648) and the standard blocks (deit/vit.py:41-45).  Element (b,h,t,d) of q/k/v is at
+ * base + b*sB + h*sH + t*sT + d (one stride set for the three, so [B,H,T,hd] and the [B,T,3,H,hd] views of a
+ * fused qkv tensor both work); o likewise with oB/oH/oT.  lse ([B,H,T] f32, may be NULL) receives the
+ * log2-domain log-sum-exp needed by the backward.  T <= 320, hd a multiple of 16 (<= 128); otherwise
+ * OCTIC_ESHAPE (callers keep torch SDPA for such shapes).                                            */
+int octic_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int H, int T, int hd,
+                   int64_t sB, int64_t sH, int64_t sT, int64_t oB, int64_t oH, int64_t oT, float scale, void* stream);
+
+/* Backward of octic_attn_fwd (P recomputed from q, k and lse; nothing T x T is stored).  o / dout share the stride
+ * set (oB,oH,oT); dq/dk/dv share (gB,gH,gT).  delta: [B,H,T] f32 scratch (row sums of dout*o), written here.   */
+int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   float* delta, void* dq, void* dk, void* dv, int64_t B, int H, int T, int hd, int64_t sB, int64_t sH,
+                   int64_t sT, int64_t oB, int64_t oH, int64_t oT, int64_t gB, int64_t gH, int64_t gT, float scale,
+                   void* stream);
+
 /* ---- octic -> standard hand-off (model.py:196-200) ---------------------------------------------
  * hybrid:    dense[m, :] = cat(A1,A2,B1,B2, E[0,:c], E[1,:c], E[0,c:], E[1,c:])   (8-tuple order,
  *            d8_utils.py:370-385; the following standard blocks' weights depend on it)

@@ -1,0 +1,461 @@
+// Softmax attention core for gfx950, bf16, short sequences (T <= 512: ViT token counts 197 / 257).
+// Replaces F.scaled_dot_product_attention in AttentionD8 (reference octic_vits/d8_layers.py:645-648) and in the
+// standard blocks (deit/vit.py:41-45).  On MI355X the stock SDPA backward for head_dim 80 takes ~640 us per call
+// (64 x 16 heads x 257 tokens); the sequence is short enough for a much simpler structure than flash attention:
+//
+//   * one workgroup per (batch, head), one wave per 32 queries (9 waves at T = 257); K and V of the head are loaded
+//     ONCE into LDS (K rows padded to an odd number of 16-byte slots -> conflict-free ds_read_b128; V rows sized so
+//     the transposing reads are conflict-free);
+//   * swapped product  X = K Q^T  on v_mfma_f32_32x32x16_bf16: the accumulator has the QUERY on the lane and the keys
+//     in registers, so max / sum of the softmax are in-lane reductions plus one exchange between the half-waves;
+//   * P = exp2(X - m) is used straight from the accumulator registers as the B operand of  O^T = V^T P  (an accumulator
+//     tile is a valid operand for a product that sums over its row index; the k order inside a step is permuted and
+//     the V^T fragments are fetched in the same order with ds_read_b64_tr_b16 from the row-major V image);
+//   * O^T keeps the query on the lane too, so the online-softmax rescale and the final 1/l are lane-local.
+// head_dim must be a multiple of 16 (<= 128).  Bound: MFMA/VALU mix, not HBM (q,k,v,o are 4 x 42 MB per call).
+#include "octic_common.hpp"
+
+namespace octic {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct AttnArgs {
+  const bf16* q; const bf16* k; const bf16* v;   // element (b,h,t,d) at base + b*sB + h*sH + t*sT + d
+  int64_t sB, sH, sT;
+  bf16* o; int64_t oB, oH, oT;
+  float* lse;            // [B,H,T] log2-domain log-sum-exp of the scaled scores
+  int H, T, hd;
+  float scale_log2;      // softmax scale * log2(e)
+};
+
+__device__ inline int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__device__ inline bf16x8 pack8(const float* p) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (bf16)p[i];
+  return r;
+}
+
+// V^T (or any row-major [key][col] LDS image) fragment of the A operand for  Y = A X  where X is an accumulator tile:
+// lane (r = lane&31 -> column c0 + r, half) gets, for k-step s, keys 16s + 4*half + {0..3} and + 8 + {0..3}.
+__device__ inline bf16x8 tr_frag(const char* img, int row_bytes, int key0, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int q4 = i >> 2, p = i & 3, half = g >> 1;
+  const char* a = img + (size_t)(key0 + 4 * half + q4) * row_bytes + (c0 + (g & 1) * 16 + 4 * p) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 8 * row_bytes));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+inline int attn_rsk(int hd) { return hd * 2 + 16; }                       // K image row bytes (odd # of 16-B slots)
+inline int attn_rsv(int dp) { int r = dp * 2; return ((r / 4) % 32 == 0) ? r + 64 : r; }   // V image row bytes
+
+// DT = ceil(hd / 32) d-tiles of the output, KS = hd / 16 k-steps of the score product
+template <int KS, int DT>
+__global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a, int rsk, int rsv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.T, hd = a.hd;
+  const int nw = blockDim.x >> 6;            // waves = key tiles
+  const int Tp = nw * 32;
+  char* Ks = smem;
+  char* Vs = smem + (size_t)Tp * rsk;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const bf16* qb = a.q + b * a.sB + h * a.sH;
+  const bf16* kb = a.k + b * a.sB + h * a.sH;
+  const bf16* vb = a.v + b * a.sB + h * a.sH;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+
+  // ---- stage K and V of this head (zero-filled pads: padded keys are masked, padded V rows meet P = 0)
+  const int kc = hd / 8, vc = (DT * 32) / 8;
+  for (int q = tid; q < Tp * kc; q += blockDim.x) {
+    const int t = q / kc, c = q - t * kc;
+    u32x4 v = {0, 0, 0, 0};
+    if (t < T) v = *(const u32x4*)(kb + (int64_t)t * a.sT + c * 8);
+    *(u32x4*)(Ks + (size_t)t * rsk + c * 16) = v;
+  }
+  for (int q = tid; q < Tp * vc; q += blockDim.x) {
+    const int t = q / vc, c = q - t * vc;
+    u32x4 v = {0, 0, 0, 0};
+    if (t < T && c < kc) v = *(const u32x4*)(vb + (int64_t)t * a.sT + c * 8);
+    *(u32x4*)(Vs + (size_t)t * rsv + c * 16) = v;
+  }
+  // ---- this wave's queries: lane (r, half) holds Q[query][16 ks + 8 half .. +7] = B operand of K Q^T
+  const int qi = wid * 32 + r;
+  const int qc = qi < T ? qi : T - 1;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qb + (int64_t)qc * a.sT + ks * 16 + half * 8);
+  __syncthreads();
+
+  f32x16 ot[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  for (int kt = 0; kt < nw; ++kt) {
+    f32x16 x;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 0.f;
+    const char* krow = Ks + (size_t)(kt * 32 + r) * rsk + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 kf = *(const bf16x8*)(krow + ks * 32);
+      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], x, 0, 0, 0);
+    }
+    // scores of query `qi` against keys kt*32 + acc_row(reg, half)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s = x[i] * a.scale_log2;
+      if (kt == nw - 1 && kt * 32 + acc_row(i, half) >= T) s = -INFINITY;
+      x[i] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);          // finite: key 0 of every tile row exists for tile 0
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float ps[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ps[i] = __builtin_amdgcn_exp2f(x[i] - m_new);
+      sum += ps[i];
+    }
+    l = l * alpha + sum;
+    m = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+    const bf16x8 pb0 = pack8(ps), pb1 = pack8(ps + 8);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const bf16x8 v0 = tr_frag(Vs, rsv, kt * 32, d * 32, lane);
+      ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb0, ot[d], 0, 0, 0);
+      const bf16x8 v1 = tr_frag(Vs, rsv, kt * 32 + 16, d * 32, lane);
+      ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb1, ot[d], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (qi < T) {
+    if (half == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * T + qi] = m + log2f(l);
+    bf16* orow = a.o + b * a.oB + h * a.oH + (int64_t)qi * a.oT;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int d0 = d * 32 + 8 * k4 + 4 * half;
+        if (d0 < hd) {
+          bf16x4 ov = {(bf16)(ot[d][4 * k4] * inv), (bf16)(ot[d][4 * k4 + 1] * inv), (bf16)(ot[d][4 * k4 + 2] * inv),
+                       (bf16)(ot[d][4 * k4 + 3] * inv)};
+          *(bf16x4*)(orow + d0) = ov;
+        }
+      }
+  }
+}
+
+template <int KS, int DT>
+static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
+  const int nw = (a.T + 31) / 32;
+  const int rsk = attn_rsk(a.hd), rsv = attn_rsv(DT * 32);
+  const size_t smem = (size_t)nw * 32 * (rsk + rsv);
+  if (smem > 160 * 1024) return OCTIC_ESHAPE;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    done = true;
+  }
+  attn_fwd_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem, s>>>(a, rsk, rsv);
+  return launch_status();
+}
+
+
+// =================================================================================================
+// Backward.  P is recomputed from q, k and the saved log-sum-exp (no T x T tensor is ever stored).
+//   dV = P^T dO ;  dP = dO V^T ;  dS = P * (dP - delta),  delta[q] = sum_d dO[q,d] O[q,d] ;  dQ = scale dS K ;  dK = scale dS^T Q
+// Two kernels so that no gradient needs a cross-wave reduction:
+//   attn_bwd_dq_kernel : wave owns 32 QUERIES (same swapped layout as the forward); K and V rows in LDS.
+//   attn_bwd_dkv_kernel: wave owns 32 KEYS; Q and dO rows (+ lse, delta) in LDS; un-swapped scores X'[q][key]
+//                        keep the key on the lane, so dK^T and dV^T accumulate lane-locally.
+// =================================================================================================
+struct AttnBwdArgs {
+  const bf16* q; const bf16* k; const bf16* v; int64_t sB, sH, sT;      // inputs
+  const bf16* o; const bf16* dout; int64_t oB, oH, oT;                   // forward output and its cotangent
+  const float* lse; float* delta;                                         // [B,H,T] f32
+  bf16* dq; bf16* dk; bf16* dv; int64_t gB, gH, gT;                     // gradients
+  int H, T, hd;
+  float scale, scale_log2;
+};
+
+__device__ inline void stage_rows(char* img, int rs, const bf16* src, int64_t st, int T, int Tp, int kc, int tid, int nthr) {
+  for (int q = tid; q < Tp * kc; q += nthr) {
+    const int t = q / kc, c = q - t * kc;
+    u32x4 v = {0, 0, 0, 0};
+    if (t < T) v = *(const u32x4*)(src + (int64_t)t * st + c * 8);
+    *(u32x4*)(img + (size_t)t * rs + c * 16) = v;
+  }
+}
+
+template <int KS, int DT>
+__global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.T, hd = a.hd;
+  const int nw = blockDim.x >> 6, Tp = nw * 32;
+  char* Ks = smem;
+  char* Vs = smem + (size_t)Tp * rs;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  stage_rows(Ks, rs, a.k + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
+  stage_rows(Vs, rs, a.v + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
+
+  const int qi = wid * 32 + r;
+  const int qc = qi < T ? qi : T - 1;
+  bf16x8 qf[KS], dof[KS];
+  float delta = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = *(const bf16x8*)(a.q + in_off + (int64_t)qc * a.sT + ks * 16 + half * 8);
+    dof[ks] = *(const bf16x8*)(a.dout + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
+    const bf16x8 of = *(const bf16x8*)(a.o + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[j];
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const int64_t stat = ((int64_t)b * a.H + h) * T + qc;
+  const float lse = a.lse[stat];
+  if (qi < T && half == 0) a.delta[stat] = delta;
+  __syncthreads();
+
+  f32x16 dqt[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqt[d][i] = 0.f;
+
+  for (int kt = 0; kt < nw; ++kt) {
+    f32x16 x, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { x[i] = 0.f; dp[i] = 0.f; }
+    const char* krow = Ks + (size_t)(kt * 32 + r) * rs + half * 16;
+    const char* vrow = Vs + (size_t)(kt * 32 + r) * rs + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(krow + ks * 32), qf[ks], x, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vrow + ks * 32), dof[ks], dp, 0, 0, 0);
+    }
+    float ds[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float p = __builtin_amdgcn_exp2f(x[i] * a.scale_log2 - lse);
+      if (kt == nw - 1 && kt * 32 + acc_row(i, half) >= T) p = 0.f;
+      ds[i] = p * (dp[i] - delta);
+    }
+    const bf16x8 b0 = pack8(ds), b1 = pack8(ds + 8);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, rs, kt * 32, d * 32, lane), b0, dqt[d], 0, 0, 0);
+      dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, rs, kt * 32 + 16, d * 32, lane), b1, dqt[d], 0, 0, 0);
+    }
+  }
+  if (qi < T) {
+    bf16* row = a.dq + b * a.gB + h * a.gH + (int64_t)qi * a.gT;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int d0 = d * 32 + 8 * k4 + 4 * half;
+        if (d0 < hd) {
+          bf16x4 ov = {(bf16)(dqt[d][4 * k4] * a.scale), (bf16)(dqt[d][4 * k4 + 1] * a.scale),
+                       (bf16)(dqt[d][4 * k4 + 2] * a.scale), (bf16)(dqt[d][4 * k4 + 3] * a.scale)};
+          *(bf16x4*)(row + d0) = ov;
+        }
+      }
+  }
+}
+
+template <int KS, int DT>
+__global__ __launch_bounds__(640) void attn_bwd_dkv_kernel(AttnBwdArgs a, int rs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.T, hd = a.hd;
+  const int nw = blockDim.x >> 6, Tp = nw * 32;
+  char* Qs = smem;
+  char* Ds = smem + (size_t)Tp * rs;
+  float* lse_s = (float*)(smem + (size_t)2 * Tp * rs);
+  float* del_s = lse_s + Tp;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  stage_rows(Qs, rs, a.q + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
+  stage_rows(Ds, rs, a.dout + o_off, a.oT, T, Tp, hd / 8, tid, blockDim.x);
+  for (int t = tid; t < Tp; t += blockDim.x) {
+    const int64_t stat = ((int64_t)b * a.H + h) * T + t;
+    lse_s[t] = t < T ? a.lse[stat] : INFINITY;    // padded queries: P = exp2(x - inf) = 0
+    del_s[t] = t < T ? a.delta[stat] : 0.f;
+  }
+  // this wave's keys: lane (r, half) holds K[key][16 ks + 8 half ..] and V[key][..] = B operands (key on the lane)
+  const int ki = wid * 32 + r;
+  const int kcl = ki < T ? ki : T - 1;
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = *(const bf16x8*)(a.k + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
+    vf[ks] = *(const bf16x8*)(a.v + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
+  }
+  __syncthreads();
+
+  f32x16 dkt[DT], dvt[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dkt[d][i] = 0.f; dvt[d][i] = 0.f; }
+
+  for (int qt = 0; qt < nw; ++qt) {
+    f32x16 x, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { x[i] = 0.f; dp[i] = 0.f; }
+    const char* qrow = Qs + (size_t)(qt * 32 + r) * rs + half * 16;
+    const char* drow = Ds + (size_t)(qt * 32 + r) * rs + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qrow + ks * 32), kf[ks], x, 0, 0, 0);    // X'[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(drow + ks * 32), vf[ks], dp, 0, 0, 0);  // dP[q][key]
+    }
+    float ps[16], ds[16];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int q0 = qt * 32 + 8 * g4 + 4 * half;            // accumulator rows 4*g4 .. 4*g4+3 are queries q0 .. q0+3
+      const f32x4 l4 = *(const f32x4*)(lse_s + q0), d4 = *(const f32x4*)(del_s + q0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = 4 * g4 + j;
+        const float p = __builtin_amdgcn_exp2f(x[i] * a.scale_log2 - l4[j]);
+        ps[i] = p;
+        ds[i] = p * (dp[i] - d4[j]);
+      }
+    }
+    const bf16x8 p0 = pack8(ps), p1 = pack8(ps + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ds, rs, qt * 32, d * 32, lane), p0, dvt[d], 0, 0, 0);
+      dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ds, rs, qt * 32 + 16, d * 32, lane), p1, dvt[d], 0, 0, 0);
+      dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, rs, qt * 32, d * 32, lane), s0, dkt[d], 0, 0, 0);
+      dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, rs, qt * 32 + 16, d * 32, lane), s1, dkt[d], 0, 0, 0);
+    }
+  }
+  if (ki < T) {
+    bf16* krow = a.dk + b * a.gB + h * a.gH + (int64_t)ki * a.gT;
+    bf16* vrow = a.dv + b * a.gB + h * a.gH + (int64_t)ki * a.gT;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int d0 = d * 32 + 8 * k4 + 4 * half;
+        if (d0 < hd) {
+          bf16x4 kv = {(bf16)(dkt[d][4 * k4] * a.scale), (bf16)(dkt[d][4 * k4 + 1] * a.scale),
+                       (bf16)(dkt[d][4 * k4 + 2] * a.scale), (bf16)(dkt[d][4 * k4 + 3] * a.scale)};
+          bf16x4 vv = {(bf16)dvt[d][4 * k4], (bf16)dvt[d][4 * k4 + 1], (bf16)dvt[d][4 * k4 + 2], (bf16)dvt[d][4 * k4 + 3]};
+          *(bf16x4*)(krow + d0) = kv;
+          *(bf16x4*)(vrow + d0) = vv;
+        }
+      }
+  }
+}
+
+template <int KS, int DT>
+static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s) {
+  const int nw = (a.T + 31) / 32;
+  // the row images are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16); rows are padded so the
+  // b128 reads are conflict-free, the transposed reads then see at most 2-way conflicts.  The tr fragments reach
+  // DT*32 columns, so rows must hold that many (the pad columns meet zero accumulator columns / are discarded).
+  const int cols = DT * 32 > a.hd ? DT * 32 : a.hd;
+  const int rs = cols * 2 + 16;
+  const size_t smem_dq = (size_t)2 * nw * 32 * rs;
+  const size_t smem_kv = smem_dq + (size_t)2 * nw * 32 * sizeof(float);
+  if (smem_kv > 160 * 1024) return OCTIC_ESHAPE;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    done = true;
+  }
+  attn_bwd_dq_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_dq, s>>>(a, rs);
+  attn_bwd_dkv_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_kv, s>>>(a, rs);
+  return launch_status();
+}
+
+}  // namespace octic
+
+using namespace octic;
+
+extern "C" {
+
+int octic_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int H, int T, int hd,
+                   int64_t sB, int64_t sH, int64_t sT, int64_t oB, int64_t oH, int64_t oT, float scale, void* stream) {
+  if (!q || !k || !v || !o) return OCTIC_ENULL;
+  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || hd <= 0 || (hd % 16) || hd > 128) return OCTIC_ESHAPE;
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)o)) & 15) return OCTIC_EALIGN;
+  if ((sB | sH | sT | oB | oH | oT) & 7) return OCTIC_EALIGN;   // rows must stay 16-byte aligned (8 bf16)
+  AttnArgs a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v;
+  a.sB = sB; a.sH = sH; a.sT = sT;
+  a.o = (bf16*)o; a.oB = oB; a.oH = oH; a.oT = oT;
+  a.lse = lse;
+  a.H = H; a.T = T; a.hd = hd;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  switch (hd / 16) {
+    case 1: return attn_fwd_launch<1, 1>(a, B, s);
+    case 2: return attn_fwd_launch<2, 1>(a, B, s);
+    case 3: return attn_fwd_launch<3, 2>(a, B, s);
+    case 4: return attn_fwd_launch<4, 2>(a, B, s);
+    case 5: return attn_fwd_launch<5, 3>(a, B, s);
+    case 6: return attn_fwd_launch<6, 3>(a, B, s);
+    case 7: return attn_fwd_launch<7, 4>(a, B, s);
+    default: return attn_fwd_launch<8, 4>(a, B, s);
+  }
+}
+
+int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   float* delta, void* dq, void* dk, void* dv, int64_t B, int H, int T, int hd, int64_t sB, int64_t sH,
+                   int64_t sT, int64_t oB, int64_t oH, int64_t oT, int64_t gB, int64_t gH, int64_t gT, float scale,
+                   void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv) return OCTIC_ENULL;
+  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || hd <= 0 || (hd % 16) || hd > 128) return OCTIC_ESHAPE;
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)o) | ((uintptr_t)dout) | ((uintptr_t)dq) |
+       ((uintptr_t)dk) | ((uintptr_t)dv)) & 15)
+    return OCTIC_EALIGN;
+  if ((sB | sH | sT | oB | oH | oT | gB | gH | gT) & 7) return OCTIC_EALIGN;
+  AttnBwdArgs a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.sB = sB; a.sH = sH; a.sT = sT;
+  a.o = (const bf16*)o; a.dout = (const bf16*)dout; a.oB = oB; a.oH = oH; a.oT = oT;
+  a.lse = lse; a.delta = delta;
+  a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.gB = gB; a.gH = gH; a.gT = gT;
+  a.H = H; a.T = T; a.hd = hd;
+  a.scale = scale;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  switch (hd / 16) {
+    case 1: return attn_bwd_launch<1, 1>(a, B, s);
+    case 2: return attn_bwd_launch<2, 1>(a, B, s);
+    case 3: return attn_bwd_launch<3, 2>(a, B, s);
+    case 4: return attn_bwd_launch<4, 2>(a, B, s);
+    case 5: return attn_bwd_launch<5, 3>(a, B, s);
+    case 6: return attn_bwd_launch<6, 3>(a, B, s);
+    case 7: return attn_bwd_launch<7, 4>(a, B, s);
+    default: return attn_bwd_launch<8, 4>(a, B, s);
+  }
+}
+
+}  // extern "C"

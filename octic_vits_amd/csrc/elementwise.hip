@@ -405,12 +405,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* a, int64_t
   }
 }
 
+// out[col] = sum_b partials[b][col]; 256 threads = 16 columns x 16 block-lanes, combined through LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* partials, int nblk, int c, float* out) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= c) return;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partials[(int64_t)b * c + col];
-  out[col] = s;
+  if (col < c)
+    for (int b = bl; b < nblk; b += 16) s += partials[(int64_t)b * c + col];
+  red[bl][cl] = s;
+  __syncthreads();
+  if (bl == 0 && col < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    out[col] = t;
+  }
 }
 
 // Compute-dtype copies of a LinearD8's f32 master weights, one launch per layer:
@@ -670,7 +680,7 @@ int octic_colsum_a1(const octic_view* dy, int64_t M, int c, int dtype, float* pa
   if (dtype == OCTIC_F32) colsum_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)dy->ptr[0], dy->ld[0], M, c, partials);
   else if (dtype == OCTIC_BF16) colsum_partial_kernel<bf16><<<nblk, 256, 0, s>>>((const bf16*)dy->ptr[0], dy->ld[0], M, c, partials);
   else return OCTIC_EDTYPE;
-  colsum_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(partials, nblk, c, out);
+  colsum_finish_kernel<<<(c + 15) / 16, 256, 0, s>>>(partials, nblk, c, out);
   return launch_status();
 }
 

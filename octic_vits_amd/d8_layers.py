@@ -437,8 +437,8 @@ class IsotypicToPatchD8(nn.Module):
 # ------------------------------------------------------------------------------------- attention
 class AttentionD8(nn.Module):
     """d8_layers.py:590-660.  qkv/proj are irrep-blocked GEMMs, head pack/unpack are HIP permutation
-    kernels, the softmax core is torch SDPA exactly as in the reference (scale = SDPA default;
-    ``self.scale`` is stored but unused there too)."""
+    kernels, the softmax core is the HIP attention kernel (csrc/attention.hip) in bf16 and torch SDPA in f32
+    (scale = SDPA default 1/sqrt(head_dim); ``self.scale`` is stored but unused, as in the reference)."""
 
     def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = True, proj_bias: bool = True,
                  attn_drop: float = 0.0, proj_drop: float = 0.0, rope=None, qk_scale=None):
@@ -463,7 +463,8 @@ class AttentionD8(nn.Module):
             raise ValueError("AttentionD8 expects [B, N, C] irreps")
         qkv = self.qkv(xs if isinstance(xs, Octic) else Octic(xp, c))
         q, k, v = OF.PackHeadsFn.apply(qkv.packed, self.num_heads, c)
-        o = self.att(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.)
+        # HIP attention core for the shapes it covers (bf16, T <= 320, no dropout); torch SDPA (== self.att) otherwise
+        o = OF.attention_core(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.)
         on = Octic(OF.UnpackHeadsFn.apply(o, c), c)
         if self.proj_drop.active or resid is None:
             return _tail(self.proj_drop(self.proj(on)), resid, rs, cs)

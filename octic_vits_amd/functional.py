@@ -232,6 +232,70 @@ class UnpackHeadsFn(torch.autograd.Function):
         return ops.pack_heads(_c(g), B, T, H, c, 1)[0], None
 
 
+# ------------------------------------------------------------------------------------- attention
+class AttnFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v for separate q, k, v of shape [B,H,T,hd] (bf16) — HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        q, k, v = _c(q), _c(k), _c(v)
+        o, lse = ops.attn_fwd(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = _c(do)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ops.attn_bwd(q, k, v, o, do, lse, ctx.scale, dq, dk, dv)
+        return dq, dk, dv, None
+
+
+class AttnFusedQKVFn(torch.autograd.Function):
+    """Attention on a fused projection output qkv [B,T,3,H,hd] (the layout of the standard block, deit/vit.py:38-39):
+    q/k/v are read through strides, the result is written as [B,T,H*hd] and the gradient comes back as ONE
+    [B,T,3,H,hd] tensor (no permute copies, no zero-fill + add of three partial gradients)."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        qkv = _c(qkv)
+        B, T, _, H, hd = qkv.shape
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        o = torch.empty((B, T, H, hd), dtype=qkv.dtype, device=qkv.device)
+        ov = o.permute(0, 2, 1, 3)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+        st = q.stride()
+        t = ops.KERNEL_TIMER.start()
+        ops.check(ops.lib().octic_attn_fwd(ops._p(q), ops._p(k), ops._p(v), ops._p(o), ops._p(lse), B, H, T, hd, st[0], st[1],
+                                           st[2], ov.stride(0), ov.stride(1), ov.stride(2), float(scale), ops._stream(qkv)))
+        ops.KERNEL_TIMER.stop(t, "attn_fwd_kernel", 4 * q.numel() * 2, 4.0 * B * H * T * T * hd)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.scale = scale
+        return o.view(B, T, H * hd)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, T, _, H, hd = qkv.shape
+        do = _c(do).view(B, T, H, hd)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        ops.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), do.permute(0, 2, 1, 3), lse, ctx.scale, dq, dk, dv)
+        return dqkv, None
+
+
+def attention_core(q, k, v, dropout_p=0.0):
+    """Drop-in for F.scaled_dot_product_attention(q, k, v) on [B,H,T,hd]: HIP kernels for the shapes they cover
+    (bf16, short sequences, no dropout), torch SDPA otherwise (f32 exact path, odd head sizes)."""
+    B, H, T, hd = q.shape
+    if dropout_p == 0.0 and q.is_cuda and ops.attn_supported(T, hd, q.dtype):
+        return AttnFn.apply(q, k, v, hd ** -0.5)
+    return torch.nn.functional.scaled_dot_product_attention(q, k, v, dropout_p=dropout_p)
+
+
 # -------------------------------------------------------------------------------------- hand-off
 class HandoffCatFn(torch.autograd.Function):
     @staticmethod

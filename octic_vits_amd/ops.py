@@ -327,6 +327,43 @@ def linear_prep(w5, cs5, cin, cout, dtype, want_wb=True):
     return views(wb, False), views(wt, True)
 
 
+def attn_fwd(q, k, v, scale):
+    """q,k,v: [B,H,T,hd] bf16 views with a common stride set (last dim contiguous) -> (o [B,H,T,hd], lse [B,H,T])"""
+    B, H, T, hd = q.shape
+    st = q.stride()
+    if st[3] != 1 or k.stride() != st or v.stride() != st:
+        raise ValueError("attn_fwd: q, k, v must share strides and be contiguous in the last dim")
+    o = torch.empty((B, H, T, hd), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, T, hd, st[0], st[1], st[2],
+                               o.stride(0), o.stride(1), o.stride(2), float(scale), _stream(q)))
+    KERNEL_TIMER.stop(t, "attn_fwd_kernel", 4 * q.numel() * 2, 4.0 * B * H * T * T * hd)
+    return o, lse
+
+
+def attn_supported(T, hd, dtype):
+    """Shapes the HIP attention core handles (others keep torch SDPA): bf16, T <= 320, hd % 16 == 0, LDS fits."""
+    if dtype != torch.bfloat16 or T > 320 or hd % 16 or hd > 128:
+        return False
+    tp = (T + 31) // 32 * 32
+    cols = max((hd + 31) // 32 * 32, hd)
+    return 2 * tp * (cols * 2 + 16) + 2 * tp * 4 <= 160 * 1024
+
+
+def attn_bwd(q, k, v, o, dout, lse, scale, dq, dk, dv):
+    """All tensors are [B,H,T,hd] views; q/k/v share strides, o/dout share strides, dq/dk/dv share strides."""
+    B, H, T, hd = q.shape
+    st, so, sg = q.stride(), o.stride(), dq.stride()
+    if k.stride() != st or v.stride() != st or dout.stride() != so or dk.stride() != sg or dv.stride() != sg:
+        raise ValueError("attn_bwd: stride sets differ")
+    delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, T,
+                               hd, st[0], st[1], st[2], so[0], so[1], so[2], sg[0], sg[1], sg[2], float(scale), _stream(q)))
+    KERNEL_TIMER.stop(t, "attn_bwd_kernels", 8 * q.numel() * 2, 14.0 * B * H * T * T * hd)
+
+
 def handoff_cat_fwd(x, c, out_dtype):
     M = x.numel() // (8 * c)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)

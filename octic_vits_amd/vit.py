@@ -1,10 +1,13 @@
 """Standard (non-octic) half of the hybrid models: vanilla pre-norm ViT blocks with the state_dict keys of
 the reference (deit/vit.py:14-134 ``Attention``/``Layer_scale_init_Block``; timm 1.0.12 ``Block`` for the
-bare default, model.py:21,63).  Stock PyTorch-ROCm ops (hipBLASLt linears, SDPA, LayerNorm) exactly like the
-reference — SURVEY.md §8a row 12; a fused HIP version of these blocks is the first "next" row (§8f-3)."""
+bare default, model.py:21,63).  Stock PyTorch-ROCm ops (hipBLASLt linears, LayerNorm, GELU) like the reference — SURVEY.md §8a row 12 — except the
+softmax attention core, which is the engine's HIP kernel for bf16 (§8f-1); fusing the rest is §8f-3."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import functional as _OF
+from . import ops as _ops
 
 
 class DropPath(nn.Module):
@@ -52,7 +55,14 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        hd = C // self.num_heads
+        qkv = self.qkv(x)
+        drop = self.attn_drop.p if self.training else 0.
+        if self.fused_attn and drop == 0. and qkv.is_cuda and _ops.attn_supported(N, hd, qkv.dtype):
+            # HIP attention core reading q/k/v through strides of the fused projection output and writing [B,N,C]
+            x = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
+            return self.proj_drop(self.proj(x))
+        qkv = qkv.reshape(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         if self.fused_attn:
             x = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.)

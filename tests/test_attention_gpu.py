@@ -1,0 +1,92 @@
+"""HIP attention core vs fp32 softmax attention on the same bf16-rounded inputs (through the C ABI).
+Tolerance: outputs are bf16 (8-bit mantissa), P is rounded to bf16 before P.V -> 2e-2 abs on O(1) outputs;
+LSE (f32) 2e-3."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, scale):
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    lse2 = torch.logsumexp(s, dim=-1) / math.log(2.0)
+    return torch.softmax(s, dim=-1) @ v.float(), lse2
+
+
+@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 257, 80), (2, 2, 197, 64), (1, 2, 33, 16), (1, 1, 160, 128), (3, 4, 65, 32),
+                                      (1, 2, 5, 48)])
+def test_attn_fwd_matches_reference(B, H, T, hd):
+    from octic_vits_amd import ops
+    g = torch.Generator().manual_seed(T * 131 + hd)
+    q, k, v = (torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, scale)
+    ro, rl = _ref(q, k, v, scale)
+    assert torch.allclose(o.float(), ro, atol=2e-2, rtol=2e-2), (o.float() - ro).abs().max()
+    assert torch.allclose(lse, rl, atol=2e-3, rtol=1e-4), (lse - rl).abs().max()
+
+
+def test_attn_fwd_strided_qkv_views():
+    """q,k,v as views of one fused [B,T,3,H,hd] tensor (the standard block's layout, deit/vit.py:38-39)."""
+    from octic_vits_amd import ops
+    B, T, H, hd = 2, 257, 4, 80
+    qkv = torch.randn(B, T, 3, H, hd, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    o, _ = ops.attn_fwd(q, k, v, hd ** -0.5)
+    ro, _ = _ref(q, k, v, hd ** -0.5)
+    assert torch.allclose(o.float(), ro, atol=2e-2, rtol=2e-2)
+
+
+def test_attn_fwd_large_logits_are_stable():
+    from octic_vits_amd import ops
+    B, H, T, hd = 1, 2, 257, 80
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    q = q * 20.0   # sharp softmax: the running-max rescale path matters
+    o, lse = ops.attn_fwd(q, k, v, hd ** -0.5)
+    ro, rl = _ref(q, k, v, hd ** -0.5)
+    assert torch.isfinite(o.float()).all()
+    assert torch.allclose(o.float(), ro, atol=3e-2, rtol=3e-2)
+
+
+def _ref_grads(q, k, v, do, scale):
+    q, k, v = (t.float().detach().requires_grad_(True) for t in (q, k, v))
+    o = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1) @ v
+    o.backward(do.float())
+    return q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 257, 80), (2, 2, 197, 64), (1, 2, 33, 16), (3, 4, 65, 32), (1, 2, 5, 48)])
+def test_attn_bwd_matches_reference(B, H, T, hd):
+    """Gradients vs autograd of the fp32 reference on the same bf16 inputs: P and dS are rounded to bf16 before the
+    gradient MFMAs -> 3e-2 of the gradient scale."""
+    from octic_vits_amd.functional import AttnFn
+    g = torch.Generator().manual_seed(T * 17 + hd)
+    q, k, v = (torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda().requires_grad_(True) for _ in range(3))
+    do = torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda()
+    o = AttnFn.apply(q, k, v, hd ** -0.5)
+    o.backward(do)
+    rq, rk, rv = _ref_grads(q, k, v, do, hd ** -0.5)
+    for name, got, want in (("dq", q.grad, rq), ("dk", k.grad, rk), ("dv", v.grad, rv)):
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got.float() - want).abs().max())
+        assert err <= 3e-2 * scale, f"{name}: max err {err:.3e} (scale {scale:.3g})"
+
+
+def test_attn_fused_qkv_function_matches_reference():
+    from octic_vits_amd.functional import AttnFusedQKVFn
+    B, T, H, hd = 2, 257, 4, 80
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
+    do = torch.randn(B, T, H * hd, generator=g).to(torch.bfloat16).cuda()
+    out = AttnFusedQKVFn.apply(qkv, hd ** -0.5)
+    out.backward(do)
+    ref = qkv.detach().float().requires_grad_(True)
+    q, k, v = (ref[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ro = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B, T, H * hd)
+    ro.backward(do.float())
+    assert torch.allclose(out.float(), ro, atol=2e-2, rtol=2e-2)
+    scale = max(1.0, float(ref.grad.abs().max()))
+    assert float((qkv.grad.float() - ref.grad).abs().max()) <= 3e-2 * scale

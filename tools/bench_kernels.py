@@ -87,3 +87,14 @@ hs = ops.pack_heads(qkv, B, T, H, c, 3)
 timeit("unpack_heads n_s=3", lambda: ops.unpack_heads(hs, B, T, H, c), 2 * qkv.numel() * 2)
 timeit("unpack_heads n_s=1", lambda: ops.unpack_heads(hs[:1], B, T, H, c), 2 * hs[0].numel() * 2)
 timeit("cast_rowscale f32->bf16", lambda: ops.cast_rowscale(x32, None, 1, bf, c), M * 8 * c * 6)
+qh, kh, vh = (rnd(B, H, T, 80) for _ in range(3))
+timeit("attn_fwd hip", lambda: ops.attn_fwd(qh, kh, vh, 80 ** -0.5), 4 * qh.numel() * 2, 4.0 * B * H * T * T * 80)
+import torch.nn.functional as F
+timeit("attn_fwd torch sdpa", lambda: F.scaled_dot_product_attention(qh, kh, vh), 4 * qh.numel() * 2, 4.0 * B * H * T * T * 80)
+from octic_vits_amd.functional import AttnFn
+qg, kg, vg = (rnd(B, H, T, 80).requires_grad_(True) for _ in range(3))
+og = AttnFn.apply(qg, kg, vg, 80 ** -0.5)
+dog = rnd(B, H, T, 80)
+timeit("attn_bwd hip", lambda: torch.autograd.grad(og, (qg, kg, vg), dog, retain_graph=True), 8 * qg.numel() * 2, 14.0 * B * H * T * T * 80)
+ot = F.scaled_dot_product_attention(qg, kg, vg)
+timeit("attn_bwd torch sdpa", lambda: torch.autograd.grad(ot, (qg, kg, vg), dog, retain_graph=True), 8 * qg.numel() * 2, 14.0 * B * H * T * T * 80)
