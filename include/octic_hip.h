@@ -164,11 +164,12 @@ int octic_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
                    int64_t sB, int64_t sH, int64_t sT, int64_t oB, int64_t oH, int64_t oT, float scale, void* stream);
 
 /* Backward of octic_attn_fwd (P recomputed from q, k and lse; nothing T x T is stored).  o / dout share the stride
- * set (oB,oH,oT); dq/dk/dv share (gB,gH,gT).  delta: [B,H,T] f32 scratch (row sums of dout*o), written here.   */
+ * set (oB,oH,oT); dq/dk/dv share (gB,gH,gT).  delta: [B,H,T] f32 (row sums of dout*o).  phase bit 0: query-owned
+ * kernel (writes delta and dq); bit 1: key-owned kernel (reads delta, writes dk and dv); 3 = both, in that order. */
 int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    float* delta, void* dq, void* dk, void* dv, int64_t B, int H, int T, int hd, int64_t sB, int64_t sH,
                    int64_t sT, int64_t oB, int64_t oH, int64_t oT, int64_t gB, int64_t gH, int64_t gT, float scale,
-                   void* stream);
+                   int phase, void* stream);
 
 /* ---- octic -> standard hand-off (model.py:196-200) ---------------------------------------------
  * hybrid:    dense[m, :] = cat(A1,A2,B1,B2, E[0,:c], E[1,:c], E[0,c:], E[1,c:])   (8-tuple order,

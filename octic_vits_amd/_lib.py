@@ -51,7 +51,7 @@ _PROTOS = {
     "octic_linear_d8_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "octic_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int,
                                c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_float, c_void_p]),
-    "octic_attn_bwd": (c_int, [c_void_p] * 10 + [c_i64, c_int, c_int, c_int] + [c_i64] * 9 + [c_float, c_void_p]),
+    "octic_attn_bwd": (c_int, [c_void_p] * 10 + [c_i64, c_int, c_int, c_int] + [c_i64] * 9 + [c_float, c_int, c_void_p]),
     "octic_attn_pack_heads": (c_int, [VP, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "octic_attn_unpack_heads": (c_int, [c_void_p, VP, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "octic_handoff_cat_fwd": (c_int, [VP, c_void_p, c_i64, c_int, c_int, c_void_p]),

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_kernel(AttnBwdArgs a, int rs
 }
 
 template <int KS, int DT>
-static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s) {
+static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream_t s) {
   const int nw = (a.T + 31) / 32;
   // the row images are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16); rows are padded so the
   // b128 reads are conflict-free, the transposed reads then see at most 2-way conflicts.  The tr fragments reach
@@ -390,8 +390,8 @@ static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s) {
     (void)hipGetLastError();
     done = true;
   }
-  attn_bwd_dq_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_dq, s>>>(a, rs);
-  attn_bwd_dkv_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_kv, s>>>(a, rs);
+  if (phase & 1) attn_bwd_dq_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_dq, s>>>(a, rs);
+  if (phase & 2) attn_bwd_dkv_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_kv, s>>>(a, rs);
   return launch_status();
 }
 
@@ -430,8 +430,9 @@ int octic_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
 int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    float* delta, void* dq, void* dk, void* dv, int64_t B, int H, int T, int hd, int64_t sB, int64_t sH,
                    int64_t sT, int64_t oB, int64_t oH, int64_t oT, int64_t gB, int64_t gH, int64_t gT, float scale,
-                   void* stream) {
+                   int phase, void* stream) {
   if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv) return OCTIC_ENULL;
+  if (phase < 1 || phase > 3) return OCTIC_ESHAPE;
   if (B <= 0 || H <= 0 || T <= 0 || T > 320 || hd <= 0 || (hd % 16) || hd > 128) return OCTIC_ESHAPE;
   if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)o) | ((uintptr_t)dout) | ((uintptr_t)dq) |
        ((uintptr_t)dk) | ((uintptr_t)dv)) & 15)
@@ -447,14 +448,14 @@ int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
   a.scale_log2 = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
   switch (hd / 16) {
-    case 1: return attn_bwd_launch<1, 1>(a, B, s);
-    case 2: return attn_bwd_launch<2, 1>(a, B, s);
-    case 3: return attn_bwd_launch<3, 2>(a, B, s);
-    case 4: return attn_bwd_launch<4, 2>(a, B, s);
-    case 5: return attn_bwd_launch<5, 3>(a, B, s);
-    case 6: return attn_bwd_launch<6, 3>(a, B, s);
-    case 7: return attn_bwd_launch<7, 4>(a, B, s);
-    default: return attn_bwd_launch<8, 4>(a, B, s);
+    case 1: return attn_bwd_launch<1, 1>(a, B, phase, s);
+    case 2: return attn_bwd_launch<2, 1>(a, B, phase, s);
+    case 3: return attn_bwd_launch<3, 2>(a, B, phase, s);
+    case 4: return attn_bwd_launch<4, 2>(a, B, phase, s);
+    case 5: return attn_bwd_launch<5, 3>(a, B, phase, s);
+    case 6: return attn_bwd_launch<6, 3>(a, B, phase, s);
+    case 7: return attn_bwd_launch<7, 4>(a, B, phase, s);
+    default: return attn_bwd_launch<8, 4>(a, B, phase, s);
   }
 }
 

@@ -60,9 +60,15 @@ class KernelTimer:
             a["flops_per_launch"] = a["flops"] / a["launches"]
         return agg
 
-    def dominant(self):
-        agg = self._agg()
-        return max(agg.values(), key=lambda a: a["total_us"]) if agg else None
+    @staticmethod
+    def bound_of(name):
+        """Roofline that bounds a kernel family: the attention kernels are MFMA/VALU-bound (q,k,v,o are read once,
+        14 T^2 hd flops per head), every other kernel of the engine moves more bytes than it can compute on."""
+        return "mfma" if name.startswith("attn_") else "hbm"
+
+    def dominant(self, bound=None):
+        agg = [a for a in self._agg().values() if bound is None or self.bound_of(a["name"]) == bound]
+        return max(agg, key=lambda a: a["total_us"]) if agg else None
 
     def summary(self):
         return {k: {"launches": a["launches"], "total_us": round(a["total_us"], 1), "avg_us": round(a["avg_us"], 2),
@@ -358,10 +364,12 @@ def attn_bwd(q, k, v, o, dout, lse, scale, dq, dk, dv):
     if k.stride() != st or v.stride() != st or dout.stride() != so or dk.stride() != sg or dv.stride() != sg:
         raise ValueError("attn_bwd: stride sets differ")
     delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
-    t = KERNEL_TIMER.start()
-    check(lib().octic_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, T,
-                               hd, st[0], st[1], st[2], so[0], so[1], so[2], sg[0], sg[1], sg[2], float(scale), _stream(q)))
-    KERNEL_TIMER.stop(t, "attn_bwd_kernels", 8 * q.numel() * 2, 14.0 * B * H * T * T * hd)
+    for phase, name, nbytes, flops in ((1, "attn_bwd_dq_kernel", 6, 6.0), (2, "attn_bwd_dkv_kernel", 6, 8.0)):
+        t = KERNEL_TIMER.start()
+        check(lib().octic_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H,
+                                   T, hd, st[0], st[1], st[2], so[0], so[1], so[2], sg[0], sg[1], sg[2], float(scale),
+                                   phase, _stream(q)))
+        KERNEL_TIMER.stop(t, name, nbytes * q.numel() * 2, flops * B * H * T * T * hd)
 
 
 def handoff_cat_fwd(x, c, out_dtype):
