@@ -136,7 +136,8 @@ def main():
             "config": {"workload": f"{args.model} (16 octic + 16 standard blocks, drop_path 0.5) DeiT-III train step: "
                                    f"bf16-autocast fwd + bwd + LAMB + EMA, 224x224, batch {args.batch}/GPU "
                                    f"(BASELINE configs[1]), data parallel over {world} GPU(s)",
-                       "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}"},
+                       "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
+                       "library_gemm_table": bool(trainer.tuned_gemms)},
             "loss": float(loss.item()),
             "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4),
         }

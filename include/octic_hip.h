@@ -217,6 +217,33 @@ int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const*
                     const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
                     float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* stream);
 
+/* ---- standard (non-equivariant) half of the hybrid: row kernels around the library GEMMs ----------------
+ * The reference's standard blocks (deit/models_v2.py Layer_scale_init_Block, used for the second half of the
+ * depth by octic_vits/model.py:130-150) are  x = x + drop_path(gamma * f(LayerNorm(x))).  The four projections
+ * stay on the BLAS library; these entry points replace the eager chain around them.  Rows are dense
+ * [rows, d] with d % 4 == 0, d <= 2048; x / residual stream / statistics are f32, branch tensors `dtype`.
+ *
+ * octic_dense_layernorm_fwd: y = (x-mean)*rstd*w + b (w, b may be NULL), stats[rows,2] = (mean, rstd).
+ * octic_dense_layernorm_bwd: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) + dres with g = gy*w (dres = cotangent
+ *   of the residual path, may be NULL); partials (may be NULL) receives octic_dense_blocks(rows) slabs [2][d]
+ *   holding sum gy*xhat and sum gy; octic_dense_finish reduces them into dw / db.
+ * octic_scale_residual_fwd: out = x + rs[row / rows_per_scale] * gamma[col] * y  (rs, gamma may be NULL).
+ * octic_scale_residual_bwd: gy = rs*gamma*gout in y's dtype; slabs [2][d] of sum rs*gout*y (= d gamma) and
+ *   sum rs*gout (times gamma = bias gradient of the projection that produced y).
+ * octic_dense_finish: out0[j] = sum_b slab[b][0][j];  out1[j] = scale1[j] * sum_b slab[b][1][j]
+ *   (out0, out1, scale1 may each be NULL).                                                              */
+int octic_dense_blocks(int64_t rows);
+int octic_dense_layernorm_fwd(const float* x, void* y, int y_dtype, const float* w, const float* b, float* stats,
+                              int64_t rows, int d, float eps, void* stream);
+int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const float* w, const float* stats,
+                              const float* dres, float* dx, float* partials, int64_t rows, int d, void* stream);
+int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, float* out1, const float* scale1,
+                       void* stream);
+int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const float* gamma, const float* rs,
+                             int64_t rows_per_scale, float* out, int64_t rows, int d, void* stream);
+int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
+                             int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

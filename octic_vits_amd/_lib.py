@@ -45,6 +45,16 @@ _PROTOS = {
     "octic_lamb_workspace_floats": (c_i64, [c_int, c_int]),
     "octic_lamb_step": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float,
                                                   c_int, c_float, c_void_p]),
+    "octic_dense_blocks": (c_int, [c_i64]),
+    "octic_dense_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int,
+                                          c_float, c_void_p]),
+    "octic_dense_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_i64, c_int, c_void_p]),
+    "octic_dense_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octic_scale_residual_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int,
+                                         c_void_p]),
+    "octic_scale_residual_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,
+                                         c_i64, c_int, c_void_p]),
     "octic_colsum_blocks": (c_int, [c_i64]),
     "octic_colsum_a1": (c_int, [VP, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "octic_cast_rowscale": (c_int, [VP, VP, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p]),

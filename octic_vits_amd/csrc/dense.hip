@@ -1,0 +1,344 @@
+// Row kernels of the standard (non-equivariant) half of a hybrid octic ViT: plain LayerNorm over dense rows and the
+// block tail  x + rs*gamma*y  (layer scale, stochastic depth, residual).  All of them are HBM-bound: one wave owns a
+// row, a lane owns the same NV 16-byte column chunks of every row it visits, so the per-column parameters and the
+// per-column gradient partial sums live in registers for the whole launch.
+//
+// Reference: deit/models_v2.py Layer_scale_init_Block (norm1/norm2 = nn.LayerNorm(eps=1e-6),
+// x = x + drop_path(gamma_1 * attn(norm1(x)))), timm drop_path (per-sample mask / keep_prob).
+#include "octic_common.hpp"
+
+namespace octic {
+
+constexpr int kDenseWaves = 8;          // waves per workgroup of the backward kernels
+constexpr int kDenseMaxBlocks = 512;    // partial-sum slabs per launch
+
+template <typename T> struct Row4;
+template <> struct Row4<float> {
+  static __device__ inline f32x4 load(const float* p) { return *(const f32x4*)p; }
+  static __device__ inline void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Row4<bf16> {
+  static __device__ inline f32x4 load(const bf16* p) {
+    bf16x4 h = *(const bf16x4*)p;
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+  static __device__ inline void store(bf16* p, f32x4 v) {
+    *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  }
+};
+
+__device__ inline float hsum(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// ------------------------------------------------------------------------------------------ LayerNorm forward
+template <typename TOUT, int NV>
+__global__ __launch_bounds__(256) void dense_ln_fwd_kernel(const float* __restrict__ x, TOUT* __restrict__ y,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           float* __restrict__ stats, long rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * 4;
+  f32x4 wv[NV], bv[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    ok[i] = col < d;
+    wv[i] = (ok[i] && w) ? *(const f32x4*)(w + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bv[i] = (ok[i] && b) ? *(const f32x4*)(b + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+    const float* xr = x + r * d;
+    f32x4 xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xv[i] = ok[i] ? *(const f32x4*)(xr + (i * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += hsum(xv[i]);
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 c = xv[i] - mean;
+      xv[i] = c;
+      if (ok[i]) q += hsum(c * c);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    TOUT* yr = y + r * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) Row4<TOUT>::store(yr + (i * 64 + lane) * 4, xv[i] * rstd * wv[i] + bv[i]);
+    if (lane == 0) {
+      stats[2 * r] = mean;
+      stats[2 * r + 1] = rstd;
+    }
+  }
+}
+
+// Fold the kDenseWaves per-wave register partials of a workgroup into its slab [2][d] (deterministic order).
+template <int NV>
+__device__ inline void slab_reduce(float* lds, float* slab, const f32x4 (&p0)[NV], const f32x4 (&p1)[NV],
+                                   const bool (&ok)[NV], int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int wv = 0; wv < kDenseWaves; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (ok[i]) {
+          const int col = (i * 64 + lane) * 4;
+          f32x4* a = (f32x4*)(lds + col);
+          f32x4* c = (f32x4*)(lds + d + col);
+          if (wv == 0) {
+            *a = p0[i];
+            *c = p1[i];
+          } else {
+            *a += p0[i];
+            *c += p1[i];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  for (int j = threadIdx.x * 4; j < 2 * d; j += blockDim.x * 4) *(f32x4*)(slab + j) = *(const f32x4*)(lds + j);
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm backward
+// dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) + dres,  g = gy*w;  slab partials: dw += gy*xhat, db += gy.
+template <typename TG, int NV>
+__global__ __launch_bounds__(kDenseWaves * 64) void dense_ln_bwd_kernel(
+    const TG* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
+    float* __restrict__ partials, long rows, int d) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * kDenseWaves;
+  f32x4 wv[NV], pw[NV], pb[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    ok[i] = col < d;
+    wv[i] = (ok[i] && w) ? *(const f32x4*)(w + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    pw[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (long r = (long)blockIdx.x * kDenseWaves + (threadIdx.x >> 6); r < rows; r += nw) {
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    f32x4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const long o = r * d + (i * 64 + lane) * 4;
+      if (ok[i]) {
+        xh[i] = (*(const f32x4*)(x + o) - mean) * rstd;
+        f32x4 gyv = Row4<TG>::load(gy + o);
+        pw[i] += gyv * xh[i];
+        pb[i] += gyv;
+        g[i] = gyv * wv[i];
+        s1 += hsum(g[i]);
+        s2 += hsum(g[i] * xh[i]);
+      }
+    }
+    const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) {
+        const long o = r * d + (i * 64 + lane) * 4;
+        f32x4 v = (g[i] - m1 - xh[i] * m2) * rstd;
+        if (dres) v += *(const f32x4*)(dres + o);
+        *(f32x4*)(dx + o) = v;
+      }
+  }
+  if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, pw, pb, ok, d);
+}
+
+// ------------------------------------------------------------------------------------------ block tail
+// out = x + rs[row / rps] * gamma[col] * y
+template <typename TY>
+__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const float* __restrict__ x, const TY* __restrict__ y,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ rs, long rps,
+                                                                 float* __restrict__ out, long rows, int d) {
+  const int d4 = d >> 2;
+  const long n4 = rows * d4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / d4;
+    const int col = (int)(i - r * d4) * 4;
+    f32x4 s = gamma ? *(const f32x4*)(gamma + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    if (rs) s *= rs[r / rps];
+    *(f32x4*)(out + i * 4) = *(const f32x4*)(x + i * 4) + s * Row4<TY>::load(y + i * 4);
+  }
+}
+
+// gy = rs*gamma*gout (dtype of y);  slab partials: p0 += rs*gout*y (d gamma), p1 += rs*gout (bias grad / gamma).
+template <typename TY, int NV>
+__global__ __launch_bounds__(kDenseWaves * 64) void scale_residual_bwd_kernel(
+    const float* __restrict__ gout, const TY* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ rs, long rps, TY* __restrict__ gy, float* __restrict__ partials, long rows, int d) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * kDenseWaves;
+  f32x4 gm[NV], p0[NV], p1[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    ok[i] = col < d;
+    gm[i] = (ok[i] && gamma) ? *(const f32x4*)(gamma + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    p0[i] = p1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long r = (long)blockIdx.x * kDenseWaves + (threadIdx.x >> 6); r < rows; r += nw) {
+    const float s = rs ? rs[r / rps] : 1.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) {
+        const long o = r * d + (i * 64 + lane) * 4;
+        f32x4 g = *(const f32x4*)(gout + o) * s;
+        p1[i] += g;
+        if (partials) p0[i] += g * Row4<TY>::load(y + o);
+        Row4<TY>::store(gy + o, g * gm[i]);
+      }
+  }
+  if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, p0, p1, ok, d);
+}
+
+// out0[j] = sum_b partials[b][j], out1[j] = scale1[j] * sum_b partials[b][d + j]   (16 columns x 16 slab groups)
+__global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restrict__ partials, int nblocks, int d,
+                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           const float* __restrict__ scale1) {
+  __shared__ float red[16][17];
+  const int cx = threadIdx.x & 15, gy = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + cx;
+  float s = 0.f;
+  if (j < 2 * d)
+    for (int b = gy; b < nblocks; b += 16) s += partials[(long)b * 2 * d + j];
+  red[gy][cx] = s;
+  __syncthreads();
+  if (gy == 0 && j < 2 * d) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    if (j < d) {
+      if (out0) out0[j] = t;
+    } else if (out1) {
+      out1[j - d] = scale1 ? t * scale1[j - d] : t;
+    }
+  }
+}
+
+static inline int dense_nv(int d) { return (d + 255) / 256; }
+static inline int dense_check(long rows, int d) {
+  if (rows < 0 || d <= 0 || (d & 3) || d > 2048) return OCTIC_ESHAPE;
+  return OCTIC_OK;
+}
+static inline int dense_blocks(long rows) {
+  long b = (rows + kDenseWaves - 1) / kDenseWaves;
+  return (int)(b < 1 ? 1 : (b > kDenseMaxBlocks ? kDenseMaxBlocks : b));
+}
+
+#define DENSE_NV_SWITCH(nv, CALL) \
+  switch (nv) {                   \
+    case 1: { constexpr int NV = 1; CALL; } break; \
+    case 2: { constexpr int NV = 2; CALL; } break; \
+    case 3: { constexpr int NV = 3; CALL; } break; \
+    case 4: { constexpr int NV = 4; CALL; } break; \
+    case 5: { constexpr int NV = 5; CALL; } break; \
+    case 6: { constexpr int NV = 6; CALL; } break; \
+    case 7: { constexpr int NV = 7; CALL; } break; \
+    default: { constexpr int NV = 8; CALL; } break; \
+  }
+
+}  // namespace octic
+
+using namespace octic;
+
+extern "C" {
+
+int octic_dense_layernorm_fwd(const float* x, void* y, int y_dtype, const float* w, const float* b, float* stats,
+                              int64_t rows, int d, float eps, void* stream) {
+  if (rows == 0) return OCTIC_OK;
+  if (!x || !y || !stats) return OCTIC_ENULL;
+  if (int e = dense_check(rows, d)) return e;
+  if (y_dtype != OCTIC_F32 && y_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
+  long blocks = (rows + 15) / 16;            // 4 rows per wave: parameters are re-read once per 4 rows
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dtype == OCTIC_BF16) {
+    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_fwd_kernel<bf16, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (bf16*)y, w, b, stats, rows, d, eps)));
+  } else {
+    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_fwd_kernel<float, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (float*)y, w, b, stats, rows, d, eps)));
+  }
+  return launch_status();
+}
+
+int octic_dense_blocks(int64_t rows) { return dense_blocks(rows); }
+
+int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const float* w, const float* stats,
+                              const float* dres, float* dx, float* partials, int64_t rows, int d, void* stream) {
+  if (rows == 0) return OCTIC_OK;
+  if (!gy || !x || !stats || !dx) return OCTIC_ENULL;
+  if (int e = dense_check(rows, d)) return e;
+  if (g_dtype != OCTIC_F32 && g_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
+  const int blocks = dense_blocks(rows);
+  const size_t lds = (size_t)2 * d * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_dtype == OCTIC_BF16) {
+    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_kernel<bf16, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>((const bf16*)gy, x, w, stats, dres,
+                                                     dx, partials, rows, d)));
+  } else {
+    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_kernel<float, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>((const float*)gy, x, w, stats,
+                                                     dres, dx, partials, rows, d)));
+  }
+  return launch_status();
+}
+
+int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, float* out1, const float* scale1,
+                       void* stream) {
+  if (!partials) return OCTIC_ENULL;
+  if (nblocks <= 0 || d <= 0) return OCTIC_ESHAPE;
+  hipLaunchKernelGGL(dense_finish_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nblocks,
+                     d, out0, out1, scale1);
+  return launch_status();
+}
+
+int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const float* gamma, const float* rs,
+                             int64_t rows_per_scale, float* out, int64_t rows, int d, void* stream) {
+  if (rows == 0) return OCTIC_OK;
+  if (!x || !y || !out) return OCTIC_ENULL;
+  if (int e = dense_check(rows, d)) return e;
+  if (y_dtype != OCTIC_F32 && y_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
+  if (rs && rows_per_scale <= 0) return OCTIC_ESHAPE;
+  const long n4 = rows * (d >> 2);
+  long blocks = (n4 + 1023) / 1024;          // 4 chunks per thread
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dtype == OCTIC_BF16)
+    scale_residual_fwd_kernel<bf16><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (const bf16*)y,
+                       gamma, rs, rows_per_scale, out, rows, d);
+  else
+    scale_residual_fwd_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (const float*)y,
+                       gamma, rs, rows_per_scale, out, rows, d);
+  return launch_status();
+}
+
+int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
+                             int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, void* stream) {
+  if (rows == 0) return OCTIC_OK;
+  if (!gout || !gy || (partials && !y)) return OCTIC_ENULL;
+  if (int e = dense_check(rows, d)) return e;
+  if (y_dtype != OCTIC_F32 && y_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
+  if (rs && rows_per_scale <= 0) return OCTIC_ESHAPE;
+  const int blocks = dense_blocks(rows);
+  const size_t lds = (size_t)2 * d * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dtype == OCTIC_BF16) {
+    DENSE_NV_SWITCH(dense_nv(d), (scale_residual_bwd_kernel<bf16, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>(gout, (const bf16*)y, gamma, rs,
+                                                     rows_per_scale, (bf16*)gy, partials, rows, d)));
+  } else {
+    DENSE_NV_SWITCH(dense_nv(d), (scale_residual_bwd_kernel<float, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>(gout, (const float*)y, gamma, rs,
+                                                     rows_per_scale, (float*)gy, partials, rows, d)));
+  }
+  return launch_status();
+}
+
+}  // extern "C"

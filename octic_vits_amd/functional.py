@@ -296,6 +296,110 @@ def attention_core(q, k, v, dropout_p=0.0):
     return torch.nn.functional.scaled_dot_product_attention(q, k, v, dropout_p=dropout_p)
 
 
+# -------------------------------------------------------------------------------------- standard half
+class DenseWeightCache:
+    """Compute-dtype copy of an nn.Linear's weight and bias, refreshed when the master parameters change."""
+
+    def __init__(self):
+        self.key = None
+        self.w = self.b = None
+
+    def get(self, w, b, dtype):
+        key = (dtype, w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+        if key != self.key:
+            with torch.no_grad():
+                self.w = _c(w.detach().to(dtype))
+                self.b = None if b is None else _c(b.detach().to(dtype))
+            self.key = key
+        return self.w, self.b
+
+
+class DenseLayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim of an f32 residual stream, result in the compute dtype.  Returns (y, x): the
+    second output is the stream itself, to be used for the residual connection, so that the residual cotangent
+    comes back through this node and is added inside the backward kernel instead of by a separate pass."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, out_dtype):
+        x = _c(x)
+        w32 = None if w is None else _c(w.detach().float())
+        b32 = None if b is None else _c(b.detach().float())
+        y, stats = ops.dense_layernorm_fwd(x, w32, b32, eps, out_dtype)
+        ctx.save_for_backward(x, stats, w32)
+        ctx.has_w, ctx.has_b = w is not None, b is not None
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gres):
+        x, stats, w32 = ctx.saved_tensors
+        if gy is None:
+            return gres, None, None, None, None
+        want = ctx.has_w and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dres = None if gres is None else _c(gres.float())
+        dx, dw, db = ops.dense_layernorm_bwd(_c(gy), x, w32, stats, dres, want_param_grads=want)
+        return dx, (dw if ctx.has_w else None), (db if ctx.has_b else None), None, None
+
+
+class DenseLinearFn(torch.autograd.Function):
+    """nn.Linear on the BLAS library with cached compute-dtype weights (no per-step cast kernels in the graph)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dtype, cache):
+        ops._require_cuda(x)
+        xb = _c(x if x.dtype == dtype else x.to(dtype))
+        wb, bb = cache.get(w, b, dtype)
+        with torch.autocast("cuda", enabled=False):
+            y = torch.nn.functional.linear(xb, wb, bb)
+        ctx.save_for_backward(xb, wb)
+        ctx.has_b, ctx.x_dtype = b is not None, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb = ctx.saved_tensors
+        g2, x2 = _c(gy).reshape(-1, wb.shape[0]), xb.reshape(-1, wb.shape[1])
+        with torch.autocast("cuda", enabled=False):
+            gx = (g2 @ wb).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+            gw = (g2.t() @ x2).float()
+            gb = g2.sum(0, dtype=torch.float32) if ctx.has_b else None
+        return gx, gw, gb, None, None
+
+
+class LinearScaleResidualFn(torch.autograd.Function):
+    """Tail of a standard block branch:  out = x + rs * gamma * (a W^T + b)  with x the f32 residual stream, a the
+    compute-dtype branch activations, gamma the layer scale [d] and rs the per-sample stochastic-depth factor
+    (both optional).  The GEMMs are the library's; everything around them is one HIP pass each way, which also
+    yields d gamma and the bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, a, w, b, gamma, rs, rps, dtype, cache):
+        ops._require_cuda(x)
+        x = _c(x)
+        ab = _c(a if a.dtype == dtype else a.to(dtype))
+        wb, bb = cache.get(w, b, dtype)
+        with torch.autocast("cuda", enabled=False):
+            y = torch.nn.functional.linear(ab, wb, bb)
+        g32 = None if gamma is None else _c(gamma.detach().float())
+        rs32 = None if rs is None else _c(rs.detach().float())
+        out = ops.scale_residual_fwd(x, y, g32, rs32, rps)
+        ctx.save_for_backward(ab, wb, y, g32, rs32)
+        ctx.meta = (rps, b is not None, gamma is not None, a.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ab, wb, y, g32, rs32 = ctx.saved_tensors
+        rps, has_b, has_gamma, a_dtype = ctx.meta
+        gout = _c(gout.float())
+        gy, dgamma, colsum = ops.scale_residual_bwd(gout, y, g32, rs32, rps, want_gamma=has_gamma, want_colsum=has_b)
+        g2, a2 = gy.reshape(-1, wb.shape[0]), ab.reshape(-1, wb.shape[1])
+        with torch.autocast("cuda", enabled=False):
+            ga = (g2 @ wb).view(ab.shape).to(a_dtype) if ctx.needs_input_grad[1] else None
+            gw = (g2.t() @ a2).float()
+        return gout, ga, gw, colsum, dgamma, None, None, None, None
+
+
 # -------------------------------------------------------------------------------------- hand-off
 class HandoffCatFn(torch.autograd.Function):
     @staticmethod

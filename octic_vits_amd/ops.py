@@ -429,3 +429,71 @@ def lift_wgrad(patches, dout, Kpad, D):
     check(L.octic_lift_wgrad(_p(patches), _p(dout), _p(dw), _p(ws), splits, rows, Kpad, D, dt_code(patches.dtype),
                              _stream(patches)))
     return dw
+
+
+# ------------------------------------------------------------------------------------------ standard half
+def dense_layernorm_fwd(x, w, b, eps, out_dtype):
+    """x: f32 [..., d] contiguous -> (y out_dtype, stats [rows, 2] f32 = (mean, rstd))."""
+    _require_cuda(x)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_layernorm_fwd(_p(x), _p(y), dt_code(out_dtype), _p(w), _p(b), _p(stats), rows, d, float(eps),
+                                          _stream(x)))
+    KERNEL_TIMER.stop(t, f"dense_ln_fwd_kernel<{_DTN[out_dtype]}>", rows * d * (4 + y.element_size()))
+    return y, stats
+
+
+def dense_layernorm_bwd(gy, x, w, stats, dres, want_param_grads=True):
+    """Returns (dx f32 = LN'(gy) + dres, dw, db)."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    nblk = lib().octic_dense_blocks(rows)
+    partials = torch.empty((nblk, 2, d), dtype=torch.float32, device=x.device) if want_param_grads else None
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_layernorm_bwd(_p(gy), dt_code(gy.dtype), _p(x), _p(w), _p(stats), _p(dres), _p(dx),
+                                          _p(partials), rows, d, _stream(x)))
+    KERNEL_TIMER.stop(t, f"dense_ln_bwd_kernel<{_DTN[gy.dtype]}>",
+                      rows * d * (gy.element_size() + 8 + (4 if dres is not None else 0)))
+    if not want_param_grads:
+        return dx, None, None
+    dw = torch.empty(d, dtype=torch.float32, device=x.device)
+    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    check(lib().octic_dense_finish(_p(partials), nblk, d, _p(dw), _p(db), _p(None), _stream(x)))
+    return dx, dw, db
+
+
+def scale_residual_fwd(x, y, gamma, rs, rps):
+    """out = x + rs[row // rps] * gamma * y   (x f32, y f32/bf16, same shape [..., d])."""
+    _require_cuda(x)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    out = torch.empty_like(x)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_scale_residual_fwd(_p(x), _p(y), dt_code(y.dtype), _p(gamma), _p(rs), int(rps), _p(out), rows, d,
+                                         _stream(x)))
+    KERNEL_TIMER.stop(t, f"scale_residual_fwd_kernel<{_DTN[y.dtype]}>", rows * d * (8 + y.element_size()))
+    return out
+
+
+def scale_residual_bwd(gout, y, gamma, rs, rps, want_gamma=True, want_colsum=True):
+    """Returns (gy in y's dtype, dgamma, gamma * colsum(rs*gout) = bias gradient of the producer of y)."""
+    d = gout.shape[-1]
+    rows = gout.numel() // d
+    gy = torch.empty(gout.shape, dtype=y.dtype, device=gout.device)
+    nblk = lib().octic_dense_blocks(rows)
+    want = want_gamma or want_colsum
+    partials = torch.empty((nblk, 2, d), dtype=torch.float32, device=gout.device) if want else None
+    t = KERNEL_TIMER.start()
+    check(lib().octic_scale_residual_bwd(_p(gout), _p(y), dt_code(y.dtype), _p(gamma), _p(rs), int(rps), _p(gy),
+                                         _p(partials), rows, d, _stream(gout)))
+    KERNEL_TIMER.stop(t, f"scale_residual_bwd_kernel<{_DTN[y.dtype]}>", rows * d * (4 + 2 * y.element_size()))
+    if not want:
+        return gy, None, None
+    dgamma = torch.empty(d, dtype=torch.float32, device=gout.device) if want_gamma else None
+    colsum = torch.empty(d, dtype=torch.float32, device=gout.device) if want_colsum else None
+    check(lib().octic_dense_finish(_p(partials), nblk, d, _p(dgamma), _p(colsum), _p(gamma), _stream(gout)))
+    return gy, dgamma, colsum

@@ -166,6 +166,10 @@ class FusedLamb:
             vp(self.chunk_tensor), vp(self.chunk_off), vp(self.chunk_len), vp(self.tensor_chunk_begin),
             self.ntensors, self.nchunks, vp(self.ws), float(self.lr), float(self.betas[0]), float(self.betas[1]),
             float(self.eps), float(self.max_grad_norm or 0.0), self.step_count, float(self.ema_decay or 0.0), stream))
+        # the kernels wrote the parameters behind autograd's back: advance their version counters so that every
+        # cache keyed on them (the compute-dtype weight copies of functional.WeightPrep) is refreshed
+        torch._C._autograd._unsafe_set_version_counter(
+            tuple(self.params), tuple(p._version + 1 for p in self.params))
 
 
 def param_groups_weight_decay(model, weight_decay, no_decay_names=()):
@@ -204,10 +208,28 @@ def synthetic_batch(batch, num_classes, device, seed, img_size=224):
     return samples.to(device), targets.to(device)
 
 
+def use_tuned_gemms(table=None):
+    """The standard half of the hybrid runs its four projections per block on the library GEMMs (hipBLASLt / rocBLAS).
+    Which library solution is fastest per (layout, m, n, k) was searched once on an MI355X with PyTorch's TunableOp and
+    is shipped as a lookup table; this only loads it (tuning itself stays off, so a step never searches).  Shapes that
+    are not in the table, or a library build whose validators differ, fall back to the library default."""
+    import torch.cuda.tunable as tunable
+    if os.environ.get("OCTIC_TUNED_GEMMS", "1") == "0":
+        return False
+    table = table or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunable", "gfx950_vit_huge_b64.csv")
+    if not os.path.exists(table):
+        return False
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    tunable.record_untuned_enable(False)
+    return bool(tunable.read_file(table))
+
+
 class Trainer:
     def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
-                 fused_optimizer=True):
+                 fused_optimizer=True, tuned_gemms=True):
         self.raw_model = model
+        self.tuned_gemms = use_tuned_gemms() if (tuned_gemms and torch.cuda.is_available()) else False
         self.model = model
         if distributed:
             # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)

@@ -1,7 +1,8 @@
 """Standard (non-octic) half of the hybrid models: vanilla pre-norm ViT blocks with the state_dict keys of
 the reference (deit/vit.py:14-134 ``Attention``/``Layer_scale_init_Block``; timm 1.0.12 ``Block`` for the
-bare default, model.py:21,63).  Stock PyTorch-ROCm ops (hipBLASLt linears, LayerNorm, GELU) like the reference — SURVEY.md §8a row 12 — except the
-softmax attention core, which is the engine's HIP kernel for bf16 (§8f-1); fusing the rest is §8f-3."""
+bare default, model.py:21,63).  In f32 / on CPU these are stock PyTorch ops like the reference.  Under bf16 autocast on the
+GPU a block runs on the engine instead (§8f-1, §8f-3): HIP LayerNorm / attention / layer-scale+drop-path+residual
+kernels around the four library GEMMs, with cached bf16 weights — same math, same parameters, same RNG draws."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -36,9 +37,22 @@ class Mlp(nn.Module):
         self.norm = norm_layer(hidden_features) if norm_layer is not None else nn.Identity()
         self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
         self.drop2 = nn.Dropout(drop)
+        self._c1, self._c2 = _OF.DenseWeightCache(), _OF.DenseWeightCache()
 
     def forward(self, x):
         return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
+
+    def fusable(self):
+        drop = self.training and (self.drop1.p > 0. or self.drop2.p > 0.)
+        return (not drop and isinstance(self.norm, nn.Identity) and type(self.act) is nn.GELU
+                and self.act.approximate == "none" and type(self.fc1) is nn.Linear and type(self.fc2) is nn.Linear)
+
+    def forward_fused(self, y, xres, gamma, rs, dtype):
+        """xres + rs*gamma*fc2(gelu(fc1(y))) with y already normalised and in the compute dtype."""
+        h = _OF.DenseLinearFn.apply(y, self.fc1.weight, self.fc1.bias, dtype, self._c1)
+        h = F.gelu(h)
+        return _OF.LinearScaleResidualFn.apply(xres, h, self.fc2.weight, self.fc2.bias, gamma, rs, y.shape[1], dtype,
+                                               self._c2)
 
 
 class Attention(nn.Module):
@@ -52,6 +66,20 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.fused_attn = fused_attn
+        self._c1, self._c2 = _OF.DenseWeightCache(), _OF.DenseWeightCache()
+
+    def fusable(self, N, dtype):
+        drop = self.training and (self.attn_drop.p > 0. or self.proj_drop.p > 0.)
+        return (not drop and self.fused_attn and type(self.qkv) is nn.Linear and type(self.proj) is nn.Linear
+                and _ops.attn_supported(N, self.qkv.in_features // self.num_heads, dtype))
+
+    def forward_fused(self, y, xres, gamma, rs, dtype):
+        """xres + rs*gamma*proj(attention(qkv(y))) with y already normalised and in the compute dtype."""
+        B, N, C = y.shape
+        hd = C // self.num_heads
+        qkv = _OF.DenseLinearFn.apply(y, self.qkv.weight, self.qkv.bias, dtype, self._c1)
+        a = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
+        return _OF.LinearScaleResidualFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, dtype, self._c2)
 
     def forward(self, x):
         B, N, C = x.shape
@@ -72,6 +100,40 @@ class Attention(nn.Module):
         return self.proj_drop(self.proj(x.transpose(1, 2).reshape(B, N, C)))
 
 
+def _drop_path_scale(dp, x):
+    """Per-sample stochastic-depth factor [B] drawn exactly like DropPath.forward draws its mask, or None."""
+    if not isinstance(dp, DropPath) or dp.drop_prob == 0. or not dp.training:
+        return None
+    keep = 1 - dp.drop_prob
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+    if keep > 0.0 and dp.scale_by_keep:
+        mask.div_(keep)
+    return mask.view(-1)
+
+
+def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2):
+    """bf16-autocast forward of one standard block on the engine's row kernels + library GEMMs, or None when the
+    block is not in that regime (f32 run, CPU, dropout active, exotic sub-modules): the caller then runs eager."""
+    if not (x.is_cuda and x.ndim == 3 and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return None
+    d = x.shape[-1]
+    for n in (norm1, norm2):
+        if type(n) is not nn.LayerNorm or tuple(n.normalized_shape) != (d,) or d % 4 or d > 2048:
+            return None
+    if not (isinstance(attn, Attention) and isinstance(mlp, Mlp) and attn.fusable(x.shape[1], torch.bfloat16)
+            and mlp.fusable()):
+        return None
+    for dp in (dp1, dp2):
+        if not isinstance(dp, (DropPath, nn.Identity)):
+            return None
+    dt = torch.bfloat16
+    y, xres = _OF.DenseLayerNormFn.apply(x, norm1.weight, norm1.bias, norm1.eps, dt)
+    x = attn.forward_fused(y, xres, gamma1, _drop_path_scale(dp1, x), dt)
+    y, xres = _OF.DenseLayerNormFn.apply(x, norm2.weight, norm2.bias, norm2.eps, dt)
+    return mlp.forward_fused(y, xres, gamma2, _drop_path_scale(dp2, x), dt)
+
+
 class Layer_scale_init_Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
                  drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, Attention_block=Attention, Mlp_block=Mlp,
@@ -87,6 +149,10 @@ class Layer_scale_init_Block(nn.Module):
         self.gamma_2 = nn.Parameter(init_values * torch.ones((dim)), requires_grad=True)
 
     def forward(self, x):
+        out = _fused_block(x, self.norm1, self.attn, self.gamma_1, self.drop_path, self.norm2, self.mlp, self.gamma_2,
+                           self.drop_path)
+        if out is not None:
+            return out
         x = x + self.drop_path(self.gamma_1 * self.attn(self.norm1(x)))
         x = x + self.drop_path(self.gamma_2 * self.mlp(self.norm2(x)))
         return x
@@ -118,6 +184,13 @@ class Block(nn.Module):
         self.drop_path2 = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
     def forward(self, x):
+        ls_ok = all(isinstance(ls, nn.Identity) or (isinstance(ls, LayerScale) and not ls.inplace)
+                    for ls in (self.ls1, self.ls2))
+        if ls_ok:
+            out = _fused_block(x, self.norm1, self.attn, getattr(self.ls1, "gamma", None), self.drop_path1, self.norm2,
+                               self.mlp, getattr(self.ls2, "gamma", None), self.drop_path2)
+            if out is not None:
+                return out
         x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
         x = x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
         return x

@@ -1,0 +1,168 @@
+"""GPU parity of the standard-half row kernels (plain LayerNorm, layer-scale + stochastic-depth + residual tail)
+through the C ABI, and of a whole fused standard block against the eager f32 oracle block.
+
+Tolerances: f32 kernels vs fp64 torch math 2e-5; bf16 outputs 2^-8 relative (one rounding); column-sum
+gradients (reductions over thousands of rows) 1e-4 relative to their scale.
+"""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import octic_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ops():
+    from octic_vits_amd import ops as o
+    return o
+
+
+def gen(seed, *shape, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("rows,d", [(1, 4), (37, 132), (257, 1280), (1030, 2048), (3000, 768), (16448, 1280)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_dense_layernorm_fwd_bwd(rows, d, out_dtype):
+    x = gen(1, rows, d) * 3 + 0.5
+    w, b = gen(2, d) * 0.3 + 1, gen(3, d) * 0.2
+    gy = gen(4, rows, d)
+    dres = gen(5, rows, d)
+    if out_dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    x64 = x.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y64 = F.layer_norm(x64, (d,), w64, b64, 1e-6)
+    y64.backward(gy.double())
+    xc, wc, bc = x.to(DEV), w.to(DEV), b.to(DEV)
+    y, stats = ops().dense_layernorm_fwd(xc, wc, bc, 1e-6, out_dtype)
+    tol = 2e-5 if out_dtype == torch.float32 else 2 ** -7
+    torch.testing.assert_close(y.float().cpu(), y64.detach().float(), rtol=tol, atol=tol)
+    mean = x.double().mean(-1)
+    torch.testing.assert_close(stats[:, 0].cpu().double(), mean, rtol=1e-5, atol=1e-5)
+    dx, dw, db = ops().dense_layernorm_bwd(gy.to(DEV).to(out_dtype), xc, wc, stats, dres.to(DEV))
+    ref_dx = x64.grad.float() + dres
+    torch.testing.assert_close(dx.cpu(), ref_dx, rtol=1e-4, atol=1e-4)
+    sc = float(rows) ** 0.5
+    torch.testing.assert_close(dw.cpu(), w64.grad.float(), rtol=1e-4, atol=1e-4 * sc)
+    torch.testing.assert_close(db.cpu(), b64.grad.float(), rtol=1e-4, atol=1e-4 * sc)
+    # no residual cotangent, no parameter gradients
+    dx2, dw2, db2 = ops().dense_layernorm_bwd(gy.to(DEV).to(out_dtype), xc, wc, stats, None, want_param_grads=False)
+    torch.testing.assert_close(dx2.cpu(), x64.grad.float(), rtol=1e-4, atol=1e-4)
+    assert dw2 is None and db2 is None
+
+
+def test_dense_layernorm_without_affine_and_empty():
+    x = gen(1, 10, 64).to(DEV)
+    y, stats = ops().dense_layernorm_fwd(x, None, None, 1e-5, torch.float32)
+    torch.testing.assert_close(y, F.layer_norm(x, (64,), None, None, 1e-5), rtol=2e-5, atol=2e-5)
+    e = torch.empty(0, 64, device=DEV)
+    y, stats = ops().dense_layernorm_fwd(e, None, None, 1e-5, torch.float32)
+    assert y.shape == (0, 64)
+    with pytest.raises(RuntimeError):
+        ops().dense_layernorm_fwd(gen(1, 4, 6).to(DEV), None, None, 1e-5, torch.float32)      # d % 4 != 0
+
+
+@pytest.mark.parametrize("B,T,d", [(1, 1, 8), (3, 17, 132), (8, 257, 1280), (64, 257, 1280)])
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_rs,with_gamma", [(True, True), (False, True), (True, False), (False, False)])
+def test_scale_residual_fwd_bwd(B, T, d, ydt, with_rs, with_gamma):
+    if B == 64 and not (with_rs and with_gamma):
+        pytest.skip("full size only for the full form")
+    x, y = gen(1, B, T, d), gen(2, B, T, d).to(ydt)
+    gamma = (gen(3, d) * 0.5) if with_gamma else None
+    rs = (torch.bernoulli(torch.full((B,), 0.6), generator=torch.Generator().manual_seed(4)) / 0.6) if with_rs else None
+    gout = gen(5, B, T, d)
+    dev = lambda t: None if t is None else t.to(DEV)
+    out = ops().scale_residual_fwd(dev(x), dev(y), dev(gamma), dev(rs), T)
+    s = torch.ones(B, 1, 1, dtype=torch.float64) if rs is None else rs.double().view(B, 1, 1)
+    g = torch.ones(d, dtype=torch.float64) if gamma is None else gamma.double()
+    ref = x.double() + s * g * y.double()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-6, atol=2e-6)
+    gy, dgamma, colsum = ops().scale_residual_bwd(dev(gout), dev(y), dev(gamma), dev(rs), T)
+    ref_gy = s * g * gout.double()
+    tol = 1e-6 if ydt == torch.float32 else 2 ** -8
+    torch.testing.assert_close(gy.cpu().double(), ref_gy, rtol=tol, atol=tol * 1e-2)
+    sc = float(B * T) ** 0.5
+    torch.testing.assert_close(dgamma.cpu().double(), (s * gout.double() * y.double()).sum((0, 1)), rtol=1e-4,
+                               atol=1e-5 * sc)
+    torch.testing.assert_close(colsum.cpu().double(), g * (s * gout.double()).sum((0, 1)), rtol=1e-4, atol=1e-5 * sc)
+
+
+def _blocks(kind, dim, heads, drop_path):
+    from octic_vits_amd import vit
+    torch.manual_seed(0)
+    if kind == "layer_scale":
+        blk = vit.Layer_scale_init_Block(dim, heads, qkv_bias=True, drop_path=drop_path, init_values=0.5)
+        ref = R.Layer_scale_init_Block(dim, heads, qkv_bias=True, drop_path=drop_path, init_values=0.5)
+    else:
+        blk = vit.Block(dim, heads, qkv_bias=True, drop_path=drop_path, init_values=None)
+        ref = R.Block(dim, heads, qkv_bias=True, drop_path=drop_path, init_values=None)
+    with torch.no_grad():
+        for i, p in enumerate(blk.parameters()):
+            p.copy_(gen(100 + i, *p.shape) * (0.08 if p.ndim > 1 else 0.3) + (1.0 if p.ndim == 1 and i % 2 == 0 else 0.0))
+    ref.load_state_dict(blk.state_dict())
+    return blk.to(DEV), ref
+
+
+@pytest.mark.parametrize("kind", ["layer_scale", "timm"])
+def test_fused_standard_block_matches_oracle(kind):
+    """bf16-autocast fused block vs the f32 CPU oracle block: output within 1e-2 of the output scale (bf16 GEMM
+    operands), every gradient within 3e-2 relative L2."""
+    dim, heads, B, T = 128, 4, 4, 50
+    blk, ref = _blocks(kind, dim, heads, 0.0)
+    x = gen(7, B, T, dim)
+    gout = gen(8, B, T, dim)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gout)
+    xg = x.to(DEV).requires_grad_(True)
+    o = ops()
+    o.KERNEL_TIMER.enable()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yg = blk(xg)
+    yg.backward(gout.to(DEV))
+    names = set(o.KERNEL_TIMER.summary())
+    o.KERNEL_TIMER.disable()
+    assert any(n.startswith("dense_ln_fwd") for n in names) and any(n.startswith("scale_residual_bwd") for n in names)
+    assert yg.dtype == torch.float32
+    scale = float(yr.detach().abs().mean())
+    assert float((yg.detach().cpu() - yr.detach()).abs().max()) < 2e-2 * max(scale, 1.0)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    assert rel(xg.grad.cpu(), xr.grad) < 3e-2
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad.cpu().float(), q.grad) < 3e-2, n
+
+
+def test_fused_standard_block_drop_path_draws_like_eager():
+    """Stochastic depth in the fused block consumes the RNG exactly like the eager block: same seed, same kept samples."""
+    dim, heads, B, T = 64, 4, 16, 20
+    blk, _ = _blocks("layer_scale", dim, heads, 0.5)
+    blk.train()
+    x = gen(9, B, T, dim).to(DEV)
+    torch.manual_seed(123)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        fused = blk(x)
+    torch.manual_seed(123)
+    eager = blk(x.double().float())                       # f32, no autocast -> eager path
+    kept_f = (fused - x).flatten(1).abs().amax(1) > 0
+    assert 0 < int(kept_f.sum()) <= B
+    torch.testing.assert_close(fused, eager, rtol=3e-2, atol=3e-2)
+
+
+def test_fused_block_is_skipped_outside_its_regime():
+    dim, heads = 64, 4
+    blk, ref = _blocks("layer_scale", dim, heads, 0.0)
+    x = gen(9, 2, 10, dim)
+    o = ops()
+    o.KERNEL_TIMER.enable()
+    y = blk(x.to(DEV))                                       # f32 without autocast: eager ops, exact reference math
+    names = set(o.KERNEL_TIMER.summary())
+    o.KERNEL_TIMER.disable()
+    assert not any(n.startswith("dense_") for n in names)
+    torch.testing.assert_close(y.cpu(), ref(x), rtol=1e-4, atol=1e-4)

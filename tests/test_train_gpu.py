@@ -67,3 +67,29 @@ def test_train_step_small_hybrid_model():
     assert all(moved) and len(moved) > 50
     frozen = [torch.equal(a, b) for a, b in zip(before, net.parameters()) if not b.requires_grad]
     assert all(frozen)                     # cls_token.1-4 stay frozen zeros (reference model.py:99-105)
+
+
+def test_weight_caches_follow_fused_optimizer():
+    """The fused LAMB step writes parameters through raw pointers; the compute-dtype weight caches must notice."""
+    from octic_vits_amd import functional as OF
+    from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.train import Trainer, synthetic_batch
+    from octic_vits_amd.vit import Layer_scale_init_Block
+    torch.manual_seed(1)
+    net = OcticVisionTransformer(img_size=56, patch_size=14, num_classes=100, embed_dim=128, depth=4, num_heads=4,
+                                 qkv_bias=True, drop_path_rate=0.0, octic_block_layers=Layer_scale_init_BlockD8,
+                                 standard_block_layers=Layer_scale_init_Block).cuda()
+    tr = Trainer(net)
+    x, y = synthetic_batch(8, 100, "cuda", 5, img_size=56)
+    for _ in range(3):
+        tr.step(x, y)
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        cached = net(x).float()
+        for m in net.modules():                      # drop every cache: the next forward re-derives from the masters
+            for k, v in vars(m).items():
+                if isinstance(v, (OF.WeightPrep, OF.DenseWeightCache)):
+                    setattr(m, k, type(v)())
+        fresh = net(x).float()
+    assert torch.equal(cached, fresh)
