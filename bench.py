@@ -116,6 +116,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(samples, targets)
+    issued = time.perf_counter() - t0          # host time to enqueue the steps (no sync): launch-bound if ~ elapsed
     sync()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER.disable()
@@ -138,7 +139,7 @@ def main():
                                    f"(BASELINE configs[1]), data parallel over {world} GPU(s)",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "library_gemm_table": bool(trainer.tuned_gemms)},
-            "loss": float(loss.item()),
+            "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),
             "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4),
         }
         k = ops.KERNEL_TIMER.dominant()

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void dense_ln_fwd_kernel(const float* __restri
       xv[i] = ok[i] ? *(const f32x4*)(xr + (i * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       s += hsum(xv[i]);
     }
-    const float mean = wave_sum(s) * inv_d;
+    const float mean = wave_total(s) * inv_d;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void dense_ln_fwd_kernel(const float* __restri
       xv[i] = c;
       if (ok[i]) q += hsum(c * c);
     }
-    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    const float rstd = rsqrtf(wave_total(q) * inv_d + eps);
     TOUT* yr = y + r * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -105,22 +105,23 @@ __device__ inline void slab_reduce(float* lds, float* slab, const f32x4 (&p0)[NV
 // ------------------------------------------------------------------------------------------ LayerNorm backward
 // dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) + dres,  g = gy*w;  slab partials: dw += gy*xhat, db += gy.
 template <typename TG, int NV>
-__global__ __launch_bounds__(kDenseWaves * 64) void dense_ln_bwd_kernel(
+__global__ __launch_bounds__(kDenseWaves * 64, 4) void dense_ln_bwd_kernel(
     const TG* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
     float* __restrict__ partials, long rows, int d) {
-  extern __shared__ float lds[];
+  extern __shared__ float lds[];             // [2][d] slab image | [d] weights (kept out of the register budget)
   const int lane = threadIdx.x & 63;
   const long nw = (long)gridDim.x * kDenseWaves;
-  f32x4 wv[NV], pw[NV], pb[NV];
+  float* wl = lds + 2 * d;
+  for (int j = threadIdx.x; j < d; j += kDenseWaves * 64) wl[j] = w ? w[j] : 1.f;
+  f32x4 pw[NV], pb[NV];
   bool ok[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int col = (i * 64 + lane) * 4;
-    ok[i] = col < d;
-    wv[i] = (ok[i] && w) ? *(const f32x4*)(w + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    ok[i] = (i * 64 + lane) * 4 < d;
     pw[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  __syncthreads();
   const float inv_d = 1.0f / (float)d;
   for (long r = (long)blockIdx.x * kDenseWaves + (threadIdx.x >> 6); r < rows; r += nw) {
     const float mean = stats[2 * r], rstd = stats[2 * r + 1];
@@ -134,12 +135,12 @@ __global__ __launch_bounds__(kDenseWaves * 64) void dense_ln_bwd_kernel(
         f32x4 gyv = Row4<TG>::load(gy + o);
         pw[i] += gyv * xh[i];
         pb[i] += gyv;
-        g[i] = gyv * wv[i];
+        g[i] = gyv * *(const f32x4*)(wl + (i * 64 + lane) * 4);
         s1 += hsum(g[i]);
         s2 += hsum(g[i] * xh[i]);
       }
     }
-    const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+    const float m1 = wave_total(s1) * inv_d, m2 = wave_total(s2) * inv_d;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       if (ok[i]) {
@@ -280,7 +281,7 @@ int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const
   if (int e = dense_check(rows, d)) return e;
   if (g_dtype != OCTIC_F32 && g_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
   const int blocks = dense_blocks(rows);
-  const size_t lds = (size_t)2 * d * sizeof(float);
+  const size_t lds = (size_t)3 * d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (g_dtype == OCTIC_BF16) {
     DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_kernel<bf16, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>((const bf16*)gy, x, w, stats, dres,

@@ -6,6 +6,7 @@
 // and kept in registers; the chunk count per lane is a template parameter (NV = 5 at ViT-H) so nothing
 // is predicated at run time.  Bound: HBM.
 // Reference: octic_vits/d8_layers.py:161-186 (forward), backward derived in SURVEY.md §10.3.
+#include <stdlib.h>
 #include "octic_common.hpp"
 
 namespace octic {
@@ -63,8 +64,11 @@ __device__ inline float pick6(const float v[6], int seg) {
   return r;
 }
 
-template <typename TOUT, int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(View x, View y, const float* a0, const float* a1, const float* a2,
+// PK: both views are one packed [M, 8c] tensor each (p[g] = p[0] + column offset, equal row strides) - the layout the
+// engine itself always uses - so a chunk's address is row base + lane*16 B + i*1 KiB and nothing per-chunk has to
+// be kept in registers; the generic variant serves foreign 5-tuple views.
+template <typename TOUT, int NV, bool PK>
+__global__ __launch_bounds__(256, PK ? 4 : 2) void ln_fwd_kernel(View x, View y, const float* a0, const float* a1, const float* a2,
                                                      const float* a3, const float* a4, const float* beta,
                                                      float* stats, int64_t M, int c, float eps) {
   const int lane = threadIdx.x & 63;
@@ -86,10 +90,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(View x, View y, const float
       if (a0) av[i] = *(const f32x4*)(alpha[g] + lm.aidx[i]);
       if (beta && lm.seg[i] == 0) bv[i] = *(const f32x4*)(beta + lm.aidx[i]);
     }
-    xb[i] = (const float*)x.p[g] + lm.off[i];
-    yb[i] = (TOUT*)y.p[g] + lm.off[i];
-    xld[i] = x.ld[g];
-    yld[i] = y.ld[g];
+    if constexpr (PK) {
+      xb[i] = (const float*)x.p[0] + (lane + 64 * i) * 4;
+      yb[i] = (TOUT*)y.p[0] + (lane + 64 * i) * 4;
+      xld[i] = x.ld[0];
+      yld[i] = y.ld[0];
+    } else {
+      xb[i] = (const float*)x.p[g] + lm.off[i];
+      yb[i] = (TOUT*)y.p[g] + lm.off[i];
+      xld[i] = x.ld[g];
+      yld[i] = y.ld[g];
+    }
   }
   const float inv_n1 = 1.0f / (float)c, inv_n2 = 1.0f / (float)(2 * c);
   for (int64_t m = wave; m < M; m += nwaves) {
@@ -147,27 +158,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(View x, View y, const float
 //   dx_s = (ghat_s - mean(ghat_s))*rstd + w_s*dS*2*(x_s-mu_s)/n_s       (w = 1 | 1/2, n = c | 2c)
 // Parameter partials: dalpha += g*xhat, dbeta += g, accumulated per wave in registers over its
 // rows, then reduced over the block's 4 waves through LDS into partials[blk][2][8c].
-template <typename TG, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(View g, View x, const float* stats, const float* a0,
+constexpr int kLnBwdWaves = 8;   // 512 slabs x 8 waves = 4 waves per SIMD: enough rows in flight to cover HBM latency
+
+template <typename TG, int NV, bool PK>
+__global__ __launch_bounds__(kLnBwdWaves * 64, PK ? 4 : 2) void ln_bwd_kernel(View g, View x, const float* stats, const float* a0,
                                                      const float* a1, const float* a2, const float* a3,
                                                      const float* a4, View dres, int has_dres, View dx,
                                                      float* partials, int64_t M, int c) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][2][8c]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][8c]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave = (int64_t)blockIdx.x * kLnBwdWaves + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * kLnBwdWaves;
   const int D = 8 * c;
   LaneMap<NV> lm;
   make_lane_map<NV>(lm, lane, c);
   const float* alpha[5] = {a0, a1, a2, a3, a4};
-  f32x4 av[NV], pa[NV], pb[NV];
+  f32x4 av[NV], pa[NV];
+  f32x4 pb = {0, 0, 0, 0};   // sum of g over rows, A1 columns only (c <= 32 NV <= 256: they all sit in chunk 0)
   float coefw[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     av[i] = f32x4{1.f, 1.f, 1.f, 1.f};
     if (a0 && lm.seg[i] >= 0) av[i] = *(const f32x4*)(alpha[lm.grp[i]] + lm.aidx[i]);
     pa[i] = f32x4{0, 0, 0, 0};
-    pb[i] = f32x4{0, 0, 0, 0};
     coefw[i] = (lm.seg[i] < 4) ? 2.0f / (float)c : 1.0f / (float)(2 * c);  // w_s*2/n_s
   }
   const float inv_n1 = 1.0f / (float)c, inv_n2 = 1.0f / (float)(2 * c);
@@ -184,9 +197,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(View g, View x, const float
       xc[i] = f32x4{0, 0, 0, 0};
       gh[i] = f32x4{0, 0, 0, 0};
       if (lm.seg[i] >= 0) {
-        const int gidx = lm.grp[i];
-        const f32x4 xv = *(const f32x4*)((const float*)x.p[gidx] + m * x.ld[gidx] + lm.off[i]);
-        const f32x4 gv = load4<TG>((const TG*)g.p[gidx] + m * g.ld[gidx] + lm.off[i]);
+        const int gidx = PK ? 0 : lm.grp[i];
+        const int eoff = PK ? (lane + 64 * i) * 4 : lm.off[i];
+        const f32x4 xv = *(const f32x4*)((const float*)x.p[gidx] + m * x.ld[gidx] + eoff);
+        const f32x4 gv = load4<TG>((const TG*)g.p[gidx] + m * g.ld[gidx] + eoff);
         const float mu = pick6(mean, lm.seg[i]);
         float t = 0.f;
 #pragma unroll
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(View g, View x, const float
           const float xh = xc[i][j] * rstd;
           gh[i][j] = av[i][j] * gv[j];
           pa[i][j] += gv[j] * xh;
-          pb[i][j] += gv[j];
+          if (i == 0) pb[j] += gv[j];
           dot += gh[i][j] * xh;
           t += gh[i][j];
         }
@@ -210,35 +224,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(View g, View x, const float
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if (lm.seg[i] >= 0) {
-        const int gidx = lm.grp[i];
+        const int gidx = PK ? 0 : lm.grp[i];
+        const int eoff = PK ? (lane + 64 * i) * 4 : lm.off[i];
         const float mg = pick6(sg, lm.seg[i]);
         const float coef = coefw[i] * dS;
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (gh[i][j] - mg) * rstd + coef * xc[i][j];
         if (has_dres) {
-          const f32x4 r = *(const f32x4*)((const float*)dres.p[gidx] + m * dres.ld[gidx] + lm.off[i]);
+          const f32x4 r = *(const f32x4*)((const float*)dres.p[gidx] + m * dres.ld[gidx] + eoff);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] += r[j];
         }
-        *(f32x4*)((float*)dx.p[gidx] + m * dx.ld[gidx] + lm.off[i]) = o;
+        *(f32x4*)((float*)dx.p[gidx] + m * dx.ld[gidx] + eoff) = o;
       }
     }
   }
-  // block reduction of the parameter partials
-  float* mine = smem + (size_t)wid * 2 * D;
+  // block reduction of the parameter partials: the waves add their registers into one [2][8c] image in turn
+  // (fixed order -> bitwise reproducible), then the block writes its slab
+  for (int w = 0; w < kLnBwdWaves; ++w) {
+    if (wid == w) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = (lane + 64 * i) * 4;
-    if (lm.seg[i] >= 0) {
-      *(f32x4*)(mine + e) = pa[i];
-      *(f32x4*)(mine + D + e) = pb[i];
+      for (int i = 0; i < NV; ++i) {
+        const int e = (lane + 64 * i) * 4;
+        if (lm.seg[i] >= 0) {
+          f32x4* qa = (f32x4*)(smem + e);
+          f32x4* qb = (f32x4*)(smem + D + e);
+          if (w == 0) {
+            *qa = pa[i];
+            if (i == 0) *qb = pb;
+          } else {
+            *qa += pa[i];
+            if (i == 0) *qb += pb;
+          }
+        }
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* outp = partials + (size_t)blockIdx.x * 2 * D;
-  for (int e = threadIdx.x; e < 2 * D; e += 256)
-    outp[e] = smem[e] + smem[2 * D + e] + smem[4 * D + e] + smem[6 * D + e];
+  // plane 0: all 8c columns; plane 1: only its first 256 columns (>= c) carry data
+  for (int e = threadIdx.x * 4; e < D + 256 && e < 2 * D; e += kLnBwdWaves * 64 * 4)
+    *(f32x4*)(outp + e) = *(const f32x4*)(smem + e);
 }
 
 // Reduce partials[nblk][2][8c] over blocks.  256 threads = 16 outputs x 16 block-lanes; the 16 lanes of an
@@ -277,10 +304,175 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* partial
   }
 }
 
-inline int ln_blocks(int64_t M) {
-  int64_t b = (M + 3) / 4;
-  const int64_t cap = 256 * 2;  // 2 blocks (8 waves) per CU x register-resident rows; grid-stride beyond
+// ---------------------------------------------------------------------------------------------------------------
+// Lane-group variants (packed rows, c % 32 == 0).  Lanes 0-7 own segment A1, 8-15 A2, 16-23 B1, 24-31 B2, 32-47 the
+// first E row, 48-63 the second: every lane's NV = c/32 chunks belong to ONE segment, so a segment mean is a sum
+// over 8 (16) neighbouring lanes - three (four) DPP adds, no LDS permutes, no per-chunk segment selects - and the
+// row-wide terms are one 64-lane DPP reduction.  A wave-load still covers whole 128-byte lines (8 lanes x 16 B).
+// The row is eight octets of c columns (A1 A2 B1 B2 | E row 0: 2 octets | E row 1: 2 octets); octet o belongs to
+// lanes 8o..8o+7 and chunk i of a lane covers packed columns col0 + 32 i .. +3: one uniform 128-byte stride, so every
+// load / store of a row uses the same base register with an immediate offset.
+struct LaneGroup {
+  bool isE;
+  int seg, col0, acol0;          // acol0 + 32 i = index into this segment's alpha
+  static constexpr int step4 = 32;
+};
+__device__ inline LaneGroup lane_group(int lane, int c) {
+  LaneGroup lg;
+  const int o = lane >> 3, j = lane & 7;
+  lg.isE = o >= 4;
+  lg.seg = lg.isE ? 4 + ((o - 4) >> 1) : o;
+  lg.col0 = o * c + j * 4;
+  lg.acol0 = (lg.isE ? (o & 1) * c : 0) + j * 4;
+  return lg;
+}
+__device__ inline const float* pick_alpha(const LaneGroup& lg, const float* a0, const float* a1, const float* a2,
+                                          const float* a3, const float* a4) {
+  const float* p = a0;
+  p = lg.seg == 1 ? a1 : p;
+  p = lg.seg == 2 ? a2 : p;
+  p = lg.seg == 3 ? a3 : p;
+  return lg.seg >= 4 ? a4 : p;
+}
+
+template <typename TOUT, int NV>
+__global__ __launch_bounds__(256, 4) void ln_fwd_g8_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           TOUT* __restrict__ y, int64_t ldy, const float* a0,
+                                                           const float* a1, const float* a2, const float* a3,
+                                                           const float* a4, const float* beta,
+                                                           float* __restrict__ stats, int64_t M, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const LaneGroup lg = lane_group(lane, c);
+  const float* ap = pick_alpha(lg, a0, a1, a2, a3, a4);
+  f32x4 av[NV], bv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    av[i] = a0 ? *(const f32x4*)(ap + lg.acol0 + i * lg.step4) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bv[i] = (beta && lg.seg == 0) ? *(const f32x4*)(beta + lg.acol0 + i * lg.step4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_n = lg.isE ? 1.0f / (float)(2 * c) : 1.0f / (float)c;
+  const float wq = lg.isE ? 0.5f * inv_n : inv_n;      // weight of this lane's squares in S
+  const int stat_idx = (lg.acol0 == 0) ? lg.seg : (lane == 1 ? 6 : -1);
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += nwaves) {
+    const float* xr = x + m * ldx + lg.col0;
+    f32x4 xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xv[i] = *(const f32x4*)(xr + i * lg.step4);
+      s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+    }
+    const float s8 = sum8(s);
+    const float s16 = sum16_from8(s8);
+    const float mean = (lg.isE ? s16 : s8) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xv[i] -= mean;
+      const f32x4 sq = xv[i] * xv[i];
+      q += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+    }
+    const float S = eps + wave_total(q * wq);
+    const float rstd = 1.0f / (kSqrt2Over4 * sqrtf(S));
+    TOUT* yr = y + m * ldy + lg.col0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) store4<TOUT>(yr + i * lg.step4, xv[i] * rstd * av[i] + bv[i]);
+    if (stats && stat_idx >= 0) stats[m * 8 + stat_idx] = (stat_idx == 6) ? rstd : mean;
+  }
+}
+
+// Backward.  Register budget (128 for 4 waves/SIMD) goes to the row in flight and the d alpha partials; alpha itself
+// and the d beta partials (A1 lanes only) live in LDS - each lane re-reads / updates only its own addresses.
+// LDS: [2][8c] slab image | [8c] alpha by packed column | [waves][c] d beta partials.
+template <typename TG, int NV>
+__global__ __launch_bounds__(kLnBwdWaves * 64, 4) void ln_bwd_g8_kernel(
+    const TG* __restrict__ g, int64_t ldg, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
+    const float* a0, const float* a1, const float* a2, const float* a3, const float* a4,
+    const float* __restrict__ dres, int64_t ldr, float* __restrict__ dx, int64_t ldd, float* __restrict__ partials,
+    int64_t M, int c) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t nwaves = (int64_t)gridDim.x * kLnBwdWaves;
+  const int D = 8 * c;
+  float* alds = smem + 2 * D;
+  float* pbl = smem + 3 * D + wid * c;
+  const LaneGroup lg = lane_group(lane, c);
+  for (int e = threadIdx.x; e < D; e += kLnBwdWaves * 64) {
+    float v = 1.f;
+    if (a0) {
+      const int sg = e < 4 * c ? e / c : 4;
+      const float* ap = sg == 0 ? a0 : (sg == 1 ? a1 : (sg == 2 ? a2 : (sg == 3 ? a3 : a4)));
+      v = ap[sg < 4 ? e - sg * c : (e - 4 * c) % (2 * c)];
+    }
+    alds[e] = v;
+  }
+  f32x4 pa[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (lg.seg == 0) *(f32x4*)(pbl + lg.acol0 + i * 32) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const float inv_n = lg.isE ? 1.0f / (float)(2 * c) : 1.0f / (float)c;
+  const float coefw = lg.isE ? inv_n : 2.0f * inv_n;    // w_s*2/n_s
+  for (int64_t m = (int64_t)blockIdx.x * kLnBwdWaves + wid; m < M; m += nwaves) {
+    const float mu = stats[m * 8 + lg.seg], rstd = stats[m * 8 + 6];
+    f32x4 xc[NV], gh[NV];
+    float dot = 0.f, t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xc[i] = *(const f32x4*)(x + m * ldx + lg.col0 + i * lg.step4) - mu;
+      const f32x4 gv = load4<TG>(g + m * ldg + lg.col0 + i * lg.step4);
+      const f32x4 xh = xc[i] * rstd;
+      gh[i] = *(const f32x4*)(alds + lg.col0 + i * lg.step4) * gv;
+      pa[i] += gv * xh;
+      if (lg.seg == 0) *(f32x4*)(pbl + lg.acol0 + i * 32) += gv;
+      const f32x4 d = gh[i] * xh;
+      dot += (d[0] + d[1]) + (d[2] + d[3]);
+      t += (gh[i][0] + gh[i][1]) + (gh[i][2] + gh[i][3]);
+    }
+    const float t8 = sum8(t);
+    const float mg = (lg.isE ? sum16_from8(t8) : t8) * inv_n;
+    const float dS = -rstd * wave_total(dot) * rstd * (1.0f / 16.0f);
+    const float coef = coefw * dS;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 o = (gh[i] - mg) * rstd + xc[i] * coef;
+      if (dres) o += *(const f32x4*)(dres + m * ldr + lg.col0 + i * lg.step4);
+      *(f32x4*)(dx + m * ldd + lg.col0 + i * lg.step4) = o;
+    }
+  }
+  // slab: plane 0 = sum g*xhat for all 8c columns, plane 1 = sum g, A1 columns only (all the finish kernel reads)
+  for (int w = 0; w < kLnBwdWaves; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        f32x4* qa = (f32x4*)(smem + lg.col0 + i * lg.step4);
+        if (w == 0) *qa = pa[i];
+        else *qa += pa[i];
+        if (lg.seg == 0) {
+          f32x4* qb = (f32x4*)(smem + D + lg.acol0 + i * 32);
+          const f32x4 mine = *(const f32x4*)(pbl + lg.acol0 + i * 32);
+          if (w == 0) *qb = mine;
+          else *qb += mine;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* outp = partials + (size_t)blockIdx.x * 2 * D;
+  for (int e = threadIdx.x * 4; e < D + c; e += kLnBwdWaves * 64 * 4) *(f32x4*)(outp + e) = *(const f32x4*)(smem + e);
+}
+
+inline int ln_blocks(int64_t M) {   // backward: one partial slab per block, 8 waves each
+  int64_t b = (M + kLnBwdWaves - 1) / kLnBwdWaves;
+  const int64_t cap = 256 * 2;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline int ln_fwd_blocks(int64_t M) {   // forward: 4 waves per block, 4 rows per wave (per-lane constants amortised)
+  int64_t b = (M + 15) / 16;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 inline int pick_nv(int c) {
@@ -288,25 +480,32 @@ inline int pick_nv(int c) {
   return need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 5 ? 5 : (need <= 8 ? 8 : 0)));
 }
 
-template <typename TOUT>
+// one packed tensor behind the five pointers?
+inline bool view_is_packed(const View& v, int c, int es) {
+  for (int g = 1; g < 5; ++g)
+    if (v.ld[g] != v.ld[0] || v.p[g] != v.p[0] + (int64_t)g * c * es) return false;
+  return true;
+}
+
+template <typename TOUT, bool PK>
 void launch_ln_fwd(int nv, int grid, hipStream_t s, View vx, View vy, const float* const a[5], const float* beta,
                    float* stats, int64_t M, int c, float eps) {
   switch (nv) {
-    case 2: ln_fwd_kernel<TOUT, 2><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
-    case 4: ln_fwd_kernel<TOUT, 4><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
-    case 5: ln_fwd_kernel<TOUT, 5><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
-    default: ln_fwd_kernel<TOUT, 8><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
+    case 2: ln_fwd_kernel<TOUT, 2, PK><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
+    case 4: ln_fwd_kernel<TOUT, 4, PK><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
+    case 5: ln_fwd_kernel<TOUT, 5, PK><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
+    default: ln_fwd_kernel<TOUT, 8, PK><<<grid, 256, 0, s>>>(vx, vy, a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps); break;
   }
 }
 
-template <typename TG>
+template <typename TG, bool PK>
 void launch_ln_bwd(int nv, int grid, size_t smem, hipStream_t s, View vg, View vx, const float* stats,
                    const float* const a[5], View vr, int has_dres, View vd, float* partials, int64_t M, int c) {
   switch (nv) {
-    case 2: ln_bwd_kernel<TG, 2><<<grid, 256, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
-    case 4: ln_bwd_kernel<TG, 4><<<grid, 256, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
-    case 5: ln_bwd_kernel<TG, 5><<<grid, 256, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
-    default: ln_bwd_kernel<TG, 8><<<grid, 256, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
+    case 2: ln_bwd_kernel<TG, 2, PK><<<grid, kLnBwdWaves * 64, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
+    case 4: ln_bwd_kernel<TG, 4, PK><<<grid, kLnBwdWaves * 64, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
+    case 5: ln_bwd_kernel<TG, 5, PK><<<grid, kLnBwdWaves * 64, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
+    default: ln_bwd_kernel<TG, 8, PK><<<grid, kLnBwdWaves * 64, smem, s>>>(vg, vx, stats, a[0], a[1], a[2], a[3], a[4], vr, has_dres, vd, partials, M, c); break;
   }
 }
 
@@ -330,11 +529,25 @@ int octic_layernorm_d8_fwd(const octic_view* x, const octic_view* y, const float
     }
   }
   View vx = make_view<void>(x), vy = make_view<void>(y);
-  const int grid = ln_blocks(M);
+  const int grid = ln_fwd_blocks(M);
   hipStream_t s = (hipStream_t)stream;
-  if (out_dtype == OCTIC_F32) launch_ln_fwd<float>(nv, grid, s, vx, vy, a, beta, stats, M, c, eps);
-  else if (out_dtype == OCTIC_BF16) launch_ln_fwd<bf16>(nv, grid, s, vx, vy, a, beta, stats, M, c, eps);
-  else return OCTIC_EDTYPE;
+  if (out_dtype != OCTIC_F32 && out_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
+  const bool pk = view_is_packed(vx, c, 4) && view_is_packed(vy, c, elem_size(out_dtype));
+  if (pk && (c % 32) == 0 && c <= 256 && !getenv("OCTIC_LN_GENERIC")) {
+    const float* xp = (const float*)vx.p[0];
+#define LN_FWD_G8(T, N) ln_fwd_g8_kernel<T, N><<<grid, 256, 0, s>>>(xp, vx.ld[0], (T*)vy.p[0], vy.ld[0], a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps)
+#define LN_FWD_G8_NV(T) switch (c / 32) { case 1: LN_FWD_G8(T, 1); break; case 2: LN_FWD_G8(T, 2); break; case 3: LN_FWD_G8(T, 3); break; \
+    case 4: LN_FWD_G8(T, 4); break; case 5: LN_FWD_G8(T, 5); break; case 6: LN_FWD_G8(T, 6); break; case 7: LN_FWD_G8(T, 7); break; default: LN_FWD_G8(T, 8); break; }
+    if (out_dtype == OCTIC_F32) { LN_FWD_G8_NV(float) } else { LN_FWD_G8_NV(bf16) }
+    return launch_status();
+  }
+  if (out_dtype == OCTIC_F32) {
+    if (pk) launch_ln_fwd<float, true>(nv, grid, s, vx, vy, a, beta, stats, M, c, eps);
+    else launch_ln_fwd<float, false>(nv, grid, s, vx, vy, a, beta, stats, M, c, eps);
+  } else {
+    if (pk) launch_ln_fwd<bf16, true>(nv, grid, s, vx, vy, a, beta, stats, M, c, eps);
+    else launch_ln_fwd<bf16, false>(nv, grid, s, vx, vy, a, beta, stats, M, c, eps);
+  }
   return launch_status();
 }
 
@@ -361,11 +574,28 @@ int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float
   View vg = make_view<void>(g), vx = make_view<void>(x), vd = make_view<void>(dx);
   View vr = dres ? make_view<void>(dres) : vd;
   const int grid = ln_blocks(M);
-  const size_t smem = (size_t)4 * 2 * 8 * c * sizeof(float);
+  const size_t smem = (size_t)2 * 8 * c * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (g_dtype == OCTIC_F32) launch_ln_bwd<float>(nv, grid, smem, s, vg, vx, stats, a, vr, dres ? 1 : 0, vd, partials, M, c);
-  else if (g_dtype == OCTIC_BF16) launch_ln_bwd<bf16>(nv, grid, smem, s, vg, vx, stats, a, vr, dres ? 1 : 0, vd, partials, M, c);
-  else return OCTIC_EDTYPE;
+  if (g_dtype != OCTIC_F32 && g_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
+  const bool pk = view_is_packed(vg, c, elem_size(g_dtype)) && view_is_packed(vx, c, 4) && view_is_packed(vd, c, 4) &&
+                  view_is_packed(vr, c, 4);
+  const int hd = dres ? 1 : 0;
+  if (pk && (c % 32) == 0 && c <= 256 && !getenv("OCTIC_LN_GENERIC")) {
+    const float* rp = dres ? (const float*)vr.p[0] : nullptr;
+    const size_t smem_g8 = (size_t)(3 * 8 * c + kLnBwdWaves * c) * sizeof(float);
+#define LN_BWD_G8(T, N) ln_bwd_g8_kernel<T, N><<<grid, kLnBwdWaves * 64, smem_g8, s>>>((const T*)vg.p[0], vg.ld[0], (const float*)vx.p[0], vx.ld[0], stats, a[0], a[1], a[2], a[3], a[4], rp, vr.ld[0], (float*)vd.p[0], vd.ld[0], partials, M, c)
+#define LN_BWD_G8_NV(T) switch (c / 32) { case 1: LN_BWD_G8(T, 1); break; case 2: LN_BWD_G8(T, 2); break; case 3: LN_BWD_G8(T, 3); break; \
+    case 4: LN_BWD_G8(T, 4); break; case 5: LN_BWD_G8(T, 5); break; case 6: LN_BWD_G8(T, 6); break; case 7: LN_BWD_G8(T, 7); break; default: LN_BWD_G8(T, 8); break; }
+    if (g_dtype == OCTIC_F32) { LN_BWD_G8_NV(float) } else { LN_BWD_G8_NV(bf16) }
+    return launch_status();
+  }
+  if (g_dtype == OCTIC_F32) {
+    if (pk) launch_ln_bwd<float, true>(nv, grid, smem, s, vg, vx, stats, a, vr, hd, vd, partials, M, c);
+    else launch_ln_bwd<float, false>(nv, grid, smem, s, vg, vx, stats, a, vr, hd, vd, partials, M, c);
+  } else {
+    if (pk) launch_ln_bwd<bf16, true>(nv, grid, smem, s, vg, vx, stats, a, vr, hd, vd, partials, M, c);
+    else launch_ln_bwd<bf16, false>(nv, grid, smem, s, vg, vx, stats, a, vr, hd, vd, partials, M, c);
+  }
   return launch_status();
 }
 

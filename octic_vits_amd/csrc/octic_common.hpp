@@ -71,11 +71,26 @@ __device__ inline float gelu_grad(float r) {
   return 0.5f * (1.0f + erff(r * kSqrt1Over2)) + r * kInvSqrt2Pi * __expf(-0.5f * r * r);
 }
 
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// DPP reductions (VALU only, no LDS permutes): sums over aligned groups of 8 / 16 lanes and over the whole wave.
+template <int CTRL, int RMASK>
+__device__ inline float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RMASK, 0xF, false);
+  return v + __int_as_float(r);
 }
+__device__ inline float sum8(float v) {          // every lane: sum over its aligned group of 8 lanes
+  v = dpp_add<0xB1, 0xF>(v);                     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);                     // quad_perm [2,3,0,1]
+  return dpp_add<0x141, 0xF>(v);                 // row_half_mirror
+}
+__device__ inline float sum16_from8(float v8) { return dpp_add<0x140, 0xF>(v8); }   // row_mirror
+__device__ inline float total_from16(float v16) {  // uniform: sum over the wave, given per-row (16 lane) sums
+  v16 = dpp_add<0x142, 0xA>(v16);                // row_bcast15 into rows 1,3
+  v16 = dpp_add<0x143, 0xC>(v16);                // row_bcast31 into rows 2,3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v16), 63));
+}
+__device__ inline float wave_total(float v) { return total_from16(sum16_from8(sum8(v))); }
+__device__ inline float wave_sum(float v) { return wave_total(v); }
+
 
 // ---- host-side argument checks -------------------------------------------------------------
 inline int elem_size(int dtype) { return dtype == OCTIC_BF16 ? 2 : 4; }

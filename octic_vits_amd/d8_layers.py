@@ -177,14 +177,17 @@ class LayerNormD8(nn.Module):
         self.scaling = AffineD8(channels, bias=bias) if elementwise_affine else nn.Identity()
         self.eps = eps
 
-    def forward(self, xs, _out_dtype=None):
+    def forward(self, xs, _out_dtype=None, _with_resid=False):
         xp, c = as_packed(xs)
         out_dtype = _out_dtype or xp.dtype
         if isinstance(self.scaling, AffineD8):
             a, beta = self.scaling.alphas(), self.scaling.beta
         else:
             a, beta = (None,) * 5, None
-        return Octic(OF.LayerNormD8Fn.apply(xp, *a, beta, self.eps, c, out_dtype), c)
+        y, xres = OF.LayerNormD8Fn.apply(xp, *a, beta, self.eps, c, out_dtype)
+        # _with_resid: also hand back the stream to take the residual from (its cotangent is then folded into this
+        # node's backward kernel)
+        return (Octic(y, c), xres) if _with_resid else Octic(y, c)
 
 
 class MlpD8(nn.Module):
@@ -474,10 +477,13 @@ class AttentionD8(nn.Module):
 def _branch(norm, fn, xs_packed, c, rs, cs, out_dtype):
     """x + drop_path(cs * fn(norm(x))) with the tail fused into fn's last GEMM when fn supports it."""
     x = Octic(xs_packed, c)
-    try:
-        xn = norm(x, _out_dtype=out_dtype)
-    except TypeError:  # foreign norm layer
-        xn = norm(x)
+    if type(norm) is LayerNormD8:
+        xn, xs_packed = norm(x, _out_dtype=out_dtype, _with_resid=True)
+    else:
+        try:
+            xn = norm(x, _out_dtype=out_dtype)
+        except TypeError:  # foreign norm layer
+            xn = norm(x)
     try:
         return fn(xn, resid=xs_packed, rs=rs, cs=cs)
     except TypeError:  # foreign attention / mlp class: compose

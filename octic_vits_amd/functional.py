@@ -105,20 +105,28 @@ class GeluD8Function(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------- LayerNorm
 class LayerNormD8Fn(torch.autograd.Function):
+    """Returns (y, x): the second output is the input stream itself.  A block that takes its residual connection
+    from it gets the residual cotangent added inside the backward kernel (no separate accumulation pass)."""
+
     @staticmethod
     def forward(ctx, x, a1, a2, b1, b2, ae, beta, eps, c, out_dtype):
+        xin = x
         x = _c(x.float())
         alpha = None if a1 is None else [_c(t.float()) for t in (a1, a2, b1, b2, ae)]
         y, stats = ops.layernorm_fwd(x, alpha, None if beta is None else _c(beta.float()), eps, out_dtype, c)
         ctx.save_for_backward(x, stats, *(alpha or []))
         ctx.c, ctx.has_affine, ctx.has_beta = c, alpha is not None, beta is not None
-        return y
+        ctx.set_materialize_grads(False)
+        return y, xin.view_as(xin)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gres):
         x, stats, *alpha = ctx.saved_tensors
+        if g is None:
+            return (gres,) + (None,) * 9
         alpha = alpha if ctx.has_affine else None
-        dx, dal, dbeta = ops.layernorm_bwd(_c(g), x, stats, alpha, None, ctx.c, want_param_grads=ctx.has_affine)
+        dres = None if gres is None else _c(gres.float())
+        dx, dal, dbeta = ops.layernorm_bwd(_c(g), x, stats, alpha, dres, ctx.c, want_param_grads=ctx.has_affine)
         if dal is None:
             dal = [None] * 5
         return (dx, *dal, dbeta if ctx.has_beta else None, None, None, None)

@@ -76,6 +76,14 @@ timeit("ln_fwd f32->bf16", lambda: ops.layernorm_fwd(x32, alpha, beta, 1e-5, bf,
 y, stats = ops.layernorm_fwd(x32, alpha, beta, 1e-5, bf, c)
 g = rnd(B, T, 8 * c)
 timeit("ln_bwd (+finish)", lambda: ops.layernorm_bwd(g, x32, stats, alpha, None, c), M * 8 * c * 10)
+dres = rnd(B, T, 8 * c, dtype=f32)
+timeit("ln_bwd +dres (+finish)", lambda: ops.layernorm_bwd(g, x32, stats, alpha, dres, c), M * 8 * c * 14)
+wd, bd = rnd(8 * c, dtype=f32), rnd(8 * c, dtype=f32)
+yd, std = ops.dense_layernorm_fwd(x32, wd, bd, 1e-6, bf)
+timeit("dense_ln_fwd f32->bf16", lambda: ops.dense_layernorm_fwd(x32, wd, bd, 1e-6, bf), M * 8 * c * 6)
+timeit("dense_ln_bwd +dres (+finish)", lambda: ops.dense_layernorm_bwd(g, x32, wd, std, dres), M * 8 * c * 14)
+timeit("scale_residual_fwd", lambda: ops.scale_residual_fwd(x32, g, wd, None, T), M * 8 * c * 10)
+timeit("scale_residual_bwd (+finish)", lambda: ops.scale_residual_bwd(x32, g, wd, None, T), M * 8 * c * 8)
 h = rnd(B, T, 32 * c)
 hy = torch.empty_like(h)
 timeit("gelu_fwd", lambda: ops.gelu_fwd(ops.pview(h, 4 * c), ops.pview(hy, 4 * c), M, 4 * c, bf, h), 2 * h.numel() * 2)
