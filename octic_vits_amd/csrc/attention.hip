@@ -13,6 +13,7 @@
 //     the V^T fragments are fetched in the same order with ds_read_b64_tr_b16 from the row-major V image);
 //   * O^T keeps the query on the lane too, so the online-softmax rescale and the final 1/l are lane-local.
 // head_dim must be a multiple of 16 (<= 128).  Bound: MFMA/VALU mix, not HBM (q,k,v,o are 4 x 42 MB per call).
+#include <stdlib.h>
 #include "octic_common.hpp"
 
 namespace octic {
@@ -53,19 +54,168 @@ __device__ inline bf16x8 tr_frag(const char* img, int row_bytes, int key0, int c
 inline int attn_rsk(int hd) { return hd * 2 + 16; }                       // K image row bytes (odd # of 16-B slots)
 inline int attn_rsv(int dp) { int r = dp * 2; return ((r / 4) % 32 == 0) ? r + 64 : r; }   // V image row bytes
 
-// DT = ceil(hd / 32) d-tiles of the output, KS = hd / 16 k-steps of the score product
+// ---- work split ------------------------------------------------------------------------------------------------
+// The sequence is cut into nt = ceil(T/32) tiles.  A wave owns one tile of its own dimension (queries in the forward
+// and dq kernels, keys in the dkv kernel) and loops over all tiles of the other one.  Nine tiles (T = 257: 16x16
+// patches + cls) would need nine waves - three on one SIMD, which then sets the pace and caps every wave at 170
+// registers.  Instead eight waves (two per SIMD, 256 registers) own tiles 0-7 and share the ninth: each wave runs
+// it against its 1-2 tiles of the other dimension and the partial results are combined through LDS (the K/V images
+// are dead by then).
+constexpr int kAttnWaves = 8;
+inline int attn_waves(int nt) { return nt == kAttnWaves + 1 ? kAttnWaves : nt; }
+constexpr int kPartPad = 4;    // f32 row pad of the partial-result images (conflict-free 16-byte accesses)
+
+// One pass of the forward over key tiles kt0, kt0+kstep, ... < nt for query tile `qtile`; online softmax state
+// (m, l: per lane = per query, l still split between the half-waves) and O^T accumulators are updated in place.
+// lane (r, half) holds Q[query][16 ks + 8 half .. +7] = B operand of K Q^T
+template <int KS>
+__device__ __forceinline__ void load_rows8(bf16x8 (&f)[KS], const bf16* base, int64_t st, int tile, int T, int lane) {
+  const int r = lane & 31, half = lane >> 5;
+  const int i = tile * 32 + r;
+  const int ic = i < T ? i : T - 1;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) f[ks] = *(const bf16x8*)(base + (int64_t)ic * st + ks * 16 + half * 8);
+}
+
 template <int KS, int DT>
-__global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a, int rsk, int rsv) {
+__device__ __forceinline__ void fwd_pass(const AttnArgs& a, const char* Ks, const char* Vs, int rsk, int rsv,
+                                         const bf16x8 (&qf)[KS], int kt0, int kstep, int nt, int lane, float& m,
+                                         float& l, f32x16 (&ot)[DT]) {
+  const int T = a.T;
+  const int r = lane & 31, half = lane >> 5;
+  for (int kt = kt0; kt < nt; kt += kstep) {
+    f32x16 x;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 0.f;
+    const char* krow = Ks + (size_t)(kt * 32 + r) * rsk + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 kf = *(const bf16x8*)(krow + ks * 32);
+      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], x, 0, 0, 0);
+    }
+    // raw scores of query `qi` against keys kt*32 + acc_row(reg, half); the softmax scale (> 0) is applied inside
+    // the exponent's fma, the running maximum m is kept in the scaled log2 domain
+    if (kt == nt - 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (kt * 32 + acc_row(i, half) >= T) x[i] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(x[0], x[1]), x[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, x[i]), x[i + 1]);
+    mx = fmaxf(mx, x[15]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx * a.scale_log2);   // finite: every key tile has at least one real key
+    if (__builtin_amdgcn_ballot_w64(m_new > m)) {      // rescale only when some query's maximum moved
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+      m = m_new;
+    }
+    float ps[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ps[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], a.scale_log2, -m));
+      sum += ps[i];
+    }
+    l += sum;
+    const bf16x8 pb0 = pack8(ps), pb1 = pack8(ps + 8);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const bf16x8 v0 = tr_frag(Vs, rsv, kt * 32, d * 32, lane);
+      ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb0, ot[d], 0, 0, 0);
+      const bf16x8 v1 = tr_frag(Vs, rsv, kt * 32 + 16, d * 32, lane);
+      ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb1, ot[d], 0, 0, 0);
+    }
+  }
+}
+
+// accumulator tile set [DT][16] (row index = d, lane = r) -> f32 image part[r][d] of one wave
+template <int DT>
+__device__ __forceinline__ void store_partial(float* part, const f32x16 (&acc)[DT], int lane, int nrows) {
+  const int r = lane & 31, half = lane >> 5;
+  if (r >= nrows) return;
+  float* row = part + (size_t)r * (DT * 32 + kPartPad);
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+      *(f32x4*)(row + d * 32 + 8 * k4 + 4 * half) =
+          f32x4{acc[d][4 * k4], acc[d][4 * k4 + 1], acc[d][4 * k4 + 2], acc[d][4 * k4 + 3]};
+}
+
+// Sum the waves' partial images (optionally weighted per wave and row) and store rows [row0, T) as bf16.
+// wgt: [waves][32] weights or nullptr; rowscale: [32] final factor per row or nullptr; scale: uniform factor.
+template <int DT>
+__device__ __forceinline__ void combine_store(const float* parts, int waves, const float* wgt, const float* rowscale,
+                                              float scale, bf16* out, int64_t st, int row0, int T, int hd, int tid,
+                                              int nthr) {
+  const int DC = DT * 32 + kPartPad;
+  const int c8 = hd / 8;
+  const int nrows = T - row0 < 32 ? T - row0 : 32;
+  for (int q = tid; q < nrows * c8; q += nthr) {
+    const int r = q / c8, c = q - r * c8;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    for (int w = 0; w < waves; ++w) {
+      const float* p = parts + ((size_t)w * 32 + r) * DC + c * 8;
+      const float g = wgt ? wgt[w * 32 + r] : 1.f;
+      s0 += *(const f32x4*)p * g;
+      s1 += *(const f32x4*)(p + 4) * g;
+    }
+    const float f = scale * (rowscale ? rowscale[r] : 1.f);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = (bf16)(s0[j] * f);
+      o[4 + j] = (bf16)(s1[j] * f);
+    }
+    *(bf16x8*)(out + (int64_t)(row0 + r) * st + c * 8) = o;
+  }
+}
+
+// accumulator tile set -> bf16 rows of the output (lane r = row `row`, 4 consecutive columns per store)
+template <int DT>
+__device__ __forceinline__ void store_rows(bf16* row, const f32x16 (&acc)[DT], float f, int hd, int half) {
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int d0 = d * 32 + 8 * k4 + 4 * half;
+      if (d0 < hd) {
+        bf16x4 ov = {(bf16)(acc[d][4 * k4] * f), (bf16)(acc[d][4 * k4 + 1] * f), (bf16)(acc[d][4 * k4 + 2] * f),
+                     (bf16)(acc[d][4 * k4 + 3] * f)};
+        *(bf16x4*)(row + d0) = ov;
+      }
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[DT]) {
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[d][i] = 0.f;
+}
+
+// DT = ceil(hd / 32) d-tiles of the output, KS = hd / 16 k-steps of the score product
+template <int KS, int DT, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int rsv, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = a.T, hd = a.hd;
-  const int nw = blockDim.x >> 6;            // waves = key tiles
-  const int Tp = nw * 32;
+  const int W = blockDim.x >> 6;             // waves: one query tile each, + a shared one if nt == W + 1
+  const int Tp = nt * 32;
   char* Ks = smem;
   char* Vs = smem + (size_t)Tp * rsk;
   const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
   const bf16* qb = a.q + b * a.sB + h * a.sH;
   const bf16* kb = a.k + b * a.sB + h * a.sH;
   const bf16* vb = a.v + b * a.sB + h * a.sH;
+  bf16* ob = a.o + b * a.oB + h * a.oH;
+  float* lseb = a.lse ? a.lse + ((int64_t)b * a.H + h) * T : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
 
@@ -83,97 +233,77 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a, int rsk, int 
     if (t < T && c < kc) v = *(const u32x4*)(vb + (int64_t)t * a.sT + c * 8);
     *(u32x4*)(Vs + (size_t)t * rsv + c * 16) = v;
   }
-  // ---- this wave's queries: lane (r, half) holds Q[query][16 ks + 8 half .. +7] = B operand of K Q^T
-  const int qi = wid * 32 + r;
-  const int qc = qi < T ? qi : T - 1;
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qb + (int64_t)qc * a.sT + ks * 16 + half * 8);
+  bf16x8 qf[KS], qfs[KS];                       // own query tile; the shared tile's rows are fetched up front too
+  load_rows8<KS>(qf, qb, a.sT, wid, T, lane);
+  if (nt != W) load_rows8<KS>(qfs, qb, a.sT, W, T, lane);
   __syncthreads();
 
   f32x16 ot[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
+  zero_acc<DT>(ot);
   float m = -INFINITY, l = 0.f;
-
-  for (int kt = 0; kt < nw; ++kt) {
-    f32x16 x;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = 0.f;
-    const char* krow = Ks + (size_t)(kt * 32 + r) * rsk + half * 16;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 kf = *(const bf16x8*)(krow + ks * 32);
-      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], x, 0, 0, 0);
-    }
-    // scores of query `qi` against keys kt*32 + acc_row(reg, half)
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float s = x[i] * a.scale_log2;
-      if (kt == nw - 1 && kt * 32 + acc_row(i, half) >= T) s = -INFINITY;
-      x[i] = s;
-      mx = fmaxf(mx, s);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);          // finite: key 0 of every tile row exists for tile 0
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    float ps[16];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      ps[i] = __builtin_amdgcn_exp2f(x[i] - m_new);
-      sum += ps[i];
-    }
-    l = l * alpha + sum;
-    m = m_new;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
-    const bf16x8 pb0 = pack8(ps), pb1 = pack8(ps + 8);
-#pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      const bf16x8 v0 = tr_frag(Vs, rsv, kt * 32, d * 32, lane);
-      ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb0, ot[d], 0, 0, 0);
-      const bf16x8 v1 = tr_frag(Vs, rsv, kt * 32 + 16, d * 32, lane);
-      ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb1, ot[d], 0, 0, 0);
-    }
-  }
+  fwd_pass<KS, DT>(a, Ks, Vs, rsk, rsv, qf, 0, 1, nt, lane, m, l, ot);
   l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
-  if (qi < T) {
-    if (half == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * T + qi] = m + log2f(l);
-    bf16* orow = a.o + b * a.oB + h * a.oH + (int64_t)qi * a.oT;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int d0 = d * 32 + 8 * k4 + 4 * half;
-        if (d0 < hd) {
-          bf16x4 ov = {(bf16)(ot[d][4 * k4] * inv), (bf16)(ot[d][4 * k4 + 1] * inv), (bf16)(ot[d][4 * k4 + 2] * inv),
-                       (bf16)(ot[d][4 * k4 + 3] * inv)};
-          *(bf16x4*)(orow + d0) = ov;
-        }
-      }
+  {
+    const int qi = wid * 32 + r;
+    if (qi < T) {
+      if (half == 0 && lseb) lseb[qi] = m + log2f(l);
+      store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half);
+    }
   }
+  if (nt == W) return;
+
+  // ---- the shared last query tile: this wave's share of the keys, then a log-sum-exp merge of the W partials
+  zero_acc<DT>(ot);
+  m = -INFINITY;
+  l = 0.f;
+  fwd_pass<KS, DT>(a, Ks, Vs, rsk, rsv, qfs, wid, W, nt, lane, m, l, ot);
+  l += __shfl_xor(l, 32, 64);
+  __syncthreads();                                   // every wave is done with the K / V images
+  const int nrows = T - W * 32;                      // real queries of the shared tile
+  float* parts = (float*)smem;                       // [W][32][DT*32 + pad]
+  float* ml = parts + (size_t)W * 32 * (DT * 32 + kPartPad);   // m[W][32] | weight[W][32] | 1/L[32]
+  store_partial<DT>(parts + (size_t)wid * 32 * (DT * 32 + kPartPad), ot, lane, nrows);
+  if (half == 0) {
+    ml[wid * 32 + r] = m;
+    ml[(W + wid) * 32 + r] = l;
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    float M = -INFINITY;
+    for (int w = 0; w < W; ++w) M = fmaxf(M, ml[w * 32 + tid]);
+    float L = 0.f;
+    for (int w = 0; w < W; ++w) {
+      const float g = __builtin_amdgcn_exp2f(ml[w * 32 + tid] - M);
+      L += ml[(W + w) * 32 + tid] * g;
+      ml[(W + w) * 32 + tid] = g;                    // l is consumed: the slot now holds the wave's weight
+    }
+    ml[2 * W * 32 + tid] = 1.0f / L;
+    const int qi = W * 32 + tid;
+    if (qi < T && lseb) lseb[qi] = M + log2f(L);
+  }
+  __syncthreads();
+  combine_store<DT>(parts, W, ml + W * 32, ml + 2 * W * 32, 1.0f, ob, a.oT, W * 32, T, hd, tid, blockDim.x);
 }
 
 template <int KS, int DT>
 static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
-  const int nw = (a.T + 31) / 32;
+  // the forward is light on registers: one wave per tile even for nine tiles (three waves on one SIMD hide the
+  // softmax latency better than the shared-tile split does: 78 vs 85 us at T = 257); the kernel supports both
+  const int nt = (a.T + 31) / 32, W = getenv("OCTIC_ATTN_FWD_SHARED") ? attn_waves(nt) : nt;
   const int rsk = attn_rsk(a.hd), rsv = attn_rsv(DT * 32);
-  const size_t smem = (size_t)nw * 32 * (rsk + rsv);
+  size_t smem = (size_t)nt * 32 * (rsk + rsv);
+  const size_t comb = ((size_t)W * 32 * (DT * 32 + kPartPad) + (2 * W + 1) * 32) * sizeof(float);
+  if (nt != W && comb > smem) smem = comb;
   if (smem > 160 * 1024) return OCTIC_ESHAPE;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, DT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, DT, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     done = true;
   }
-  attn_fwd_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem, s>>>(a, rsk, rsv);
+  if (W <= 8) attn_fwd_kernel<KS, DT, 512><<<(int)(B * a.H), W * 64, smem, s>>>(a, rsk, rsv, nt);
+  else attn_fwd_kernel<KS, DT, 640><<<(int)(B * a.H), W * 64, smem, s>>>(a, rsk, rsv, nt);
   return launch_status();
 }
 
@@ -181,7 +311,7 @@ static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
 // =================================================================================================
 // Backward.  P is recomputed from q, k and the saved log-sum-exp (no T x T tensor is ever stored).
 //   dV = P^T dO ;  dP = dO V^T ;  dS = P * (dP - delta),  delta[q] = sum_d dO[q,d] O[q,d] ;  dQ = scale dS K ;  dK = scale dS^T Q
-// Two kernels so that no gradient needs a cross-wave reduction:
+// Two kernels so that no gradient needs a cross-wave reduction (beyond the shared ninth tile):
 //   attn_bwd_dq_kernel : wave owns 32 QUERIES (same swapped layout as the forward); K and V rows in LDS.
 //   attn_bwd_dkv_kernel: wave owns 32 KEYS; Q and dO rows (+ lse, delta) in LDS; un-swapped scores X'[q][key]
 //                        keep the key on the lane, so dK^T and dV^T accumulate lane-locally.
@@ -204,45 +334,45 @@ __device__ inline void stage_rows(char* img, int rs, const bf16* src, int64_t st
   }
 }
 
-template <int KS, int DT>
-__global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int T = a.T, hd = a.hd;
-  const int nw = blockDim.x >> 6, Tp = nw * 32;
-  char* Ks = smem;
-  char* Vs = smem + (size_t)Tp * rs;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
-  const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
-  stage_rows(Ks, rs, a.k + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
-  stage_rows(Vs, rs, a.v + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
-
-  const int qi = wid * 32 + r;
-  const int qc = qi < T ? qi : T - 1;
+// dQ^T of query tile `qtile` accumulated over key tiles kt0, kt0+kstep, ...; also writes delta for the tile if asked.
+// per-query operands of the dq kernel for one query tile: Q and dO fragments, log-sum-exp, delta = <dO, O>
+template <int KS>
+struct DqRows {
   bf16x8 qf[KS], dof[KS];
+  float lse, delta;
+};
+template <int KS>
+__device__ __forceinline__ void load_dq_rows(DqRows<KS>& R, const AttnBwdArgs& a, int64_t in_off, int64_t o_off,
+                                             int64_t stat_off, int qtile, int lane, bool write_delta) {
+  const int T = a.T;
+  const int r = lane & 31, half = lane >> 5;
+  const int qi = qtile * 32 + r;
+  const int qc = qi < T ? qi : T - 1;
   float delta = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = *(const bf16x8*)(a.q + in_off + (int64_t)qc * a.sT + ks * 16 + half * 8);
-    dof[ks] = *(const bf16x8*)(a.dout + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
+    R.qf[ks] = *(const bf16x8*)(a.q + in_off + (int64_t)qc * a.sT + ks * 16 + half * 8);
+    R.dof[ks] = *(const bf16x8*)(a.dout + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
     const bf16x8 of = *(const bf16x8*)(a.o + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[j];
+    for (int j = 0; j < 8; ++j) delta += (float)R.dof[ks][j] * (float)of[j];
   }
   delta += __shfl_xor(delta, 32, 64);
-  const int64_t stat = ((int64_t)b * a.H + h) * T + qc;
-  const float lse = a.lse[stat];
-  if (qi < T && half == 0) a.delta[stat] = delta;
-  __syncthreads();
+  R.delta = delta;
+  R.lse = a.lse[stat_off + qc];
+  if (write_delta && qi < T && half == 0) a.delta[stat_off + qc] = delta;
+}
 
-  f32x16 dqt[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dqt[d][i] = 0.f;
-
-  for (int kt = 0; kt < nw; ++kt) {
+template <int KS, int DT>
+__device__ __forceinline__ void dq_pass(const AttnBwdArgs& a, const char* Ks, const char* Vs, int rs,
+                                        const DqRows<KS>& R, int kt0, int kstep, int nt, int lane,
+                                        f32x16 (&dqt)[DT]) {
+  const int T = a.T;
+  const int r = lane & 31, half = lane >> 5;
+  const float lse = R.lse, delta = R.delta;
+  const bf16x8 (&qf)[KS] = R.qf;
+  const bf16x8 (&dof)[KS] = R.dof;
+  for (int kt = kt0; kt < nt; kt += kstep) {
     f32x16 x, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { x[i] = 0.f; dp[i] = 0.f; }
@@ -257,7 +387,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float p = __builtin_amdgcn_exp2f(x[i] * a.scale_log2 - lse);
-      if (kt == nw - 1 && kt * 32 + acc_row(i, half) >= T) p = 0.f;
+      if (kt == nt - 1 && kt * 32 + acc_row(i, half) >= T) p = 0.f;
       ds[i] = p * (dp[i] - delta);
     }
     const bf16x8 b0 = pack8(ds), b1 = pack8(ds + 8);
@@ -267,44 +397,52 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs)
       dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, rs, kt * 32 + 16, d * 32, lane), b1, dqt[d], 0, 0, 0);
     }
   }
-  if (qi < T) {
-    bf16* row = a.dq + b * a.gB + h * a.gH + (int64_t)qi * a.gT;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int d0 = d * 32 + 8 * k4 + 4 * half;
-        if (d0 < hd) {
-          bf16x4 ov = {(bf16)(dqt[d][4 * k4] * a.scale), (bf16)(dqt[d][4 * k4 + 1] * a.scale),
-                       (bf16)(dqt[d][4 * k4 + 2] * a.scale), (bf16)(dqt[d][4 * k4 + 3] * a.scale)};
-          *(bf16x4*)(row + d0) = ov;
-        }
-      }
-  }
 }
 
-template <int KS, int DT>
-__global__ __launch_bounds__(640) void attn_bwd_dkv_kernel(AttnBwdArgs a, int rs) {
+template <int KS, int DT, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = a.T, hd = a.hd;
-  const int nw = blockDim.x >> 6, Tp = nw * 32;
-  char* Qs = smem;
-  char* Ds = smem + (size_t)Tp * rs;
-  float* lse_s = (float*)(smem + (size_t)2 * Tp * rs);
-  float* del_s = lse_s + Tp;
+  const int W = blockDim.x >> 6, Tp = nt * 32;
+  char* Ks = smem;
+  char* Vs = smem + (size_t)Tp * rs;
   const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
   const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH;
+  const int64_t stat_off = ((int64_t)b * a.H + h) * T;
+  bf16* dqb = a.dq + b * a.gB + h * a.gH;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
-  stage_rows(Qs, rs, a.q + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
-  stage_rows(Ds, rs, a.dout + o_off, a.oT, T, Tp, hd / 8, tid, blockDim.x);
-  for (int t = tid; t < Tp; t += blockDim.x) {
-    const int64_t stat = ((int64_t)b * a.H + h) * T + t;
-    lse_s[t] = t < T ? a.lse[stat] : INFINITY;    // padded queries: P = exp2(x - inf) = 0
-    del_s[t] = t < T ? a.delta[stat] : 0.f;
-  }
+  stage_rows(Ks, rs, a.k + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
+  stage_rows(Vs, rs, a.v + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
+  DqRows<KS> mine, shared;                          // the shared tile's rows are fetched up front too
+  load_dq_rows<KS>(mine, a, in_off, o_off, stat_off, wid, lane, true);
+  if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane, wid == 0);
+  __syncthreads();
+
+  f32x16 dqt[DT];
+  zero_acc<DT>(dqt);
+  dq_pass<KS, DT>(a, Ks, Vs, rs, mine, 0, 1, nt, lane, dqt);
+  if (wid * 32 + r < T) store_rows<DT>(dqb + (int64_t)(wid * 32 + r) * a.gT, dqt, a.scale, hd, half);
+  if (nt == W) return;
+
+  zero_acc<DT>(dqt);
+  dq_pass<KS, DT>(a, Ks, Vs, rs, shared, wid, W, nt, lane, dqt);
+  __syncthreads();
+  float* parts = (float*)smem;
+  store_partial<DT>(parts + (size_t)wid * 32 * (DT * 32 + kPartPad), dqt, lane, T - W * 32);
+  __syncthreads();
+  combine_store<DT>(parts, W, nullptr, nullptr, a.scale, dqb, a.gT, W * 32, T, hd, tid, blockDim.x);
+}
+
+// dK^T, dV^T of key tile `ktile` accumulated over query tiles qt0, qt0+qstep, ...
+template <int KS, int DT>
+__device__ __forceinline__ void dkv_pass(const AttnBwdArgs& a, const char* Qs, const char* Ds, const float* lse_s,
+                                         const float* del_s, int rs, int64_t in_off, int ktile, int qt0, int qstep,
+                                         int nt, int lane, f32x16 (&dkt)[DT], f32x16 (&dvt)[DT]) {
+  const int T = a.T;
+  const int r = lane & 31, half = lane >> 5;
   // this wave's keys: lane (r, half) holds K[key][16 ks + 8 half ..] and V[key][..] = B operands (key on the lane)
-  const int ki = wid * 32 + r;
+  const int ki = ktile * 32 + r;
   const int kcl = ki < T ? ki : T - 1;
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -312,15 +450,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_kernel(AttnBwdArgs a, int rs
     kf[ks] = *(const bf16x8*)(a.k + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
     vf[ks] = *(const bf16x8*)(a.v + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
   }
-  __syncthreads();
-
-  f32x16 dkt[DT], dvt[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dkt[d][i] = 0.f; dvt[d][i] = 0.f; }
-
-  for (int qt = 0; qt < nw; ++qt) {
+  for (int qt = qt0; qt < nt; qt += qstep) {
     f32x16 x, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { x[i] = 0.f; dp[i] = 0.f; }
@@ -353,45 +483,90 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_kernel(AttnBwdArgs a, int rs
       dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, rs, qt * 32 + 16, d * 32, lane), s1, dkt[d], 0, 0, 0);
     }
   }
-  if (ki < T) {
-    bf16* krow = a.dk + b * a.gB + h * a.gH + (int64_t)ki * a.gT;
-    bf16* vrow = a.dv + b * a.gB + h * a.gH + (int64_t)ki * a.gT;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int d0 = d * 32 + 8 * k4 + 4 * half;
-        if (d0 < hd) {
-          bf16x4 kv = {(bf16)(dkt[d][4 * k4] * a.scale), (bf16)(dkt[d][4 * k4 + 1] * a.scale),
-                       (bf16)(dkt[d][4 * k4 + 2] * a.scale), (bf16)(dkt[d][4 * k4 + 3] * a.scale)};
-          bf16x4 vv = {(bf16)dvt[d][4 * k4], (bf16)dvt[d][4 * k4 + 1], (bf16)dvt[d][4 * k4 + 2], (bf16)dvt[d][4 * k4 + 3]};
-          *(bf16x4*)(krow + d0) = kv;
-          *(bf16x4*)(vrow + d0) = vv;
-        }
-      }
+}
+
+template <int KS, int DT, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int rs, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.T, hd = a.hd;
+  const int W = blockDim.x >> 6, Tp = nt * 32;
+  char* Qs = smem;
+  char* Ds = smem + (size_t)Tp * rs;
+  float* lse_s = (float*)(smem + (size_t)2 * Tp * rs);
+  float* del_s = lse_s + Tp;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH;
+  bf16* dkb = a.dk + b * a.gB + h * a.gH;
+  bf16* dvb = a.dv + b * a.gB + h * a.gH;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  stage_rows(Qs, rs, a.q + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
+  stage_rows(Ds, rs, a.dout + o_off, a.oT, T, Tp, hd / 8, tid, blockDim.x);
+  for (int t = tid; t < Tp; t += blockDim.x) {
+    const int64_t stat = ((int64_t)b * a.H + h) * T + t;
+    lse_s[t] = t < T ? a.lse[stat] : INFINITY;    // padded queries: P = exp2(x - inf) = 0
+    del_s[t] = t < T ? a.delta[stat] : 0.f;
   }
+  __syncthreads();
+
+  f32x16 dkt[DT], dvt[DT];
+  zero_acc<DT>(dkt);
+  zero_acc<DT>(dvt);
+  dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, in_off, wid, 0, 1, nt, lane, dkt, dvt);
+  if (wid * 32 + r < T) {
+    store_rows<DT>(dkb + (int64_t)(wid * 32 + r) * a.gT, dkt, a.scale, hd, half);
+    store_rows<DT>(dvb + (int64_t)(wid * 32 + r) * a.gT, dvt, 1.0f, hd, half);
+  }
+  if (nt == W) return;
+
+  zero_acc<DT>(dkt);
+  zero_acc<DT>(dvt);
+  dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, in_off, W, wid, W, nt, lane, dkt, dvt);
+  __syncthreads();
+  float* parts = (float*)smem;
+  float* mine = parts + (size_t)wid * 32 * (DT * 32 + kPartPad);
+  store_partial<DT>(mine, dkt, lane, T - W * 32);
+  __syncthreads();
+  combine_store<DT>(parts, W, nullptr, nullptr, a.scale, dkb, a.gT, W * 32, T, hd, tid, blockDim.x);
+  __syncthreads();
+  store_partial<DT>(mine, dvt, lane, T - W * 32);
+  __syncthreads();
+  combine_store<DT>(parts, W, nullptr, nullptr, 1.0f, dvb, a.gT, W * 32, T, hd, tid, blockDim.x);
 }
 
 template <int KS, int DT>
 static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream_t s) {
-  const int nw = (a.T + 31) / 32;
+  // dq is light enough for one wave per tile (105 vs 108 us); dkv (two accumulator sets) needs the 256-register
+  // budget of the eight-wave split (105 vs 156 us with spills)
+  const int nt = (a.T + 31) / 32, W = attn_waves(nt), Wq = getenv("OCTIC_ATTN_DQ_SHARED") ? W : nt;
   // the row images are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16); rows are padded so the
   // b128 reads are conflict-free, the transposed reads then see at most 2-way conflicts.  The tr fragments reach
   // DT*32 columns, so rows must hold that many (the pad columns meet zero accumulator columns / are discarded).
   const int cols = DT * 32 > a.hd ? DT * 32 : a.hd;
   const int rs = cols * 2 + 16;
-  const size_t smem_dq = (size_t)2 * nw * 32 * rs;
-  const size_t smem_kv = smem_dq + (size_t)2 * nw * 32 * sizeof(float);
+  size_t smem_dq = (size_t)2 * nt * 32 * rs;
+  size_t smem_kv = smem_dq + (size_t)2 * nt * 32 * sizeof(float);
+  const size_t comb = (size_t)W * 32 * (DT * 32 + kPartPad) * sizeof(float);
+  if (nt != W && comb > smem_dq) smem_dq = comb;
+  if (nt != W && comb > smem_kv) smem_kv = comb;
   if (smem_kv > 160 * 1024) return OCTIC_ESHAPE;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<KS, DT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KS, DT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<KS, DT, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KS, DT, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     done = true;
   }
-  if (phase & 1) attn_bwd_dq_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_dq, s>>>(a, rs);
-  if (phase & 2) attn_bwd_dkv_kernel<KS, DT><<<(int)(B * a.H), nw * 64, smem_kv, s>>>(a, rs);
+  if (phase & 1) {
+    if (Wq <= 8) attn_bwd_dq_kernel<KS, DT, 512><<<(int)(B * a.H), Wq * 64, smem_dq, s>>>(a, rs, nt);
+    else attn_bwd_dq_kernel<KS, DT, 640><<<(int)(B * a.H), Wq * 64, smem_dq, s>>>(a, rs, nt);
+  }
+  if (phase & 2) {
+    if (W <= 8) attn_bwd_dkv_kernel<KS, DT, 512><<<(int)(B * a.H), W * 64, smem_kv, s>>>(a, rs, nt);
+    else attn_bwd_dkv_kernel<KS, DT, 640><<<(int)(B * a.H), W * 64, smem_kv, s>>>(a, rs, nt);
+  }
   return launch_status();
 }
 

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octic_vits_amd import ops  # noqa: E402
 
 dev = "cuda"
-B, T, c, H = 64, 257, 160, 16
+B, T, c, H = 64, int(os.environ.get("OCTIC_BENCH_T", "257")), 160, 16
 M = B * T
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 bf, f32 = torch.bfloat16, torch.float32
