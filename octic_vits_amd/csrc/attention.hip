@@ -536,9 +536,9 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
 
 template <int KS, int DT>
 static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream_t s) {
-  // dq is light enough for one wave per tile (105 vs 108 us); dkv (two accumulator sets) needs the 256-register
-  // budget of the eight-wave split (105 vs 156 us with spills)
-  const int nt = (a.T + 31) / 32, W = attn_waves(nt), Wq = getenv("OCTIC_ATTN_DQ_SHARED") ? W : nt;
+  // dkv (two accumulator sets) needs the 256-register budget of the eight-wave split (105 vs 156 us with spills);
+  // dq runs the same either way (~106 us) and follows it
+  const int nt = (a.T + 31) / 32, W = attn_waves(nt), Wq = getenv("OCTIC_ATTN_DQ_PER_TILE") ? nt : W;
   // the row images are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16); rows are padded so the
   // b128 reads are conflict-free, the transposed reads then see at most 2-way conflicts.  The tr fragments reach
   // DT*32 columns, so rows must hold that many (the pad columns meet zero accumulator columns / are discarded).

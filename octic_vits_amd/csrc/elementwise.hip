@@ -141,14 +141,20 @@ struct HeadPtrs {
   char* p[3];
 };
 
-// Per-lane constants of one head-side access slot: the lane moves V elements of token r at head-vector
-// position e; their packed column is col = a + s*cs + h*ch (see the kernel comment).
+// Per-lane constants of one head-side access slot.  A slot is ONE 16-byte access of the heads array = NP pieces of
+// V elements of token r starting at head-vector position e; piece p sits at packed column
+// lds[p] + mult[p] * (s*c + h*w) of the LDS tile (mult = 2 inside the two-dimensional irrep's rows).
+template <int NP>
 struct HeadSlot {
-  int lds;   // element offset inside the LDS tile for (s,h) = (0,0):  r*row_elems + a
-  int cs;    // column stride per s
-  int ch;    // column stride per head
-  int glb;   // element offset inside the (s,h) run of the heads array: r*hd + e
+  int lds[NP];   // element offset inside the LDS tile for (s,h) = (0,0), or -1 beyond the run
+  int mult[NP];
+  int glb;       // element offset inside the (s,h) run of the heads array: r*hd + e
 };
+template <int PB> struct Piece;
+template <> struct Piece<2> { typedef unsigned short type; };
+template <> struct Piece<4> { typedef unsigned int type; };
+template <> struct Piece<8> { typedef uint2 type; };
+template <> struct Piece<16> { typedef u32x4 type; };
 
 template <typename T, int V, int DIR, int SLOTS>
 __global__ __launch_bounds__(256) void heads_permute_kernel(View v, HeadPtrs heads, int64_t B, int64_t T_, int H, int c,
@@ -162,6 +168,7 @@ __global__ __launch_bounds__(256) void heads_permute_kernel(View v, HeadPtrs hea
   const int64_t t0 = (int64_t)(blockIdx.x - b * tiles_per_b) * TT;
   const int nt = (int)((T_ - t0) < TT ? (T_ - t0) : TT);
   constexpr int EPC = 16 / (int)sizeof(T);
+  const int row_stride = row_elems;
   const int cpr = row_elems / EPC;  // 16-byte chunks per token row
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 
@@ -179,52 +186,64 @@ __global__ __launch_bounds__(256) void heads_permute_kernel(View v, HeadPtrs hea
       } else {
         gp = (T*)v.p[4] + m * v.ld[4] + (e - 4 * cv);
       }
-      u32x4* lp = (u32x4*)(tile + (size_t)r * row_elems + e);
+      u32x4* lp = (u32x4*)(tile + (size_t)r * row_stride + e);
       if (load) *lp = *(const u32x4*)gp;
       else *(u32x4*)gp = *lp;
     }
   };
 
   // head side: for a fixed (s,h) the TT head vectors are ONE contiguous run of TT*hd elements.  Slot k of a lane
-  // covers run element (lane + 64k)*V; everything that does not depend on (s,h) is computed once here.
-  HeadSlot sl[SLOTS];
+  // is the access at run element (lane + 64k)*SE; it is gathered from / scattered to NP pieces of V
+  // elements in the LDS tile (V divides w, so a piece never straddles an irrep block; hd = 8w is a multiple of EPC
+  // whenever V*NP = EPC, so a slot never straddles a token).  Everything that does not depend on (s,h) is computed
+  // once here.
+  constexpr int PB = V * (int)sizeof(T);     // piece bytes
+  constexpr int NP = DIR == 1 ? 16 / PB : 1; // pieces per head-side access: a 16-byte gather pays off when scattering
+                                             // INTO the tile (heads -> view: 105 -> 91 us) but not when reading it
+                                             // (view -> heads: 62 us with single pieces, 79 with gathers)
+  constexpr int SE = NP * V;                 // elements per head-side access
+  typedef typename Piece<NP * PB>::type slot_t;
+  typedef typename Piece<PB>::type piece_t;
+  HeadSlot<NP> sl[SLOTS];
   const int run = nt * hd;  // valid elements of the run (last tile of a sample may be short)
 #pragma unroll
   for (int k = 0; k < SLOTS; ++k) {
-    const int idx = (lane + 64 * k) * V;
-    const int r = idx / hd, e = idx - r * hd;
-    int a, cs, ch;
-    if (e < 4 * w) {
-      const int g = e / w;
-      a = g * (n_s * c) + (e - g * w); cs = c; ch = w;
-    } else {
-      const int rr = (e - 4 * w) / (2 * w);
-      a = 4 * n_s * c + rr * (2 * n_s * c) + (e - 4 * w - rr * 2 * w); cs = 2 * c; ch = 2 * w;
+    const int idx = (lane + 64 * k) * SE;
+    sl[k].glb = idx < run ? idx : -1;
+#pragma unroll
+    for (int pz = 0; pz < NP; ++pz) {
+      const int id = idx + pz * V;
+      const int r = id / hd, e = id - r * hd;
+      int a, mult;
+      if (e < 4 * w) {
+        const int g = e / w;
+        a = g * (n_s * c) + (e - g * w); mult = 1;
+      } else {
+        const int rr = (e - 4 * w) / (2 * w);
+        a = 4 * n_s * c + rr * (2 * n_s * c) + (e - 4 * w - rr * 2 * w); mult = 2;
+      }
+      sl[k].lds[pz] = r * row_stride + a;
+      sl[k].mult[pz] = mult;
     }
-    sl[k].lds = idx < run ? r * row_elems + a : -1;
-    sl[k].cs = cs; sl[k].ch = ch; sl[k].glb = idx;
   }
   auto head_phase = [&](bool to_heads) {
 #pragma unroll 4
     for (int sh = wid; sh < n_s * H; sh += 4) {      // one wave per (s, head)
       const int s = sh / H, h = sh - s * H;
       T* gbase = (T*)heads.p[s] + ((b * H + h) * T_ + t0) * hd;
+      const int col = s * c + h * w;
 #pragma unroll
       for (int k = 0; k < SLOTS; ++k) {
-        if (sl[k].lds >= 0) {
-          T* lp = tile + sl[k].lds + s * sl[k].cs + h * sl[k].ch;
-          T* gp = gbase + sl[k].glb;
-          if (V * sizeof(T) == 4) {
-            if (to_heads) *(unsigned*)gp = *(const unsigned*)lp; else *(unsigned*)lp = *(const unsigned*)gp;
-          } else if (V * sizeof(T) == 8) {
-            if (to_heads) *(uint2*)gp = *(const uint2*)lp; else *(uint2*)lp = *(const uint2*)gp;
-          } else if (V * sizeof(T) == 16) {
-            if (to_heads) *(u32x4*)gp = *(const u32x4*)lp; else *(u32x4*)lp = *(const u32x4*)gp;
-          } else {
+        if (sl[k].glb >= 0) {
+          union { slot_t v; piece_t pc[NP]; } u;
+          if (to_heads) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-              if (to_heads) gp[i] = lp[i]; else lp[i] = gp[i];
-            }
+            for (int pz = 0; pz < NP; ++pz) u.pc[pz] = *(const piece_t*)(tile + sl[k].lds[pz] + sl[k].mult[pz] * col);
+            *(slot_t*)(gbase + sl[k].glb) = u.v;
+          } else {
+            u.v = *(const slot_t*)(gbase + sl[k].glb);
+#pragma unroll
+            for (int pz = 0; pz < NP; ++pz) *(piece_t*)(tile + sl[k].lds[pz] + sl[k].mult[pz] * col) = u.pc[pz];
           }
         }
       }
@@ -461,7 +480,8 @@ static int heads_launch(View vv, HeadPtrs hp, int64_t B, int64_t T_, int H, int 
   if (TT * row_bytes > 160 * 1024) return OCTIC_ESHAPE;
   const size_t smem = TT * row_bytes;
   const int grid = (int)(B * ((T_ + TT - 1) / TT));
-  const int slots = (TT * hd / V + 63) / 64;
+  const int se = DIR == 1 ? 16 / (int)sizeof(T) : V;                // elements per head-side access (see the kernel)
+  const int slots = (TT * hd / se + 63) / 64;
 #define OCTIC_HEADS_LAUNCH(SL)                                                                                          \
   do {                                                                                                                  \
     if (smem > 64 * 1024)                                                                                               \
@@ -492,8 +512,10 @@ static int heads_dispatch(const octic_view* v, void* const heads[3], int64_t B, 
   const int vmax = 16 / (int)sizeof(T);
   int V = 1;
   while (V * 2 <= vmax && (w % (V * 2)) == 0) V *= 2;
+  if constexpr (sizeof(T) == 2) {
+    if (V == 8) return heads_launch<T, 8, DIR>(vv, hp, B, T_, H, c, n_s, s);
+  }
   switch (V) {
-    case 8: return heads_launch<T, 8, DIR>(vv, hp, B, T_, H, c, n_s, s);
     case 4: return heads_launch<T, 4, DIR>(vv, hp, B, T_, H, c, n_s, s);
     case 2: return heads_launch<T, 2, DIR>(vv, hp, B, T_, H, c, n_s, s);
     default: return heads_launch<T, 1, DIR>(vv, hp, B, T_, H, c, n_s, s);
