@@ -10,6 +10,7 @@
 // [N,K] (nn.Linear) layout.  The row range is split over `splits` workgroup sets writing f32 slabs;
 // the finish kernel sums the slabs in a fixed order (bitwise reproducible), applies the layer-scale
 // chain rule (see octic_hip.h) and writes dW / dcs / dbias.
+#include <stdlib.h>
 #include "octic_common.hpp"
 
 namespace octic {
@@ -23,14 +24,14 @@ struct WgGroup {
   int K, N;
   int pair;
   int k_tiles, n_tiles;
-  int tile_begin;
+  int wg_begin;      // first logical workgroup id of this group
+  int splits;        // row splits of this group (the two-dimensional irrep has twice the rows and gets twice the splits)
   int64_t slab_off;  // element offset of this group's [N,K] block inside a slab
 };
 struct WgArgs {
   WgGroup g[5];
   int ngroups;
-  int tiles;       // tiles per split
-  int splits;
+  int wgs;         // workgroups in all
   int64_t slab_elems;
   float* slabs;
 };
@@ -57,15 +58,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs args) {
   int gi = 0;
 #pragma unroll
   for (int i = 1; i < 5; ++i)
-    if (i < args.ngroups && lid >= args.g[i].tile_begin * args.splits) gi = i;
+    if (i < args.ngroups && lid >= args.g[i].wg_begin) gi = i;
   const WgGroup& G = args.g[gi];
   const int gt = G.k_tiles * G.n_tiles;
-  const int rel = lid - G.tile_begin * args.splits;
+  const int rel = lid - G.wg_begin;
   const int split = rel / gt, lt = rel - split * gt;
   const int kt = lt / G.n_tiles, nt = lt - kt * G.n_tiles;
   const int k0 = kt * BW, n0 = nt * BW;
   const int K = G.K, N = G.N;
-  int64_t chunk = (G.rows + args.splits - 1) / args.splits;
+  int64_t chunk = (G.rows + G.splits - 1) / G.splits;
   chunk = (chunk + BMR - 1) / BMR * BMR;
   const int64_t r0 = (int64_t)split * chunk;
   const int64_t r1 = r0 + chunk < G.rows ? r0 + chunk : G.rows;
@@ -188,11 +189,159 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs args) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16, 160 x 160 tiles, K and N multiples of 160 (every shape of the ViT-H block): LDS-DMA ring.
+// Three stages of 32 reduction rows; a stage is the X tile and the dY tile as they lie in HBM (32 rows x 320 B each,
+// no padding: global_load_lds writes 1 KiB per wave-instruction linearly).  Rows whose index has bit 3 set are stored
+// rotated by two 16-byte chunks (the rotation is applied on the SOURCE side: lane l of a DMA instruction fetches the
+// chunk that belongs at its LDS position), which makes the transposing reads of rows r and r+8 hit disjoint banks.
+// 60 KiB of LDS and <= 128 VGPRs: two workgroups per CU (the register-staged kernel above fits one).
+// Row tails: rows >= r1 fetch from a zero page, so they add nothing.
+constexpr int kWgS = 3, kWgR = 32;
+constexpr int kWgTile = kWgR * 320;
+constexpr int kWgStage = 2 * kWgTile;
+__device__ __attribute__((aligned(256))) unsigned char g_wg_zero[512];
+
+__device__ inline void wg_wait_vmcnt(int n) {
+  if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(WgArgs args) {
+  constexpr int TT = 5, BW = 160;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (i < args.ngroups && lid >= args.g[i].wg_begin) gi = i;
+  const WgGroup& G = args.g[gi];
+  const int gt = G.k_tiles * G.n_tiles;
+  const int rel = lid - G.wg_begin;
+  const int split = rel / gt, lt = rel - split * gt;
+  const int kt = lt / G.n_tiles, nt = lt - kt * G.n_tiles;
+  const int k0 = kt * BW, n0 = nt * BW;
+  const int K = G.K, N = G.N;
+  int64_t chunk = (G.rows + G.splits - 1) / G.splits;
+  chunk = (chunk + kWgR - 1) / kWgR * kWgR;
+  const int64_t r0 = (int64_t)split * chunk;
+  const int64_t r1 = r0 + chunk < G.rows ? r0 + chunk : G.rows;
+  const int nsteps = r0 < r1 ? (int)((r1 - r0 + kWgR - 1) / kWgR) : 0;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wk = wid & 1, wn = wid >> 1;
+  const int fr = lane & 15, kg = lane >> 4;
+
+  // ---- DMA descriptors: instruction j of this wave is tile chunk q = wid + 4j (0-9: X, 10-19: dY)
+  const char* src[5];
+  int64_t inc[5];
+  int row_in_tile[5], cbyte[5], ldst[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int q = wid + 4 * j;
+    const bool isY = q >= 10;
+    const int qq = isY ? q - 10 : q;
+    const int o = qq * 1024 + lane * 16;
+    const int row = o / 320;
+    const int cpos = (o - row * 320) >> 4;                       // chunk position inside the LDS row
+    const int c = ((row & 8) ? cpos + 18 : cpos) % 20;           // the chunk that lives there (rotation by 2)
+    const int64_t mm = r0 + row;
+    const int64_t ld = isY ? G.dy_ld : G.x_ld;
+    const int width = isY ? N : K;
+    const int64_t ro = G.pair ? (mm >> 1) * ld + (mm & 1) * (int64_t)width : mm * ld;
+    src[j] = (isY ? G.dy : G.x) + (ro + (isY ? n0 : k0)) * 2 + c * 16;
+    inc[j] = (G.pair ? 16 : 32) * ld * 2;
+    row_in_tile[j] = row;
+    cbyte[j] = c * 16;
+    ldst[j] = (isY ? kWgTile : 0) + qq * 1024;
+  }
+  int l_step = 0, l_stage = 0;
+  auto issue = [&]() {
+    char* st = lds + l_stage * kWgStage;
+    const bool tail = (int64_t)(l_step + 1) * kWgR > r1 - r0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const char* p = src[j];
+      if (tail && r0 + (int64_t)l_step * kWgR + row_in_tile[j] >= r1) p = (const char*)g_wg_zero + cbyte[j];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)(st + ldst[j]), 16, 0, 0);
+      src[j] += inc[j];
+    }
+    l_stage = l_stage == kWgS - 1 ? 0 : l_stage + 1;
+    ++l_step;
+  };
+
+  f32x4 acc[TT][TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i)
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  // ---- fragment addresses inside a tile (transposing reads: lane fr = 4q+p of a 16-lane group addresses row q,
+  // columns 4p..4p+3 of a 4x16 block); rows kg*8 + (fr>>2) (+4): bit 3 of the row = kg & 1 -> rotation
+  const int frow = kg * 8 + (fr >> 2);
+  const int rot = (kg & 1) * 2;
+  int offa[TT], offb[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    const int ca = wk * 10 + i * 2 + ((fr & 3) >> 1), cb = wn * 10 + i * 2 + ((fr & 3) >> 1);
+    offa[i] = frow * 320 + ((ca + rot) % 20) * 16 + (fr & 1) * 8;
+    offb[i] = kWgTile + frow * 320 + ((cb + rot) % 20) * 16 + (fr & 1) * 8;
+  }
+
+  if (nsteps > 0) issue();
+  if (nsteps > 1) issue();
+  int c_stage = 0;
+  for (int sidx = 0; sidx < nsteps; ++sidx) {
+    wg_wait_vmcnt(sidx + 1 < nsteps ? 5 : 0);
+    __builtin_amdgcn_s_barrier();          // every wave's share of tile sidx has landed; stage of tile sidx-1 is free
+    if (sidx + 2 < nsteps) issue();
+    const char* base = lds + c_stage * kWgStage;
+    c_stage = c_stage == kWgS - 1 ? 0 : c_stage + 1;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    bf16x8 af[TT], bfr[TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + offa[i]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + offa[i] + 4 * 320));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      af[i] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + offb[j]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + offb[j] + 4 * 320));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      bfr[j] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int j = 0; j < TT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  }
+
+  // slab store: lane holds k = kb + kg*4 + (0..3) of row n = nb + fr
+  float* slab = args.slabs + (int64_t)split * args.slab_elems + G.slab_off;
+#pragma unroll
+  for (int j = 0; j < TT; ++j) {
+    const int n = n0 + wn * (TT * 16) + j * 16 + fr;
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int k = k0 + wk * (TT * 16) + i * 16 + kg * 4;
+      *(f32x4*)(slab + (int64_t)n * K + k) = acc[i][j];
+    }
+  }
+}
+
 // One wave per weight row n of a group: G[n,:] = sum_splits slab ; dW = cs[n]*G ; dcs[n] = <W[n,:],G[n,:]> (+ bias term)
 struct FinGroup {
   int64_t slab_off;
   int K, N;
   int row_begin;
+  int splits;
   const float* w32;
   const float* cs;
   float* dw;
@@ -202,7 +351,6 @@ struct FinArgs {
   FinGroup g[5];
   int ngroups;
   int rows_total;
-  int splits;
   int64_t slab_elems;
   const float* slabs;
   const float* bias;
@@ -224,7 +372,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinArgs a) {
   float dot = 0.f;
   for (int k = lane * 4; k < G.K; k += 256) {
     f32x4 v = {0, 0, 0, 0};
-    for (int sp = 0; sp < a.splits; ++sp) v += *(const f32x4*)(a.slabs + (int64_t)sp * a.slab_elems + G.slab_off + (int64_t)n * G.K + k);
+    for (int sp = 0; sp < G.splits; ++sp) v += *(const f32x4*)(a.slabs + (int64_t)sp * a.slab_elems + G.slab_off + (int64_t)n * G.K + k);
     if (G.cs) {
       const f32x4 w = *(const f32x4*)(G.w32 + (int64_t)n * G.K + k);
       dot += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
@@ -266,10 +414,10 @@ int launch_wgrad_tt(WgArgs& a, hipStream_t s) {
   for (int i = 0; i < a.ngroups; ++i) {
     a.g[i].k_tiles = (a.g[i].K + BW - 1) / BW;
     a.g[i].n_tiles = (a.g[i].N + BW - 1) / BW;
-    a.g[i].tile_begin = t;
-    t += a.g[i].k_tiles * a.g[i].n_tiles;
+    a.g[i].wg_begin = t;
+    t += a.g[i].k_tiles * a.g[i].n_tiles * a.g[i].splits;
   }
-  a.tiles = t;
+  a.wgs = t;
   constexpr size_t smem = (size_t)2 * 2 * WElem<TIN>::BMR * (BW * sizeof(TIN) + 16);
   static bool attr_done = false;
   if (!attr_done) {
@@ -277,12 +425,36 @@ int launch_wgrad_tt(WgArgs& a, hipStream_t s) {
     (void)hipGetLastError();
     attr_done = true;
   }
-  wgrad_kernel<TIN, TT><<<t * a.splits, 256, smem, s>>>(a);
+  wgrad_kernel<TIN, TT><<<t, 256, smem, s>>>(a);
+  return launch_status();
+}
+
+inline bool wgrad_ring_ok(const WgArgs& a) {
+  if (getenv("OCTIC_WGRAD_CLASSIC")) return false;
+  for (int i = 0; i < a.ngroups; ++i) {
+    const WgGroup& g = a.g[i];
+    if ((g.K % 160) || (g.N % 160)) return false;
+    if ((((uintptr_t)g.x) | ((uintptr_t)g.dy)) & 15) return false;
+  }
+  return true;
+}
+
+inline int launch_wgrad_ring(WgArgs& a, hipStream_t s) {
+  int t = 0;
+  for (int i = 0; i < a.ngroups; ++i) {
+    a.g[i].k_tiles = a.g[i].K / 160;
+    a.g[i].n_tiles = a.g[i].N / 160;
+    a.g[i].wg_begin = t;
+    t += a.g[i].k_tiles * a.g[i].n_tiles * a.g[i].splits;
+  }
+  a.wgs = t;
+  wgrad_ring_kernel<<<t, 256, kWgS * kWgStage, s>>>(a);
   return launch_status();
 }
 
 template <typename TIN>
 int launch_wgrad(WgArgs& a, hipStream_t s) {
+  if (sizeof(TIN) == 2 && wgrad_ring_ok(a)) return launch_wgrad_ring(a, s);
   switch (pick_tt(a)) {
     case 2: return launch_wgrad_tt<TIN, 2>(a, s);
     case 3: return launch_wgrad_tt<TIN, 3>(a, s);
@@ -292,6 +464,9 @@ int launch_wgrad(WgArgs& a, hipStream_t s) {
 }
 
 inline int64_t linear_slab_elems(int cin, int cout) { return (int64_t)8 * cin * cout; }
+// `splits` of the C ABI is the split count of the two-dimensional irrep's [2M]-row problem; the one-dimensional
+// irreps have half the rows and take half the splits, so every workgroup reduces about the same number of rows
+inline int group_splits(int splits, bool isE) { return isE ? splits : (splits + 1) / 2; }
 
 }  // namespace octic
 
@@ -315,8 +490,8 @@ int octic_linear_d8_wgrad_tile(int64_t M, int cin, int cout) {
 }
 
 int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
-  // enough row-splits to give every CU a couple of workgroups, bounded so the f32 slabs stay a
-  // fraction of the activation bytes the kernel has to read anyway
+  // enough row-splits to give every CU two workgroups, bounded so the f32 slabs stay a fraction of the activation
+  // bytes the kernel has to read anyway
   WgArgs a = {};
   a.ngroups = 5;
   for (int i = 0; i < 5; ++i) {
@@ -325,12 +500,12 @@ int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
     a.g[i].rows = i == 0 ? 2 * M : M;
   }
   const int bw = 32 * pick_tt(a);
-  int tiles = 0;
-  for (int i = 0; i < 5; ++i) tiles += ((a.g[i].K + bw - 1) / bw) * ((a.g[i].N + bw - 1) / bw);
-  int s = (512 + tiles - 1) / tiles;
-  const int64_t max_by_rows = (M + 255) / 256;
+  const int tiles_e = ((2 * cin + bw - 1) / bw) * ((2 * cout + bw - 1) / bw);
+  const int tiles_1 = 4 * ((cin + bw - 1) / bw) * ((cout + bw - 1) / bw);
+  int s = (int)((512.0 / (tiles_e + 0.5 * tiles_1)) + 0.5);
+  const int64_t max_by_rows = (2 * M + 255) / 256;
   if (s > max_by_rows) s = (int)max_by_rows;
-  if (s > 16) s = 16;
+  if (s > 32) s = 32;
   if (s < 1) s = 1;
   return s;
 }
@@ -344,7 +519,6 @@ int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, 
   if (M <= 0 || splits <= 0) return OCTIC_ESHAPE;
   WgArgs a = {};
   a.ngroups = 5;
-  a.splits = splits;
   a.slab_elems = linear_slab_elems(cin, cout);
   a.slabs = workspace;
   // slab layout: [W_A1 | W_A2 | W_B1 | W_B2 | W_E]; launch order E first
@@ -360,6 +534,7 @@ int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, 
     g.K = isE ? 2 * cin : cin;
     g.N = isE ? 2 * cout : cout;
     g.pair = isE ? 1 : 0;
+    g.splits = group_splits(splits, isE);
     g.slab_off = isE ? (int64_t)4 * cin * cout : (int64_t)irrep * cin * cout;
   }
   if (dtype == OCTIC_F32) return launch_wgrad<float>(a, (hipStream_t)stream);
@@ -375,7 +550,6 @@ int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, in
   if (cs && (!w32 || !dcs)) return OCTIC_ENULL;
   FinArgs a = {};
   a.ngroups = 5;
-  a.splits = splits;
   a.slab_elems = linear_slab_elems(cin, cout);
   a.slabs = workspace;
   a.bias = bias;
@@ -389,6 +563,7 @@ int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, in
     g.N = isE ? 2 * cout : cout;
     g.slab_off = isE ? (int64_t)4 * cin * cout : (int64_t)irrep * cin * cout;
     g.row_begin = row;
+    g.splits = group_splits(splits, isE);
     row += g.N;
     g.w32 = cs ? w32[irrep] : nullptr;
     g.cs = cs ? cs[irrep] : nullptr;
@@ -409,7 +584,6 @@ int octic_lift_wgrad(const void* patches, const void* dout, float* dw, float* wo
   if (rows <= 0 || splits <= 0 || Kpad <= 0 || (Kpad % 8) || D <= 0 || (D % 8)) return OCTIC_ESHAPE;
   WgArgs a = {};
   a.ngroups = 1;
-  a.splits = splits;
   a.slab_elems = (int64_t)Kpad * D;
   a.slabs = workspace;
   WgGroup& g = a.g[0];
@@ -421,19 +595,20 @@ int octic_lift_wgrad(const void* patches, const void* dout, float* dw, float* wo
   g.K = Kpad;
   g.N = D;
   g.pair = 0;
+  g.splits = splits;
   g.slab_off = 0;
   int e = dtype == OCTIC_F32 ? launch_wgrad<float>(a, (hipStream_t)stream)
                              : (dtype == OCTIC_BF16 ? launch_wgrad<bf16>(a, (hipStream_t)stream) : OCTIC_EDTYPE);
   if (e) return e;
   FinArgs f = {};
   f.ngroups = 1;
-  f.splits = splits;
   f.slab_elems = a.slab_elems;
   f.slabs = workspace;
   f.g[0].K = Kpad;
   f.g[0].N = D;
   f.g[0].slab_off = 0;
   f.g[0].row_begin = 0;
+  f.g[0].splits = splits;
   f.g[0].dw = dw;
   f.rows_total = D;
   wgrad_finish_kernel<<<(D + 3) / 4, 256, 0, (hipStream_t)stream>>>(f);

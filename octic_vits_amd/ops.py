@@ -249,8 +249,11 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
     if t is not None:
         es = 2 if dtype == torch.bfloat16 else 4
         tt = L.octic_linear_d8_wgrad_tile(M, cin, cout) // 32
-        KERNEL_TIMER.stop(t, f"wgrad_kernel<{_DTN[dtype]},{tt}>", M * 8 * (cin + cout) * es + splits * 8 * cin * cout * 4,
-                          24.0 * M * cin * cout)
+        ring = dtype == torch.bfloat16 and cin % 160 == 0 and cout % 160 == 0      # wgrad.hip: wgrad_ring_ok
+        name = "wgrad_ring_kernel<bf16>" if ring else f"wgrad_kernel<{_DTN[dtype]},{tt}>"
+        # slabs: the two-dimensional irrep (half of the 8*cin*cout weights) uses `splits`, the others splits/2
+        slab = (splits + (splits + 1) // 2) * 4 * cin * cout * 4
+        KERNEL_TIMER.stop(t, name, M * 8 * (cin + cout) * es + slab, 24.0 * M * cin * cout)
     dw = [torch.empty((cout, cin), dtype=torch.float32, device=dev) for _ in range(4)]
     dw.append(torch.empty((2 * cout, 2 * cin), dtype=torch.float32, device=dev))
     dcs = None
