@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 1
+#define OCTIC_ABI_VERSION 2
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -210,12 +210,15 @@ int octic_lift_wgrad(const void* patches, const void* dout, float* dw, float* wo
  * pointers p,g,m,v,ema (ema may be NULL), per-tensor weight decay, and a chunk list
  * (tensor id, element offset, length) with tensor_chunk_begin[ntensors+1] giving each tensor's chunk
  * range.  workspace: octic_lamb_workspace_floats() f32; workspace[1] holds the global grad norm after the
- * call (the number deit/engine.py:84 logs).                                                        */
+ * call (the number deit/engine.py:84 logs).  bf16_shadow (may be NULL; entries may be NULL): per-tensor bf16
+ * buffers that receive a rounded copy of the updated parameter in the same pass - the compute-dtype weights
+ * torch.autocast would otherwise re-cast at every use.                                              */
 int64_t octic_lamb_workspace_floats(int ntensors, int nchunks);
 int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
                     const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
                     const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
-                    float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* stream);
+                    float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
+                    void* stream);
 
 /* ---- standard (non-equivariant) half of the hybrid: row kernels around the library GEMMs ----------------
  * The reference's standard blocks (deit/models_v2.py Layer_scale_init_Block, used for the second half of the

@@ -44,7 +44,7 @@ _PROTOS = {
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "octic_lamb_workspace_floats": (c_i64, [c_int, c_int]),
     "octic_lamb_step": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float,
-                                                  c_int, c_float, c_void_p]),
+                                                  c_int, c_float, c_void_p, c_void_p]),
     "octic_dense_blocks": (c_int, [c_i64]),
     "octic_dense_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                                           c_float, c_void_p]),
@@ -97,7 +97,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.octic_abi_version() != 1:
+        if L.octic_abi_version() != 2:
             raise RuntimeError("octic_vits_amd: ABI version mismatch between _lib.py and liboctic_hip.so")
         _LIB = L
     return _LIB

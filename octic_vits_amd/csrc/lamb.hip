@@ -20,6 +20,7 @@ struct LambTables {
   float* const* m;
   float* const* v;
   float* const* ema;    // may be null
+  bf16* const* shadow;  // may be null; entries may be null: bf16 copy of the updated parameter
   const float* wd;      // [ntensors] weight decay per tensor
   const int* chunk_tensor;   // [nchunks]
   const int64_t* chunk_off;  // [nchunks]
@@ -141,15 +142,17 @@ __global__ __launch_bounds__(256) void lamb_stage2_kernel(LambTables t, const fl
   float* p = t.p[ti] + off;
   const float* u = t.g[ti] + off;
   float* e = t.ema ? t.ema[ti] + off : nullptr;
+  bf16* sh = (t.shadow && t.shadow[ti]) ? t.shadow[ti] + off : nullptr;
   const int n = t.chunk_len[ch];
   const float step = lr * ratio[ti];
-  const bool al = ((((uintptr_t)p) | ((uintptr_t)u) | ((uintptr_t)e)) & 15) == 0;
+  const bool al = ((((uintptr_t)p) | ((uintptr_t)u) | ((uintptr_t)e)) & 15) == 0 && (((uintptr_t)sh) & 7) == 0;
   const int n4 = al ? (n >> 2) : 0;
   for (int i = threadIdx.x; i < n4; i += 256) {
     f32x4 pv = ((const f32x4*)p)[i];
     const f32x4 uv = ((const f32x4*)u)[i];
     pv -= step * uv;
     ((f32x4*)p)[i] = pv;
+    if (sh) ((bf16x4*)sh)[i] = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
     if (e) {
       f32x4 ev = ((const f32x4*)e)[i];
       ev += ema_w * (pv - ev);
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(256) void lamb_stage2_kernel(LambTables t, const fl
   for (int i = n4 * 4 + threadIdx.x; i < n; i += 256) {
     const float pv = p[i] - step * u[i];
     p[i] = pv;
+    if (sh) sh[i] = (bf16)pv;
     if (e) e[i] += ema_w * (pv - e[i]);
   }
 }
@@ -172,13 +176,14 @@ extern "C" {
 int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
                     const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
                     const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
-                    float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* stream) {
+                    float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
+                    void* stream) {
   if (!p || !g || !m || !v || !wd || !chunk_tensor || !chunk_off || !chunk_len || !tensor_chunk_begin || !workspace)
     return OCTIC_ENULL;
   if (ntensors <= 0 || nchunks <= 0 || step <= 0) return OCTIC_ESHAPE;
   LambTables t;
   t.p = (float* const*)p; t.g = (float* const*)g; t.m = (float* const*)m; t.v = (float* const*)v;
-  t.ema = (float* const*)ema; t.wd = wd;
+  t.ema = (float* const*)ema; t.shadow = (bf16* const*)bf16_shadow; t.wd = wd;
   t.chunk_tensor = chunk_tensor; t.chunk_off = chunk_off; t.chunk_len = chunk_len;
   t.tensor_chunk_begin = tensor_chunk_begin;
   // workspace layout: [2] scalars | [nchunks] g2 | [nchunks] p2 | [nchunks] u2 | [ntensors] ratio

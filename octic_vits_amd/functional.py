@@ -312,14 +312,24 @@ class DenseWeightCache:
         self.key = None
         self.w = self.b = None
 
+    @staticmethod
+    def _key(w, b, dtype):
+        return (dtype, w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+
     def get(self, w, b, dtype):
-        key = (dtype, w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+        key = self._key(w, b, dtype)
         if key != self.key:
             with torch.no_grad():
                 self.w = _c(w.detach().to(dtype))
                 self.b = None if b is None else _c(b.detach().to(dtype))
             self.key = key
         return self.w, self.b
+
+    def adopt(self, w, b, w_copy, b_copy, dtype):
+        """Take compute-dtype copies produced elsewhere (the fused optimizer writes them in its update pass) as the
+        current cache content for the parameters' present versions."""
+        self.w, self.b = w_copy, b_copy
+        self.key = self._key(w, b, dtype)
 
 
 class DenseLayerNormFn(torch.autograd.Function):

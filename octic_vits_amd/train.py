@@ -79,7 +79,10 @@ class FusedLamb:
 
     CHUNK = 65536
 
-    def __init__(self, param_groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0, ema_decay=None):
+    def __init__(self, param_groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0, ema_decay=None,
+                 shadow_layers=()):
+        """shadow_layers: (nn.Linear, functional.DenseWeightCache) pairs; their weights/biases get a bf16 copy
+        written by the update kernel itself, handed to the cache after every step (no per-step cast launches)."""
         from . import _lib
         self._lib = _lib
         self.lr, self.betas, self.eps, self.max_grad_norm, self.ema_decay = lr, betas, eps, max_grad_norm, ema_decay
@@ -122,6 +125,19 @@ class FusedLamb:
         self.v_ptrs = torch.tensor(base(self.v), dtype=i64, device=dev)
         self.e_ptrs = torch.tensor(base(self.ema), dtype=i64, device=dev) if self.ema is not None else None
         self.g_ptrs = torch.zeros(len(self.params), dtype=i64, device=dev)
+        index = {id(p): i for i, p in enumerate(self.params)}
+        sh_ptrs, self._shadows = [0] * len(self.params), []
+        for lin, cache in shadow_layers:
+            w, b = lin.weight, lin.bias
+            if id(w) not in index or (b is not None and id(b) not in index):
+                continue
+            wb = torch.empty_like(w, dtype=torch.bfloat16)
+            bb = None if b is None else torch.empty_like(b, dtype=torch.bfloat16)
+            sh_ptrs[index[id(w)]] = wb.data_ptr()
+            if b is not None:
+                sh_ptrs[index[id(b)]] = bb.data_ptr()
+            self._shadows.append((lin, cache, wb, bb))
+        self.s_ptrs = torch.tensor(sh_ptrs, dtype=i64, device=dev) if self._shadows else None
         self._g_key = None
         self.ntensors, self.nchunks = len(self.params), len(ct)
         self.ws = torch.zeros(int(_lib.lib().octic_lamb_workspace_floats(self.ntensors, self.nchunks)),
@@ -165,11 +181,14 @@ class FusedLamb:
             vp(self.p_ptrs), vp(self.g_ptrs), vp(self.m_ptrs), vp(self.v_ptrs), vp(self.e_ptrs), vp(self.wd),
             vp(self.chunk_tensor), vp(self.chunk_off), vp(self.chunk_len), vp(self.tensor_chunk_begin),
             self.ntensors, self.nchunks, vp(self.ws), float(self.lr), float(self.betas[0]), float(self.betas[1]),
-            float(self.eps), float(self.max_grad_norm or 0.0), self.step_count, float(self.ema_decay or 0.0), stream))
+            float(self.eps), float(self.max_grad_norm or 0.0), self.step_count, float(self.ema_decay or 0.0),
+            vp(self.s_ptrs), stream))
         # the kernels wrote the parameters behind autograd's back: advance their version counters so that every
         # cache keyed on them (the compute-dtype weight copies of functional.WeightPrep) is refreshed
         torch._C._autograd._unsafe_set_version_counter(
             tuple(self.params), tuple(p._version + 1 for p in self.params))
+        for lin, cache, wb, bb in self._shadows:     # the bf16 copies written above are current for the new versions
+            cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16)
 
 
 def param_groups_weight_decay(model, weight_decay, no_decay_names=()):
@@ -225,6 +244,18 @@ def use_tuned_gemms(table=None):
     return bool(tunable.read_file(table))
 
 
+def library_gemm_layers(model):
+    """(nn.Linear, DenseWeightCache) of every projection of the standard half (vit.Attention / vit.Mlp)."""
+    from . import vit
+    out = []
+    for m in model.modules():
+        if isinstance(m, vit.Attention):
+            out += [(m.qkv, m._c1), (m.proj, m._c2)]
+        elif isinstance(m, vit.Mlp):
+            out += [(m.fc1, m._c1), (m.fc2, m._c2)]
+    return out
+
+
 class Trainer:
     def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
                  fused_optimizer=True, tuned_gemms=True):
@@ -238,7 +269,8 @@ class Trainer:
                 find_unused_parameters=False, static_graph=False)
         groups = param_groups_weight_decay(model, weight_decay, model.no_weight_decay())
         if fused_optimizer:
-            self.optimizer = FusedLamb(groups, lr=lr, ema_decay=ema_decay)   # LAMB and EMA in one fused step
+            # LAMB and EMA in one fused step; it also refreshes the bf16 weights of the library-GEMM layers
+            self.optimizer = FusedLamb(groups, lr=lr, ema_decay=ema_decay, shadow_layers=library_gemm_layers(model))
             self.ema = None
         else:
             self.optimizer = Lamb(groups, lr=lr, weight_decay=weight_decay)
