@@ -8,7 +8,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboctic_hip.so")
+LIB_PATH = os.environ.get("OCTIC_LIB") or os.path.join(HERE, "liboctic_hip.so")   # OCTIC_LIB: developer A/B builds
 HEADER_PATH = os.path.join(HERE, "..", "include", "octic_hip.h")
 
 F32, BF16 = 0, 1

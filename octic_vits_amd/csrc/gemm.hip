@@ -339,14 +339,23 @@ __device__ char g_store_sink[64 * 16 * 2];
 
 __device__ inline void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt needs an immediate
   switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
     case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
     case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
     case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
     case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0 and anything else: drain (always safe)
   }
 }
 
@@ -543,13 +552,38 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
 // L2->CU traffic for fc1: 42 MB (X once) + 316 MB (W per 128-row block) = 358 MB.
 // ================================================================================================
 constexpr int kXStage = kRingBN * 128;   // one W tile: 80 rows x 128 B
+constexpr int kXS = 3;                   // ring depth (5 measured no faster)
+
+#ifdef OCTIC_XREG_TRACE
+// developer-only timeline (build with -DOCTIC_XREG_TRACE): s_memtime stamps of the first 256 workgroups
+__device__ unsigned long long g_xreg_trace[256 * 4 * 64];
+extern "C" void* octic_dbg_xreg_trace(void) {
+  void* p = nullptr;
+  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_xreg_trace));
+  return p;
+}
+#define XTRACE(slot)                                                                                   \
+  do {                                                                                                 \
+    if (tile < 256 && lane == 0 && (slot) < 64) g_xreg_trace[(tile * 4 + wid) * 64 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define XTRACE(slot) do {} while (0)
+#endif
 
 template <typename TOUT, int EPI, int KSTEPS>
 __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
   constexpr int NT = 5, MT = 2;
   constexpr int NKT = (KSTEPS + 1) / 2;      // 64-wide W tiles per n-tile
-  constexpr int NSTORE = NT * MT;
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // kRingS stages x 80 rows x 128 B
+  // epilogue staging: a wave writes 16 rows x 80 columns of results into its private LDS tile in the MFMA layout and
+  // reads it back row-wise, so a global store instruction writes 16 bytes per lane along rows (6.4 row segments of
+  // 80 columns per instruction) instead of 16 rows x 4 columns: the s_memtime timeline showed ~5000 cycles per
+  // n-tile epilogue with the direct stores (address-path bound: 16 partial lines per instruction).
+  constexpr int EPV = 16 / (int)sizeof(TOUT);            // elements per 16-byte chunk
+  constexpr int CPR = kRingBN / EPV;                     // chunks per staged row
+  constexpr int SRS = kRingBN * (int)sizeof(TOUT) + 16;  // staged row stride (bytes): conflict-free both ways
+  constexpr int SCH = (16 * CPR + 63) / 64;              // store instructions per 16-row half
+  constexpr int NSTORE = sizeof(TOUT) == 2 ? SCH * MT : NT * MT;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // kXS stages x 80 rows x 128 B | 4 x staging tile
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -572,6 +606,7 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, kg = lane >> 4;
+  XTRACE(0);
 
   // ---- W DMA sources (as in the ring kernel): 10 wave-instructions per tile, waves 0,1 take 3, waves 2,3 take 2
   const int drow = lane >> 3;
@@ -598,7 +633,7 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
       if (q < w_cnt)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + k * 2),
                                          (__attribute__((address_space(3))) void*)(st + (w_first + q) * 1024), 16, 0, 0);
-    l_stage = l_stage == kRingS - 1 ? 0 : l_stage + 1;
+    l_stage = l_stage == kXS - 1 ? 0 : l_stage + 1;
     if (++l_kt == nkt) {
       l_kt = 0;
       ++l_nt;
@@ -606,8 +641,9 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
     }
   };
   // the W stream starts first so it overlaps the X fragment loads below
-  issue();
-  if (steps > 1) issue();
+#pragma unroll
+  for (int pz = 0; pz < kXS - 1; ++pz)
+    if (pz < steps) issue();
 
   // ---- X fragments of this wave's 32 rows for the whole K: lane (fr,kg) holds X[row fr][32 ks + 8 kg .. +7]
   bf16x8 xf[KSTEPS][MT];
@@ -618,9 +654,20 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
     const int64_t off = G.pair ? (mm >> 1) * G.a_ld + (mm & 1) * (int64_t)K : mm * G.a_ld;
     const bf16* xr = (const bf16*)G.a + off + kg * 8;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-      if (ks < ksteps) xf[ks][j] = *(const bf16x8*)(xr + ks * 32);   // wave-uniform guard
+    for (int ks = 0; ks < KSTEPS; ++ks)          // unconditional: k-steps a group does not have re-read its step 0
+      xf[ks][j] = *(const bf16x8*)(xr + (ks < ksteps ? ks : 0) * 32);
   }
+  // The X registers are re-defined by an empty asm once their loads have landed.  hipcc's waitcnt pass tracks
+  // pending VMEM results per register and cannot see that loads issued before a loop are complete after its first
+  // trip: left alone it protects EVERY MFMA block of the loop with `s_waitcnt vmcnt(0)`, which also drains the DMA
+  // ring and the epilogue stores at every step (the first version of this kernel did exactly that).  After this
+  // statement the registers' last writer is the asm, so the loop carries no VMEM dependence on them.
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+      asm volatile("" : "+v"(xf[ks][j]));
+  XTRACE(1);
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -631,12 +678,20 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
   const int rd_w = fr * 128;                            // + i*2048
   const int ch0 = (kg ^ sw) << 4, ch1 = ((4 + kg) ^ sw) << 4;
 
-  // ---- epilogue constants
+  // ---- epilogue constants.  bf16 outputs go through the LDS staging tile (row-wise 16-byte stores); f32 outputs
+  // (fused residual) keep the direct MFMA-layout path: their 4 columns are already 16 bytes per lane, and the
+  // staged variant needs more registers than the 170 this kernel has (spills, 59 -> 70 us on proj+res).
+  constexpr bool kStaged = sizeof(TOUT) == 2;
+  TOUT* const sink = (TOUT*)(g_store_sink + lane * 16);
+  const bool has_bias = G.bias != nullptr;
+  const bool has_cs = EPI == 1 && G.cs != nullptr, has_rs = EPI == 1 && args.rs != nullptr,
+             has_res = EPI == 1 && G.resid != nullptr;
+  int e_nt = nt_begin;
+  // direct path state
   TOUT* ybase[MT];
   const TOUT* rbase[MT];
   float rsv[MT];
   bool rok[MT];
-  TOUT* const sink = (TOUT*)(g_store_sink + lane * 16);
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int64_t mm = m0 + wid * 32 + j * 16 + fr;
@@ -649,11 +704,10 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
     rbase[j] = (const TOUT*)G.resid + roff;
     rsv[j] = (EPI == 1 && args.rs) ? args.rs[token / args.rps] : 1.0f;
   }
-  const bool has_bias = G.bias != nullptr;
-  const bool has_cs = EPI == 1 && G.cs != nullptr, has_rs = EPI == 1 && args.rs != nullptr,
-             has_res = EPI == 1 && G.resid != nullptr;
-  int e_nt = nt_begin;
-  auto epilogue = [&]() {
+  // staged path state
+  char* const stg = lds + kXS * kXStage + wid * (16 * SRS);
+  // row-wise phase: chunk q = lane + 64 t of a 16-row half is row q / CPR, 16-byte column chunk q % CPR
+  auto epilogue_direct = [&]() {
     const int nb = e_nt * kRingBN + kg * 4;
     ++e_nt;
 #pragma unroll
@@ -677,21 +731,87 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
       }
     }
   };
+  auto epilogue_staged = [&]() {
+    const int n0 = e_nt * kRingBN;
+    ++e_nt;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      // phase A: this wave's 16 x 80 block, MFMA layout -> LDS (lane: row fr, columns i*16 + kg*4 .. +3)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n0 + i * 16 + kg * 4;
+        const int nc2 = n < N ? n : 0;
+        f32x4 v = acc[i][j];
+        if (has_bias) v += *(const f32x4*)(G.bias + nc2);
+        if (has_cs) v *= *(const f32x4*)(G.cs + nc2);
+        if (has_rs) v *= rsv[j];
+        store_out4<TOUT>((TOUT*)(stg + fr * SRS) + i * 16 + kg * 4, v);
+        acc[i][j] = f32x4{0, 0, 0, 0};
+      }
+      // phase B: rows of the block, 16 bytes per lane (+ residual), always SCH store instructions
+#pragma unroll
+      for (int t = 0; t < SCH; ++t) {
+        const int q = lane + 64 * t;
+        const bool inb = q < 16 * CPR;
+        const int row = inb ? q / CPR : 0;
+        const int scolt = inb ? (q - row * CPR) * EPV : 0;
+        const int64_t mm = m0 + wid * 32 + j * 16 + row;
+        const int n = n0 + scolt;
+        const bool ok = inb && mm < G.rows && n < N;
+        const int64_t mc = ok ? mm : 0;
+        const int64_t yoff = G.pair ? (mc >> 1) * G.y_ld + (mc & 1) * (int64_t)N : mc * G.y_ld;
+        u32x4 v = *(const u32x4*)(stg + row * SRS + scolt * (int)sizeof(TOUT));
+        if (has_res) {
+          const int64_t roff = G.pair ? (mc >> 1) * G.r_ld + (mc & 1) * (int64_t)N : mc * G.r_ld;
+          const u32x4 r = *(const u32x4*)(ok ? (const TOUT*)G.resid + roff + n : (const TOUT*)sink);
+          if constexpr (sizeof(TOUT) == 4) {
+            f32x4 a = __builtin_bit_cast(f32x4, v) + __builtin_bit_cast(f32x4, r);
+            v = __builtin_bit_cast(u32x4, a);
+          } else {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, v), c = __builtin_bit_cast(bf16x8, r);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)a[e] + (float)c[e]);
+            v = __builtin_bit_cast(u32x4, o);
+          }
+        }
+        *(u32x4*)(ok ? (TOUT*)G.y + yoff + n : sink) = v;
+      }
+    }
+  };
+  auto epilogue = [&]() {
+    if constexpr (kStaged) epilogue_staged();
+    else epilogue_direct();
+  };
 
   // ---- ring over (n-tile, k-tile) steps; only W moves
   const bool plain_waits = !(has_res || has_bias || has_cs);   // VGPR-destination loads in the epilogue: drain instead
-  int c_stage = 0, st1 = 0, st2 = 0;
+  // VMEM program order per step s: [wait tile s][barrier] DMA(s+P) compute(s) [stores if the n-tile is done], P = kXS-1.
+  // Younger than DMA(s) at that wait: DMA(s+1..s+P-1) and the stores of steps s-P..s-1.
+  int c_stage = 0, sth[kXS - 1];
+#pragma unroll
+  for (int pz = 0; pz < kXS - 1; ++pz) sth[pz] = 0;
   for (int nt_i = 0; nt_i < nt_count; ++nt_i) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt >= nkt) break;                    // wave-uniform
       const int s = nt_i * nkt + kt;
-      if (plain_waits) wait_vmcnt(s + 1 < steps ? w_cnt + st1 + st2 : 0);
-      else wait_vmcnt(0);
+      if (plain_waits) {
+        const int left = steps - 1 - s;          // DMA tiles younger than tile s: kXS-2 in steady state
+        int stores = 0;
+#pragma unroll
+        for (int pz = 0; pz < kXS - 1; ++pz) stores += sth[pz];
+        // tail of the workgroup: a smaller count than strictly needed is always safe (it only waits longer)
+        wait_vmcnt(left >= kXS - 2 ? (kXS - 2) * w_cnt + (stores > 20 ? 20 : stores) : left * w_cnt);
+      } else {
+        wait_vmcnt(0);
+      }
+      XTRACE(2 + 3 * s);
       __builtin_amdgcn_s_barrier();
-      if (s + 2 < steps) issue();
+      XTRACE(3 + 3 * s);
+      if (s + kXS - 1 < steps) issue();
       const char* base = lds + c_stage * kXStage + rd_w;
-      c_stage = c_stage == kRingS - 1 ? 0 : c_stage + 1;
+      c_stage = c_stage == kXS - 1 ? 0 : c_stage + 1;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if (kt * 2 + ks < ksteps) {
@@ -706,17 +826,19 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], xf[kt * 2 + ks][j], acc[i][j], 0, 0, 0);
         }
       }
-      st2 = st1;
-      st1 = 0;
+      XTRACE(4 + 3 * s);
+#pragma unroll
+      for (int pz = kXS - 2; pz > 0; --pz) sth[pz] = sth[pz - 1];
+      sth[0] = 0;
     }
     epilogue();
-    st1 = NSTORE;
+    sth[0] = NSTORE;
   }
 }
 
 template <typename TOUT, int KSTEPS>
 int launch_xreg_k(GemmArgs& a, bool fused, int t, hipStream_t s) {
-  const size_t smem = (size_t)kRingS * kXStage;
+  const size_t smem = (size_t)kXS * kXStage + (sizeof(TOUT) == 2 ? 4 * 16 * (kRingBN * sizeof(TOUT) + 16) : 0);
   if (fused) linear_d8_xreg_kernel<TOUT, 1, KSTEPS><<<t, 256, smem, s>>>(a);
   else linear_d8_xreg_kernel<TOUT, 0, KSTEPS><<<t, 256, smem, s>>>(a);
   return launch_status();
