@@ -122,6 +122,10 @@ int octic_linear_d8_tile_n(int64_t M, int cin, int cout);
  *     dbias[n]  = cs_A1[n] * dysum[n]          with dysum = column sums of dy_A1
  * which is the gradient of  y = resid + rs*cs*(xW^T+b)  w.r.t. W, cs, b when dy = rs*dL/dy.
  * w32 (f32 master weights) and bias are only read when cs != NULL.                            */
+/* octic_linear_d8_wgrad_has_colsum: 1 if the wgrad launch for this shape also leaves the column sums of the invariant
+ * irrep's dY (the bias gradient) in the workspace; _finish then takes them when called with dysum == NULL and
+ * octic_colsum_a1 is not needed.                                                                       */
+int octic_linear_d8_wgrad_has_colsum(int cin, int cout, int dtype);
 int64_t octic_linear_d8_wgrad_workspace_bytes(int cin, int cout, int splits);
 int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout);
 int octic_linear_d8_wgrad_tile(int64_t M, int cin, int cout);   /* tile width 32*TT of wgrad_kernel<TIN, TT> */

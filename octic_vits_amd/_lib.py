@@ -42,6 +42,7 @@ _PROTOS = {
     "octic_linear_d8_wgrad": (c_int, [VP, VP, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "octic_linear_d8_wgrad_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octic_linear_d8_wgrad_has_colsum": (c_int, [c_int, c_int, c_int]),
     "octic_lamb_workspace_floats": (c_i64, [c_int, c_int]),
     "octic_lamb_step": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float,
                                                   c_int, c_float, c_void_p, c_void_p]),

@@ -27,6 +27,7 @@ struct WgGroup {
   int wg_begin;      // first logical workgroup id of this group
   int splits;        // row splits of this group (the two-dimensional irrep has twice the rows and gets twice the splits)
   int64_t slab_off;  // element offset of this group's [N,K] block inside a slab
+  float* colsum;     // ring kernel only: [splits][N] partial column sums of dY (bias gradient), or null
 };
 struct WgArgs {
   WgGroup g[5];
@@ -278,6 +279,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(WgArgs args) {
   for (int i = 0; i < TT; ++i)
 #pragma unroll
     for (int j = 0; j < TT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  // bias gradient for free: the column sums of dY are one more MFMA row with an all-ones X fragment.  Only the
+  // invariant irrep has a bias; its k-tile-0 workgroups (waves wk == 0) carry the extra 5 MFMAs per step.
+  const bool do_cs = G.colsum != nullptr && kt == 0 && wk == 0;
+  f32x4 accs[TT];
+#pragma unroll
+  for (int j = 0; j < TT; ++j) accs[j] = f32x4{0, 0, 0, 0};
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
   // ---- fragment addresses inside a tile (transposing reads: lane fr = 4q+p of a 16-lane group addresses row q,
   // columns 4p..4p+3 of a 4x16 block); rows kg*8 + (fr>>2) (+4): bit 3 of the row = kg & 1 -> rotation
@@ -321,6 +330,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(WgArgs args) {
 #pragma unroll
       for (int j = 0; j < TT; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (do_cs) {
+#pragma unroll
+      for (int j = 0; j < TT; ++j) accs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[j], accs[j], 0, 0, 0);
+    }
   }
 
   // slab store: lane holds k = kb + kg*4 + (0..3) of row n = nb + fr
@@ -333,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(WgArgs args) {
       const int k = k0 + wk * (TT * 16) + i * 16 + kg * 4;
       *(f32x4*)(slab + (int64_t)n * K + k) = acc[i][j];
     }
+    if (do_cs && kg == 0) G.colsum[(int64_t)split * N + n] = accs[j][0];   // all 16 output rows are equal
   }
 }
 
@@ -355,6 +369,7 @@ struct FinArgs {
   const float* slabs;
   const float* bias;
   const float* dysum;
+  const float* colsum_part;   // [splits of group 0][N of group 0] partial column sums left by the ring kernel, or null
   float* dbias;
 };
 
@@ -379,14 +394,25 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinArgs a) {
     }
     if (G.dw) *(f32x4*)(G.dw + (int64_t)n * G.K + k) = v * s;
   }
+  float ysum = 0.f;
+  bool have_ysum = false;
+  if (gi == 0) {
+    if (a.dysum) {
+      ysum = a.dysum[n];
+      have_ysum = true;
+    } else if (a.colsum_part) {
+      for (int sp = 0; sp < G.splits; ++sp) ysum += a.colsum_part[(int64_t)sp * G.N + n];
+      have_ysum = true;
+    }
+  }
   if (G.cs) {
     dot = wave_sum(dot);
     if (lane == 0 && G.dcs) {
-      if (gi == 0 && a.bias && a.dysum) dot += a.bias[n] * a.dysum[n];
+      if (gi == 0 && a.bias && have_ysum) dot += a.bias[n] * ysum;
       G.dcs[n] = dot;
     }
   }
-  if (gi == 0 && lane == 0 && a.dbias && a.dysum) a.dbias[n] = s * a.dysum[n];
+  if (gi == 0 && lane == 0 && a.dbias && have_ysum) a.dbias[n] = s * ysum;
 }
 
 inline int pick_tt(const WgArgs& a) {
@@ -474,8 +500,15 @@ using namespace octic;
 
 extern "C" {
 
+// behind the slabs: [splits][cout] partial column sums of the invariant irrep's dY (ring kernel)
+inline int64_t colsum_off_elems(int cin, int cout, int splits) { return linear_slab_elems(cin, cout) * (int64_t)splits; }
+
 int64_t octic_linear_d8_wgrad_workspace_bytes(int cin, int cout, int splits) {
-  return linear_slab_elems(cin, cout) * (int64_t)splits * 4;
+  return (colsum_off_elems(cin, cout, splits) + (int64_t)splits * cout) * 4;
+}
+
+int octic_linear_d8_wgrad_has_colsum(int cin, int cout, int dtype) {
+  return dtype == OCTIC_BF16 && (cin % 160) == 0 && (cout % 160) == 0 && !getenv("OCTIC_WGRAD_CLASSIC");
 }
 
 int octic_linear_d8_wgrad_tile(int64_t M, int cin, int cout) {
@@ -502,7 +535,8 @@ int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
   const int bw = 32 * pick_tt(a);
   const int tiles_e = ((2 * cin + bw - 1) / bw) * ((2 * cout + bw - 1) / bw);
   const int tiles_1 = 4 * ((cin + bw - 1) / bw) * ((cout + bw - 1) / bw);
-  int s = (int)((512.0 / (tiles_e + 0.5 * tiles_1)) + 0.5);
+  static const double target = getenv("OCTIC_WGRAD_WGS") ? atof(getenv("OCTIC_WGRAD_WGS")) : 512.0;
+  int s = (int)((target / (tiles_e + 0.5 * tiles_1)) + 0.5);
   const int64_t max_by_rows = (2 * M + 255) / 256;
   if (s > max_by_rows) s = (int)max_by_rows;
   if (s > 32) s = 32;
@@ -536,6 +570,7 @@ int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, 
     g.pair = isE ? 1 : 0;
     g.splits = group_splits(splits, isE);
     g.slab_off = isE ? (int64_t)4 * cin * cout : (int64_t)irrep * cin * cout;
+    g.colsum = irrep == 0 ? workspace + colsum_off_elems(cin, cout, splits) : nullptr;
   }
   if (dtype == OCTIC_F32) return launch_wgrad<float>(a, (hipStream_t)stream);
   if (dtype == OCTIC_BF16) return launch_wgrad<bf16>(a, (hipStream_t)stream);
@@ -554,6 +589,9 @@ int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, in
   a.slabs = workspace;
   a.bias = bias;
   a.dysum = dysum;
+  // no explicit dysum but a bias gradient wanted: the caller vouches (octic_linear_d8_wgrad_has_colsum) that the
+  // wgrad launch left the partial column sums behind the slabs
+  a.colsum_part = (!dysum && (dbias || (bias && cs))) ? workspace + colsum_off_elems(cin, cout, splits) : nullptr;
   a.dbias = dbias;
   int row = 0;
   for (int irrep = 0; irrep < 5; ++irrep) {  // group 0 must be A1 (bias terms)

@@ -200,7 +200,9 @@ class LinearD8Fn(torch.autograd.Function):
             ops.linear_fwd(gv, wt, None, ops.pview(dx, cin), M, cout, cin, dtype, dtype, x)
             if dx.dtype != x_in_dtype:
                 dx = dx.to(x_in_dtype)
-        dysum = ops.colsum_a1(gv, M, cout, dtype, x) if has_bias else None
+        # bias gradient = column sums of the invariant block of g: the bf16 wgrad kernel produces them on the side
+        # (one extra MFMA row); other paths run the column-sum kernel
+        dysum = ops.colsum_a1(gv, M, cout, dtype, x) if (has_bias and not ops.wgrad_has_colsum(cin, cout, dtype)) else None
         w32 = [_c(w.detach().float()) for w in w5] if has_cs else None
         dw, dcs, dbias = ops.linear_wgrad(xv, gv, M, cin, cout, dtype, x, w32=w32, cs5=cs32, bias=b32, dysum=dysum,
                                           want_bias=has_bias)

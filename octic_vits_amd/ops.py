@@ -267,6 +267,10 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
     return dw, dcs, dbias
 
 
+def wgrad_has_colsum(cin, cout, dtype):
+    return bool(lib().octic_linear_d8_wgrad_has_colsum(cin, cout, dt_code(dtype)))
+
+
 def colsum_a1(dyv, M, c, dtype, ref):
     L = lib()
     nblk = L.octic_colsum_blocks(M)

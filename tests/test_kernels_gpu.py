@@ -225,6 +225,13 @@ def test_linear_wgrad(B, T, cin, cout, dtype, scaled):
         if scaled:
             close(dcs[i], cs[i].grad, tol, tol, f"dcs {names[i]}")
     close(dbias, bias.grad, tol, tol, "dbias")
+    if o.wgrad_has_colsum(cin, cout, dtype):
+        # the bf16 ring kernel leaves the column sums of dY behind the slabs: no explicit dysum needed
+        dw2, dcs2, dbias2 = o.linear_wgrad(o.pview(x, cin), o.pview(dy, cout), M, cin, cout, dtype, x, dysum=None,
+                                           want_bias=True, **kw)
+        close(dbias2, bias.grad, tol, tol, "dbias from the wgrad kernel's own column sums")
+        if scaled:
+            close(dcs2[0], cs[0].grad, tol, tol, "dcs A1 from the wgrad kernel's own column sums")
 
 
 def test_wgrad_is_bitwise_reproducible():
