@@ -246,6 +246,12 @@ int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const
                               const float* dres, float* dx, float* partials, int64_t rows, int d, void* stream);
 int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, float* out1, const float* scale1,
                        void* stream);
+/* octic_dense_gelu_bwd: dh = gelu'(h) * g (exact erf GELU, bf16 [rows, d], d % 8 == 0) and, when partials != NULL,
+ * octic_dense_gelu_blocks() slabs [d] of column sums of dh (bias gradient of the projection that produced h;
+ * reduce with octic_dense_finish(partials, blocks, d/2, out, out + d/2, NULL)).  Replaces GeluBackward + the
+ * bias-gradient reduction of the standard MLP (deit/vit.py Mlp).                                          */
+int octic_dense_gelu_blocks(void);
+int octic_dense_gelu_bwd(const void* h, const void* g, void* dh, float* partials, int64_t rows, int d, void* stream);
 int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, float* out, int64_t rows, int d, void* stream);
 int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,

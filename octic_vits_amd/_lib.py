@@ -52,6 +52,8 @@ _PROTOS = {
     "octic_dense_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_i64, c_int, c_void_p]),
     "octic_dense_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octic_dense_gelu_blocks": (c_int, []),
+    "octic_dense_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "octic_scale_residual_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int,
                                          c_void_p]),
     "octic_scale_residual_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,

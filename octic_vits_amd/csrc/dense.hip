@@ -227,6 +227,59 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------ GELU backward (+ bias grad)
+// dh = gelu'(h) * g for dense bf16 [rows, d] (the standard MLP's hidden activations, d = 4 * dim) and, on the side,
+// the column sums of dh = gradient of the bias of the projection that produced h.  A workgroup is 64 column chunks
+// (8 columns = 16 bytes each) x 4 row phases and walks a strip of rows; per-thread partial sums, one LDS fold over
+// the row phases, slab [row_block][d].
+constexpr int kGeluRowBlocks = 256;    // x 10 column blocks at d = 5120: 10 waves per SIMD's worth of work in flight
+__global__ __launch_bounds__(256) void dense_gelu_bwd_kernel(const bf16* __restrict__ h, const bf16* __restrict__ g,
+                                                             bf16* __restrict__ dh, float* __restrict__ partials,
+                                                             long rows, int d) {
+  __shared__ float red[4][64][8];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + cl) * 8;
+  const long per = (rows + kGeluRowBlocks - 1) / kGeluRowBlocks;
+  const long r0 = (long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < d) {
+    long r = r0 + ph;
+    for (; r + 4 < r1; r += 8) {          // two rows per trip: four 16-byte loads in flight per lane
+      const bf16x8 hv0 = *(const bf16x8*)(h + r * d + col), hv1 = *(const bf16x8*)(h + (r + 4) * d + col);
+      const bf16x8 gv0 = *(const bf16x8*)(g + r * d + col), gv1 = *(const bf16x8*)(g + (r + 4) * d + col);
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o0[e] = (bf16)(gelu_grad((float)hv0[e]) * (float)gv0[e]);
+        o1[e] = (bf16)(gelu_grad((float)hv1[e]) * (float)gv1[e]);
+        acc[e] += (float)o0[e] + (float)o1[e];      // sum what the GEMMs downstream actually see
+      }
+      *(bf16x8*)(dh + r * d + col) = o0;
+      *(bf16x8*)(dh + (r + 4) * d + col) = o1;
+    }
+    for (; r < r1; r += 4) {
+      const bf16x8 hv = *(const bf16x8*)(h + r * d + col);
+      const bf16x8 gv = *(const bf16x8*)(g + r * d + col);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (bf16)(gelu_grad((float)hv[e]) * (float)gv[e]);
+        acc[e] += (float)o[e];
+      }
+      *(bf16x8*)(dh + r * d + col) = o;
+    }
+  }
+  if (!partials) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ph][cl][e] = acc[e];
+  __syncthreads();
+  if (ph == 0 && col < d) {
+    float* out = partials + (long)blockIdx.y * d + col;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = (red[0][cl][e] + red[1][cl][e]) + (red[2][cl][e] + red[3][cl][e]);
+  }
+}
+
 static inline int dense_nv(int d) { return (d + 255) / 256; }
 static inline int dense_check(long rows, int d) {
   if (rows < 0 || d <= 0 || (d & 3) || d > 2048) return OCTIC_ESHAPE;
@@ -299,6 +352,18 @@ int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, f
   if (nblocks <= 0 || d <= 0) return OCTIC_ESHAPE;
   hipLaunchKernelGGL(dense_finish_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nblocks,
                      d, out0, out1, scale1);
+  return launch_status();
+}
+
+int octic_dense_gelu_blocks(void) { return kGeluRowBlocks; }
+
+int octic_dense_gelu_bwd(const void* h, const void* g, void* dh, float* partials, int64_t rows, int d, void* stream) {
+  if (rows == 0) return OCTIC_OK;
+  if (!h || !g || !dh) return OCTIC_ENULL;
+  if (rows < 0 || d <= 0 || (d & 7)) return OCTIC_ESHAPE;
+  if ((((uintptr_t)h) | ((uintptr_t)g) | ((uintptr_t)dh)) & 15) return OCTIC_EALIGN;
+  dense_gelu_bwd_kernel<<<dim3((d / 8 + 63) / 64, kGeluRowBlocks), dim3(256), 0, (hipStream_t)stream>>>(
+      (const bf16*)h, (const bf16*)g, (bf16*)dh, partials, rows, d);
   return launch_status();
 }
 

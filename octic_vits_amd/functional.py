@@ -386,6 +386,34 @@ class DenseLinearFn(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+class DenseLinearGeluFn(torch.autograd.Function):
+    """gelu(x W^T + b) of the standard MLP (bf16): library GEMM with bias epilogue + torch's exact GELU forward; the
+    backward is one HIP pass that yields dh = gelu'(h) g and the bias gradient (column sums of dh) together."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cache):
+        ops._require_cuda(x)
+        dtype = torch.bfloat16
+        xb = _c(x if x.dtype == dtype else x.to(dtype))
+        wb, bb = cache.get(w, b, dtype)
+        with torch.autocast("cuda", enabled=False):
+            h = torch.nn.functional.linear(xb, wb, bb)
+            y = torch.nn.functional.gelu(h)
+        ctx.save_for_backward(xb, wb, h)
+        ctx.has_b, ctx.x_dtype = b is not None, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb, h = ctx.saved_tensors
+        dh, db = ops.dense_gelu_bwd(h, _c(gy.to(h.dtype)), want_colsum=ctx.has_b)
+        g2, x2 = dh.reshape(-1, wb.shape[0]), xb.reshape(-1, wb.shape[1])
+        with torch.autocast("cuda", enabled=False):
+            gx = (g2 @ wb).view(xb.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+            gw = (g2.t() @ x2).float()
+        return gx, gw, db, None
+
+
 class LinearScaleResidualFn(torch.autograd.Function):
     """Tail of a standard block branch:  out = x + rs * gamma * (a W^T + b)  with x the f32 residual stream, a the
     compute-dtype branch activations, gamma the layer scale [d] and rs the per-sample stochastic-depth factor

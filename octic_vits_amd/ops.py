@@ -504,3 +504,23 @@ def scale_residual_bwd(gout, y, gamma, rs, rps, want_gamma=True, want_colsum=Tru
     colsum = torch.empty(d, dtype=torch.float32, device=gout.device) if want_colsum else None
     check(lib().octic_dense_finish(_p(partials), nblk, d, _p(dgamma), _p(colsum), _p(gamma), _stream(gout)))
     return gy, dgamma, colsum
+
+
+def dense_gelu_bwd(h, g, want_colsum=True):
+    """dh = gelu'(h) * g for bf16 [..., d]; also the column sums of dh (f32 [d]) when asked."""
+    _require_cuda(h)
+    d = h.shape[-1]
+    rows = h.numel() // d
+    dh = torch.empty_like(h)
+    nblk = lib().octic_dense_gelu_blocks()
+    partials = torch.empty((nblk, d), dtype=torch.float32, device=h.device) if want_colsum else None
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_gelu_bwd(_p(h), _p(g), _p(dh), _p(partials), rows, d, _stream(h)))
+    KERNEL_TIMER.stop(t, "dense_gelu_bwd_kernel", rows * d * 6)
+    if not want_colsum:
+        return dh, None
+    out = torch.empty(d, dtype=torch.float32, device=h.device)
+    half = d // 2
+    check(lib().octic_dense_finish(_p(partials), nblk, half, _p(out), ctypes.c_void_p(out.data_ptr() + 4 * half),
+                                   _p(None), _stream(h)))
+    return dh, out

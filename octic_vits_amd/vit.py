@@ -49,8 +49,10 @@ class Mlp(nn.Module):
 
     def forward_fused(self, y, xres, gamma, rs, dtype):
         """xres + rs*gamma*fc2(gelu(fc1(y))) with y already normalised and in the compute dtype."""
-        h = _OF.DenseLinearFn.apply(y, self.fc1.weight, self.fc1.bias, dtype, self._c1)
-        h = F.gelu(h)
+        if dtype == torch.bfloat16 and self.fc1.out_features % 8 == 0:
+            h = _OF.DenseLinearGeluFn.apply(y, self.fc1.weight, self.fc1.bias, self._c1)
+        else:
+            h = F.gelu(_OF.DenseLinearFn.apply(y, self.fc1.weight, self.fc1.bias, dtype, self._c1))
         return _OF.LinearScaleResidualFn.apply(xres, h, self.fc2.weight, self.fc2.bias, gamma, rs, y.shape[1], dtype,
                                                self._c2)
 

@@ -166,3 +166,18 @@ def test_fused_block_is_skipped_outside_its_regime():
     o.KERNEL_TIMER.disable()
     assert not any(n.startswith("dense_") for n in names)
     torch.testing.assert_close(y.cpu(), ref(x), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,d", [(1, 8), (37, 136), (514, 640), (16448, 5120)])
+def test_dense_gelu_bwd_and_bias_grad(rows, d):
+    """dh = gelu'(h) g (bf16 out: one rounding, 2^-8) and its column sums (reduction over rows: 1e-3 of scale)."""
+    h = gen(1, rows, d).bfloat16()
+    g = gen(2, rows, d).bfloat16()
+    h64 = h.double().requires_grad_(True)
+    F.gelu(h64).backward(g.double())
+    dh, db = ops().dense_gelu_bwd(h.to(DEV), g.to(DEV))
+    torch.testing.assert_close(dh.cpu().double(), h64.grad, rtol=2 ** -7, atol=2e-3)
+    # the bias gradient sums exactly the bf16 values the downstream GEMMs consume
+    torch.testing.assert_close(db.cpu().double(), dh.cpu().double().sum(0), rtol=1e-4, atol=1e-3 * float(rows) ** 0.5)
+    dh2, db2 = ops().dense_gelu_bwd(h.to(DEV), g.to(DEV), want_colsum=False)
+    assert db2 is None and torch.equal(dh2, dh)
