@@ -346,6 +346,7 @@ __device__ inline void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt nee
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
     case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
@@ -359,14 +360,22 @@ __device__ inline void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt nee
   }
 }
 
-template <typename TIN, typename TOUT, int EPI>
+// NT = 16-column MFMA tiles per wave (tile width BN = 16 NT: 80 or 160), S = ring stages.  The wide tile (NT = 10,
+// S = 2: 72 KiB, still two workgroups per CU) is for the long-K / narrow-N problems (fc2, input gradients of qkv and
+// fc1: N = 160 | 320): with 80-column tiles their X panel went through the L2->LDS path once per n-tile and each X
+// k-tile (16 KiB) fed only 20 MFMAs per wave - above the ~70 GB/s per CU that path sustains.
+template <typename TIN, typename TOUT, int EPI, int NT, int S>
 __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
   constexpr int EPC = Elem<TIN>::EPC;
   constexpr int BKE = 8 * EPC;
-  constexpr int NT = 5, MT = 2;
+  constexpr int MT = 2;
+  constexpr int BN = 16 * NT;
+  constexpr int STAGE = (kBM + BN) * 128;
+  constexpr int WI = BN / 8;                  // W DMA instructions per tile (8 rows each)
+  constexpr int WQ = (WI + 3) / 4;            // per wave, at most
   constexpr int NSTORE = NT * MT;             // store instructions per wave per epilogue
   typedef typename Elem<TIN>::frag frag;
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // kRingS stages x (128 + 80) rows x 128 B
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // S stages x (128 + BN) rows x 128 B
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -403,15 +412,16 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
     const int64_t off = G.pair ? (mm >> 1) * G.a_ld + (mm & 1) * (int64_t)K : mm * G.a_ld;
     xsrc[q] = G.a + off * (int64_t)sizeof(TIN);
   }
-  // W rows: 10 instructions over 4 waves: waves 0,1 take 3, waves 2,3 take 2
-  const int w_first = wid < 2 ? wid * 3 : 6 + (wid - 2) * 2;
-  const int w_cnt = wid < 2 ? 3 : 2;
+  // W rows: WI instructions over 4 waves (10: waves 0,1 take 3, waves 2,3 take 2; 20: 5 each)
+  const int w_rem = WI & 3;
+  const int w_cnt = WI / 4 + (wid < w_rem ? 1 : 0);
+  const int w_first = wid * (WI / 4) + (wid < w_rem ? wid : w_rem);
   const int dma_cnt = 4 + w_cnt;              // this wave's DMA instructions per step
-  const char* wsrc[3];
+  const char* wsrc[WQ];
   auto set_w = [&](int nt) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      int n = nt * kRingBN + (w_first + q) * 8 + drow;
+    for (int q = 0; q < WQ; ++q) {
+      int n = nt * BN + (w_first + q) * 8 + drow;
       n = n < N ? n : N - 1;
       wsrc[q] = G.w + (int64_t)n * K * (int64_t)sizeof(TIN);
     }
@@ -422,18 +432,18 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
     int k = l_kt * BKE + dkc * EPC;
     k = k < K ? k : 0;                        // chunks past K belong to a skipped k-step: any valid address
     const int kb = k * (int)sizeof(TIN);
-    char* st = lds + l_stage * kRingStage;
+    char* st = lds + l_stage * STAGE;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[q] + kb),
                                        (__attribute__((address_space(3))) void*)(st + (wid * 4 + q) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < WQ; ++q)
       if (q < w_cnt)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + kb),
                                          (__attribute__((address_space(3))) void*)(st + kBM * 128 + (w_first + q) * 1024),
                                          16, 0, 0);
-    l_stage = l_stage == kRingS - 1 ? 0 : l_stage + 1;
+    l_stage = l_stage == S - 1 ? 0 : l_stage + 1;
     if (++l_kt == nkt) {
       l_kt = 0;
       ++l_nt;
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
              has_res = EPI == 1 && G.resid != nullptr;
   int e_nt = nt_begin;
   auto epilogue = [&]() {
-    const int nb = e_nt * kRingBN + kg * 4;
+    const int nb = e_nt * BN + kg * 4;
     ++e_nt;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -508,16 +518,19 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
   // ---- ring.  VMEM program order per step s:  [wait tile s][barrier] DMA(s+2)  compute(s)  [stores if n-tile done]
   // so the ops younger than DMA(s) at the wait of step s are: stores(s-2)?, DMA(s+1), stores(s-1)?.
   issue();
-  if (steps > 1) issue();
+  if (S > 2 && steps > 1) issue();
   int c_kt = 0, c_stage = 0;
   int st1 = 0, st2 = 0;   // store instructions issued in step s-1 / s-2
   for (int s = 0; s < steps; ++s) {
+    // S = 3: DMA runs two tiles ahead (tile s+1 may still be in flight at this wait); S = 2: one tile ahead, so
+    // only the stores of step s-1 are younger than DMA(s)
     if (has_res) wait_vmcnt(0);               // residual loads have VGPR destinations: keep hipcc's own waits exact
-    else wait_vmcnt(s + 1 < steps ? dma_cnt + st1 + st2 : 0);
+    else if (S > 2) wait_vmcnt(s + 1 < steps ? dma_cnt + st1 + st2 : 0);
+    else wait_vmcnt(st1);
     __builtin_amdgcn_s_barrier();             // every wave's share of tile s has landed; the stage of tile s-1 is free
-    if (s + 2 < steps) issue();
-    const char* base = lds + c_stage * kRingStage;
-    c_stage = c_stage == kRingS - 1 ? 0 : c_stage + 1;
+    if (s + S - 1 < steps) issue();
+    const char* base = lds + c_stage * STAGE;
+    c_stage = c_stage == S - 1 ? 0 : c_stage + 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (ks == 1 && last_half_only && c_kt == nkt - 1) break;
@@ -880,12 +893,13 @@ int launch_xreg(GemmArgs& a, hipStream_t s) {
   return launch_xreg_k<TOUT, 10>(a, fused, t, s);
 }
 
-template <typename TIN, typename TOUT>
-int launch_ring(GemmArgs& a, hipStream_t s) {
+template <typename TIN, typename TOUT, int NT, int S>
+int launch_ring_nt(GemmArgs& a, hipStream_t s) {
+  constexpr int BN = 16 * NT;
   int t = 0;
   bool fused = a.rs != nullptr || a.lift_np > 0;
   for (int i = 0; i < a.ngroups; ++i) {
-    a.g[i].n_tiles = (a.g[i].N + kRingBN - 1) / kRingBN;
+    a.g[i].n_tiles = (a.g[i].N + BN - 1) / BN;
     a.g[i].m_tiles = (int)((a.g[i].rows + kBM - 1) / kBM);
     static const int target_steps = getenv("OCTIC_RING_STEPS") ? atoi(getenv("OCTIC_RING_STEPS")) : 1;
     const int bke = 128 / (int)sizeof(TIN);
@@ -899,17 +913,27 @@ int launch_ring(GemmArgs& a, hipStream_t s) {
     fused = fused || a.g[i].cs || a.g[i].resid;
   }
   a.total_tiles = t;
-  const size_t smem = (size_t)kRingS * kRingStage;
+  const size_t smem = (size_t)S * (kBM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 0, NT, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 1, NT, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipGetLastError();
     attr_done = true;
   }
-  if (fused) linear_d8_ring_kernel<TIN, TOUT, 1><<<t, 256, smem, s>>>(a);
-  else linear_d8_ring_kernel<TIN, TOUT, 0><<<t, 256, smem, s>>>(a);
+  if (fused) linear_d8_ring_kernel<TIN, TOUT, 1, NT, S><<<t, 256, smem, s>>>(a);
+  else linear_d8_ring_kernel<TIN, TOUT, 0, NT, S><<<t, 256, smem, s>>>(a);
   return launch_status();
+}
+
+template <typename TIN, typename TOUT>
+int launch_ring(GemmArgs& a, hipStream_t s) {
+  // wide tile when every group's N is a multiple of 160 and the problem is long in K (the X panel dominates)
+  static const int wide = getenv("OCTIC_RING_WIDE") ? atoi(getenv("OCTIC_RING_WIDE")) : 1;
+  bool ok = wide && sizeof(TIN) == 2 && a.lift_np == 0;
+  for (int i = 0; i < a.ngroups; ++i) ok = ok && (a.g[i].N % 160) == 0 && a.g[i].K >= 2 * a.g[i].N;
+  if (ok) return launch_ring_nt<TIN, TOUT, 10, 2>(a, s);
+  return launch_ring_nt<TIN, TOUT, 5, 3>(a, s);
 }
 
 inline bool ring_ok(const GemmArgs& a, int dtype) {
