@@ -54,6 +54,47 @@ __device__ inline bf16x8 tr_frag(const char* img, int row_bytes, int key0, int c
 inline int attn_rsk(int hd) { return hd * 2 + 16; }                       // K image row bytes (odd # of 16-B slots)
 inline int attn_rsv(int dp) { int r = dp * 2; return ((r / 4) % 32 == 0) ? r + 64 : r; }   // V image row bytes
 
+// Stage two row images (zero-filled beyond T rows / kcA, kcB source chunks per row) with all global loads of a batch
+// in flight before the first LDS store.  The s_memtime timeline showed 10-20k cycles (a third of the kernel) in
+// the one-load-one-store loops this replaces: every trip waited out a full HBM round trip.
+constexpr int kStageBatch = 5;
+__device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA, int64_t stA, int kcA, int wcA,
+                                          char* imgB, int rsB, const bf16* srcB, int64_t stB, int kcB, int wcB,
+                                          int T, int Tp, int tid, int nthr) {
+  // wc = chunks written per row (>= kc: the extra ones are zeros), kc = chunks that exist in the source row
+  const int totA = Tp * wcA, totB = Tp * wcB;
+  const int tot = totA > totB ? totA : totB;
+  for (int base = 0; base < tot; base += kStageBatch * nthr) {
+    u32x4 va[kStageBatch], vb[kStageBatch];
+#pragma unroll
+    for (int it = 0; it < kStageBatch; ++it) {
+      const int q = base + it * nthr + tid;
+      va[it] = u32x4{0, 0, 0, 0};
+      vb[it] = u32x4{0, 0, 0, 0};
+      if (q < totA) {
+        const int t = q / wcA, c = q - t * wcA;
+        if (t < T && c < kcA) va[it] = *(const u32x4*)(srcA + (int64_t)t * stA + c * 8);
+      }
+      if (q < totB) {
+        const int t = q / wcB, c = q - t * wcB;
+        if (t < T && c < kcB) vb[it] = *(const u32x4*)(srcB + (int64_t)t * stB + c * 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kStageBatch; ++it) {
+      const int q = base + it * nthr + tid;
+      if (q < totA) {
+        const int t = q / wcA, c = q - t * wcA;
+        *(u32x4*)(imgA + (size_t)t * rsA + c * 16) = va[it];
+      }
+      if (q < totB) {
+        const int t = q / wcB, c = q - t * wcB;
+        *(u32x4*)(imgB + (size_t)t * rsB + c * 16) = vb[it];
+      }
+    }
+  }
+}
+
 // ---- work split ------------------------------------------------------------------------------------------------
 // The sequence is cut into nt = ceil(T/32) tiles.  A wave owns one tile of its own dimension (queries in the forward
 // and dq kernels, keys in the dkv kernel) and loops over all tiles of the other one.  Nine tiles (T = 257: 16x16
@@ -61,6 +102,22 @@ inline int attn_rsv(int dp) { int r = dp * 2; return ((r / 4) % 32 == 0) ? r + 6
 // registers.  Instead eight waves (two per SIMD, 256 registers) own tiles 0-7 and share the ninth: each wave runs
 // it against its 1-2 tiles of the other dimension and the partial results are combined through LDS (the K/V images
 // are dead by then).
+#ifdef OCTIC_ATTN_TRACE
+// developer-only timeline (build with -DOCTIC_ATTN_TRACE): [kernel 0 fwd / 1 dq / 2 dkv][256 workgroups][10 waves][16]
+__device__ unsigned long long g_attn_trace[3 * 256 * 10 * 16];
+extern "C" void* octic_dbg_attn_trace(void) {
+  void* p = nullptr;
+  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_attn_trace));
+  return p;
+}
+#define ATRACE(kern, slot)                                                                              \
+  do {                                                                                                  \
+    if (blockIdx.x < 256 && (threadIdx.x & 63) == 0 && (slot) < 16)                                     \
+      g_attn_trace[(((kern) * 256 + blockIdx.x) * 10 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define ATRACE(kern, slot) do {} while (0)
+#endif
 constexpr int kAttnWaves = 8;
 inline int attn_waves(int nt) { return nt == kAttnWaves + 1 ? kAttnWaves : nt; }
 constexpr int kPartPad = 4;    // f32 row pad of the partial-result images (conflict-free 16-byte accesses)
@@ -218,30 +275,23 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
   float* lseb = a.lse ? a.lse + ((int64_t)b * a.H + h) * T : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
+  ATRACE(0, 0);
 
-  // ---- stage K and V of this head (zero-filled pads: padded keys are masked, padded V rows meet P = 0)
-  const int kc = hd / 8, vc = (DT * 32) / 8;
-  for (int q = tid; q < Tp * kc; q += blockDim.x) {
-    const int t = q / kc, c = q - t * kc;
-    u32x4 v = {0, 0, 0, 0};
-    if (t < T) v = *(const u32x4*)(kb + (int64_t)t * a.sT + c * 8);
-    *(u32x4*)(Ks + (size_t)t * rsk + c * 16) = v;
-  }
-  for (int q = tid; q < Tp * vc; q += blockDim.x) {
-    const int t = q / vc, c = q - t * vc;
-    u32x4 v = {0, 0, 0, 0};
-    if (t < T && c < kc) v = *(const u32x4*)(vb + (int64_t)t * a.sT + c * 8);
-    *(u32x4*)(Vs + (size_t)t * rsv + c * 16) = v;
-  }
+  // ---- this wave's query rows first (their loads overlap the staging), then K and V of this head (zero-filled
+  // pads: padded keys are masked, padded V rows meet P = 0)
   bf16x8 qf[KS], qfs[KS];                       // own query tile; the shared tile's rows are fetched up front too
   load_rows8<KS>(qf, qb, a.sT, wid, T, lane);
   if (nt != W) load_rows8<KS>(qfs, qb, a.sT, W, T, lane);
+  stage_two(Ks, rsk, kb, a.sT, hd / 8, hd / 8, Vs, rsv, vb, a.sT, hd / 8, (DT * 32) / 8, T, Tp, tid, blockDim.x);
+  ATRACE(0, 1);
   __syncthreads();
+  ATRACE(0, 2);
 
   f32x16 ot[DT];
   zero_acc<DT>(ot);
   float m = -INFINITY, l = 0.f;
   fwd_pass<KS, DT>(a, Ks, Vs, rsk, rsv, qf, 0, 1, nt, lane, m, l, ot);
+  ATRACE(0, 3);
   l += __shfl_xor(l, 32, 64);
   {
     const int qi = wid * 32 + r;
@@ -250,6 +300,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
       store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half);
     }
   }
+  ATRACE(0, 4);
   if (nt == W) return;
 
   // ---- the shared last query tile: this wave's share of the keys, then a log-sum-exp merge of the W partials
@@ -325,16 +376,6 @@ struct AttnBwdArgs {
   float scale, scale_log2;
 };
 
-__device__ inline void stage_rows(char* img, int rs, const bf16* src, int64_t st, int T, int Tp, int kc, int tid, int nthr) {
-  for (int q = tid; q < Tp * kc; q += nthr) {
-    const int t = q / kc, c = q - t * kc;
-    u32x4 v = {0, 0, 0, 0};
-    if (t < T) v = *(const u32x4*)(src + (int64_t)t * st + c * 8);
-    *(u32x4*)(img + (size_t)t * rs + c * 16) = v;
-  }
-}
-
-// dQ^T of query tile `qtile` accumulated over key tiles kt0, kt0+kstep, ...; also writes delta for the tile if asked.
 // per-query operands of the dq kernel for one query tile: Q and dO fragments, log-sum-exp, delta = <dO, O>
 template <int KS>
 struct DqRows {
@@ -412,26 +453,34 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   bf16* dqb = a.dq + b * a.gB + h * a.gH;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
-  stage_rows(Ks, rs, a.k + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
-  stage_rows(Vs, rs, a.v + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
+  ATRACE(1, 0);
   DqRows<KS> mine, shared;                          // the shared tile's rows are fetched up front too
   load_dq_rows<KS>(mine, a, in_off, o_off, stat_off, wid, lane, true);
   if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane, wid == 0);
+  stage_two(Ks, rs, a.k + in_off, a.sT, hd / 8, hd / 8, Vs, rs, a.v + in_off, a.sT, hd / 8, hd / 8, T, Tp, tid,
+            blockDim.x);
+  ATRACE(1, 1);
   __syncthreads();
+  ATRACE(1, 2);
 
   f32x16 dqt[DT];
   zero_acc<DT>(dqt);
   dq_pass<KS, DT>(a, Ks, Vs, rs, mine, 0, 1, nt, lane, dqt);
+  ATRACE(1, 3);
   if (wid * 32 + r < T) store_rows<DT>(dqb + (int64_t)(wid * 32 + r) * a.gT, dqt, a.scale, hd, half);
+  ATRACE(1, 4);
   if (nt == W) return;
 
   zero_acc<DT>(dqt);
   dq_pass<KS, DT>(a, Ks, Vs, rs, shared, wid, W, nt, lane, dqt);
+  ATRACE(1, 5);
   __syncthreads();
+  ATRACE(1, 6);
   float* parts = (float*)smem;
   store_partial<DT>(parts + (size_t)wid * 32 * (DT * 32 + kPartPad), dqt, lane, T - W * 32);
   __syncthreads();
   combine_store<DT>(parts, W, nullptr, nullptr, a.scale, dqb, a.gT, W * 32, T, hd, tid, blockDim.x);
+  ATRACE(1, 7);
 }
 
 // dK^T, dV^T of key tile `ktile` accumulated over query tiles qt0, qt0+qstep, ...
@@ -500,29 +549,36 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   bf16* dvb = a.dv + b * a.gB + h * a.gH;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
-  stage_rows(Qs, rs, a.q + in_off, a.sT, T, Tp, hd / 8, tid, blockDim.x);
-  stage_rows(Ds, rs, a.dout + o_off, a.oT, T, Tp, hd / 8, tid, blockDim.x);
+  ATRACE(2, 0);
+  stage_two(Qs, rs, a.q + in_off, a.sT, hd / 8, hd / 8, Ds, rs, a.dout + o_off, a.oT, hd / 8, hd / 8, T, Tp, tid,
+            blockDim.x);
   for (int t = tid; t < Tp; t += blockDim.x) {
     const int64_t stat = ((int64_t)b * a.H + h) * T + t;
     lse_s[t] = t < T ? a.lse[stat] : INFINITY;    // padded queries: P = exp2(x - inf) = 0
     del_s[t] = t < T ? a.delta[stat] : 0.f;
   }
+  ATRACE(2, 1);
   __syncthreads();
+  ATRACE(2, 2);
 
   f32x16 dkt[DT], dvt[DT];
   zero_acc<DT>(dkt);
   zero_acc<DT>(dvt);
   dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, in_off, wid, 0, 1, nt, lane, dkt, dvt);
+  ATRACE(2, 3);
   if (wid * 32 + r < T) {
     store_rows<DT>(dkb + (int64_t)(wid * 32 + r) * a.gT, dkt, a.scale, hd, half);
     store_rows<DT>(dvb + (int64_t)(wid * 32 + r) * a.gT, dvt, 1.0f, hd, half);
   }
+  ATRACE(2, 4);
   if (nt == W) return;
 
   zero_acc<DT>(dkt);
   zero_acc<DT>(dvt);
   dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, in_off, W, wid, W, nt, lane, dkt, dvt);
+  ATRACE(2, 5);
   __syncthreads();
+  ATRACE(2, 6);
   float* parts = (float*)smem;
   float* mine = parts + (size_t)wid * 32 * (DT * 32 + kPartPad);
   store_partial<DT>(mine, dkt, lane, T - W * 32);
@@ -532,6 +588,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   store_partial<DT>(mine, dvt, lane, T - W * 32);
   __syncthreads();
   combine_store<DT>(parts, W, nullptr, nullptr, 1.0f, dvb, a.gT, W * 32, T, hd, tid, blockDim.x);
+  ATRACE(2, 7);
 }
 
 template <int KS, int DT>
