@@ -379,29 +379,39 @@ struct AttnBwdArgs {
 // per-query operands of the dq kernel for one query tile: Q and dO fragments, log-sum-exp, delta = <dO, O>
 template <int KS>
 struct DqRows {
-  bf16x8 qf[KS], dof[KS];
+  bf16x8 qf[KS], dof[KS], of[KS];
   float lse, delta;
 };
+// issue the loads only: the staging loads follow right behind, so the two memory round trips overlap ...
 template <int KS>
 __device__ __forceinline__ void load_dq_rows(DqRows<KS>& R, const AttnBwdArgs& a, int64_t in_off, int64_t o_off,
-                                             int64_t stat_off, int qtile, int lane, bool write_delta) {
+                                             int64_t stat_off, int qtile, int lane) {
   const int T = a.T;
   const int r = lane & 31, half = lane >> 5;
   const int qi = qtile * 32 + r;
   const int qc = qi < T ? qi : T - 1;
-  float delta = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     R.qf[ks] = *(const bf16x8*)(a.q + in_off + (int64_t)qc * a.sT + ks * 16 + half * 8);
     R.dof[ks] = *(const bf16x8*)(a.dout + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
-    const bf16x8 of = *(const bf16x8*)(a.o + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) delta += (float)R.dof[ks][j] * (float)of[j];
+    R.of[ks] = *(const bf16x8*)(a.o + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
   }
+  R.lse = a.lse[stat_off + qc];
+}
+// ... and delta = <dO, O> once everything has landed
+template <int KS>
+__device__ __forceinline__ void finish_dq_rows(DqRows<KS>& R, const AttnBwdArgs& a, int64_t stat_off, int qtile,
+                                               int lane, bool write_delta) {
+  const int r = lane & 31, half = lane >> 5;
+  const int qi = qtile * 32 + r;
+  float delta = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta += (float)R.dof[ks][j] * (float)R.of[ks][j];
   delta += __shfl_xor(delta, 32, 64);
   R.delta = delta;
-  R.lse = a.lse[stat_off + qc];
-  if (write_delta && qi < T && half == 0) a.delta[stat_off + qc] = delta;
+  if (write_delta && qi < a.T && half == 0) a.delta[stat_off + qi] = delta;
 }
 
 template <int KS, int DT>
@@ -455,10 +465,12 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   const int r = lane & 31, half = lane >> 5;
   ATRACE(1, 0);
   DqRows<KS> mine, shared;                          // the shared tile's rows are fetched up front too
-  load_dq_rows<KS>(mine, a, in_off, o_off, stat_off, wid, lane, true);
-  if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane, wid == 0);
+  load_dq_rows<KS>(mine, a, in_off, o_off, stat_off, wid, lane);
+  if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane);
   stage_two(Ks, rs, a.k + in_off, a.sT, hd / 8, hd / 8, Vs, rs, a.v + in_off, a.sT, hd / 8, hd / 8, T, Tp, tid,
             blockDim.x);
+  finish_dq_rows<KS>(mine, a, stat_off, wid, lane, true);
+  if (nt != W) finish_dq_rows<KS>(shared, a, stat_off, W, lane, wid == 0);
   ATRACE(1, 1);
   __syncthreads();
   ATRACE(1, 2);
@@ -484,21 +496,30 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
 }
 
 // dK^T, dV^T of key tile `ktile` accumulated over query tiles qt0, qt0+qstep, ...
-template <int KS, int DT>
-__device__ __forceinline__ void dkv_pass(const AttnBwdArgs& a, const char* Qs, const char* Ds, const float* lse_s,
-                                         const float* del_s, int rs, int64_t in_off, int ktile, int qt0, int qstep,
-                                         int nt, int lane, f32x16 (&dkt)[DT], f32x16 (&dvt)[DT]) {
-  const int T = a.T;
-  const int r = lane & 31, half = lane >> 5;
-  // this wave's keys: lane (r, half) holds K[key][16 ks + 8 half ..] and V[key][..] = B operands (key on the lane)
-  const int ki = ktile * 32 + r;
-  const int kcl = ki < T ? ki : T - 1;
+// the wave's key rows: lane (r, half) holds K[key][16 ks + 8 half ..] and V[key][..] = B operands (key on the lane)
+template <int KS>
+struct KvRows {
   bf16x8 kf[KS], vf[KS];
+};
+template <int KS>
+__device__ __forceinline__ void load_kv_rows(KvRows<KS>& R, const AttnBwdArgs& a, int64_t in_off, int ktile, int lane) {
+  const int r = lane & 31, half = lane >> 5;
+  const int ki = ktile * 32 + r;
+  const int kcl = ki < a.T ? ki : a.T - 1;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    kf[ks] = *(const bf16x8*)(a.k + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
-    vf[ks] = *(const bf16x8*)(a.v + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
+    R.kf[ks] = *(const bf16x8*)(a.k + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
+    R.vf[ks] = *(const bf16x8*)(a.v + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
   }
+}
+
+template <int KS, int DT>
+__device__ __forceinline__ void dkv_pass(const AttnBwdArgs& a, const char* Qs, const char* Ds, const float* lse_s,
+                                         const float* del_s, int rs, const KvRows<KS>& R, int qt0, int qstep, int nt,
+                                         int lane, f32x16 (&dkt)[DT], f32x16 (&dvt)[DT]) {
+  const int r = lane & 31, half = lane >> 5;
+  const bf16x8 (&kf)[KS] = R.kf;
+  const bf16x8 (&vf)[KS] = R.vf;
   for (int qt = qt0; qt < nt; qt += qstep) {
     f32x16 x, dp;
 #pragma unroll
@@ -550,6 +571,8 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   ATRACE(2, 0);
+  KvRows<KS> kv;                                     // own key rows first: their round trip overlaps the staging
+  load_kv_rows<KS>(kv, a, in_off, wid, lane);
   stage_two(Qs, rs, a.q + in_off, a.sT, hd / 8, hd / 8, Ds, rs, a.dout + o_off, a.oT, hd / 8, hd / 8, T, Tp, tid,
             blockDim.x);
   for (int t = tid; t < Tp; t += blockDim.x) {
@@ -564,7 +587,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   f32x16 dkt[DT], dvt[DT];
   zero_acc<DT>(dkt);
   zero_acc<DT>(dvt);
-  dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, in_off, wid, 0, 1, nt, lane, dkt, dvt);
+  dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, kv, 0, 1, nt, lane, dkt, dvt);
   ATRACE(2, 3);
   if (wid * 32 + r < T) {
     store_rows<DT>(dkb + (int64_t)(wid * 32 + r) * a.gT, dkt, a.scale, hd, half);
@@ -575,7 +598,8 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
 
   zero_acc<DT>(dkt);
   zero_acc<DT>(dvt);
-  dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, in_off, W, wid, W, nt, lane, dkt, dvt);
+  load_kv_rows<KS>(kv, a, in_off, W, lane);
+  dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, kv, wid, W, nt, lane, dkt, dvt);
   ATRACE(2, 5);
   __syncthreads();
   ATRACE(2, 6);
