@@ -133,13 +133,17 @@ def main():
     ms = elapsed / args.steps * 1e3
     ips = world * args.batch * args.steps / elapsed
 
+    n_oct = model.octic_equi_break_layer
+    n_std = len(model.blocks) - n_oct
     if rank == 0:
         line = {
             "metric": "images/sec Hybrid Octic ViT-H/14 224² bf16 train step", "value": round(ips, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (randn images, multi-hot targets; random-init weights)",
-            "config": {"workload": f"{args.model} (16 octic + 16 standard blocks, drop_path 0.5) DeiT-III train step: "
+            "config": {"workload": f"{args.model} ({n_oct} octic + {n_std} standard blocks"
+                                   f"{', invariant hand-off' if getattr(model, 'invariant', False) else ''}, drop_path 0.5) "
+                                   "DeiT-III train step: "
                                    f"bf16-autocast fwd + bwd + LAMB + EMA, 224x224, batch {args.batch}/GPU "
                                    f"(BASELINE configs[1]), data parallel over {world} GPU(s)",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",

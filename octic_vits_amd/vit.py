@@ -58,14 +58,15 @@ class Mlp(nn.Module):
 
 
 class Attention(nn.Module):
-    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., fused_attn=True):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., fused_attn=True,
+                 proj_bias=True):
         super().__init__()
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.scale = qk_scale or head_dim ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
         self.proj_drop = nn.Dropout(proj_drop)
         self.fused_attn = fused_attn
         self._c1, self._c2 = _OF.DenseWeightCache(), _OF.DenseWeightCache()
@@ -196,3 +197,52 @@ class Block(nn.Module):
         x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
         x = x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
         return x
+
+
+MemEffAttention = Attention     # dinov2.layers.MemEffAttention: same parameters; the HIP core replaces xformers
+
+
+def drop_add_residual_stochastic_depth(x, residual_func, sample_drop_ratio: float = 0.0):
+    """dinov2/layers/block.py:113-140: residual branch on a random batch subset, added back scaled by b / subset."""
+    b = x.shape[0]
+    keep = max(int(b * (1 - sample_drop_ratio)), 1)
+    brange = torch.randperm(b, device=x.device)[:keep]
+    residual = residual_func(x[brange]).flatten(1)
+    return torch.index_add(x.flatten(1), 0, brange, residual.to(x.dtype), alpha=b / keep).view_as(x)
+
+
+class NestedTensorBlock(Block):
+    """dinov2.layers ``Block`` / ``NestedTensorBlock`` (dinov2/layers/block.py:43-111, 234-260), the standard block of
+    the DINOv2 octic models (octic_vits/dinov2_models.py:12,55).  Same parameter names as the timm block.  Eval and
+    drop_path <= 0.1 run through the fused engine path of ``Block``; drop_path > 0.1 in training uses the
+    reference's batch-subset stochastic depth.  A list of crop batches is processed crop by crop (attention never
+    mixes samples, so this equals the reference's packed xformers path)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, proj_bias=True, ffn_bias=True, drop=0.0,
+                 attn_drop=0.0, init_values=None, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 attn_class=None, ffn_layer=None, **kwargs):
+        super().__init__(dim, num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, proj_drop=drop, attn_drop=attn_drop,
+                         init_values=init_values, drop_path=drop_path, act_layer=act_layer, norm_layer=norm_layer)
+        if not proj_bias:
+            self.attn.proj.bias = None
+        if not ffn_bias:
+            self.mlp.fc1.bias = None
+            self.mlp.fc2.bias = None
+        self.sample_drop_ratio = drop_path
+
+    def _one(self, x):
+        if self.training and self.sample_drop_ratio > 0.1:
+            x = drop_add_residual_stochastic_depth(x, lambda t: self.ls1(self.attn(self.norm1(t))), self.sample_drop_ratio)
+            return drop_add_residual_stochastic_depth(x, lambda t: self.ls2(self.mlp(self.norm2(t))),
+                                                      self.sample_drop_ratio)
+        if self.training and self.sample_drop_ratio > 0.0:
+            x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
+            return x + self.drop_path1(self.ls2(self.mlp(self.norm2(x))))     # block.py:104 reuses drop_path1
+        return super().forward(x)
+
+    def forward(self, x_or_x_list):
+        if isinstance(x_or_x_list, torch.Tensor):
+            return self._one(x_or_x_list)
+        if isinstance(x_or_x_list, list):
+            return [self._one(x) for x in x_or_x_list]
+        raise AssertionError

@@ -911,6 +911,178 @@ class OcticVisionTransformer(nn.Module):
         return set(base + ["_orig_mod." + n for n in base])
 
 
+# ----------------------------------------------------------------------------------------------
+# DINOv2 entry points (octic_vits/dinov2_models.py) with the standard blocks of dinov2/layers/block.py
+# ----------------------------------------------------------------------------------------------
+def drop_add_residual_stochastic_depth(x, residual_func, sample_drop_ratio=0.0):
+    """dinov2/layers/block.py:113-140: the residual branch runs on a random subset of the batch and is added back
+    scaled by batch / subset (training with drop_path > 0.1)."""
+    b = x.shape[0]
+    keep = max(int(b * (1 - sample_drop_ratio)), 1)
+    brange = torch.randperm(b, device=x.device)[:keep]
+    residual = residual_func(x[brange]).flatten(1)
+    out = torch.index_add(x.flatten(1), 0, brange, residual.to(x.dtype), alpha=b / keep)
+    return out.view_as(x)
+
+
+class NestedTensorBlock(nn.Module):
+    """dinov2/layers/block.py:43-111, 234-260 (``Block`` / ``NestedTensorBlock``); same parameter names as the timm
+    block.  A list input (crops of different resolutions) is processed crop by crop: attention never mixes samples,
+    so this equals the reference's packed xformers path, which cannot run without xformers - **parity unpinned**."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, proj_bias=True, ffn_bias=True, drop=0.0,
+                 attn_drop=0.0, init_values=None, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 attn_class=None, ffn_layer=None, **_):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        if not proj_bias:
+            self.attn.proj.bias = None
+        self.ls1 = _LayerScale(dim, init_values) if init_values else nn.Identity()
+        self.drop_path1 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop,
+                       bias=ffn_bias)
+        self.ls2 = _LayerScale(dim, init_values) if init_values else nn.Identity()
+        self.drop_path2 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.sample_drop_ratio = drop_path
+
+    def _one(self, x):
+        attn = lambda t: self.ls1(self.attn(self.norm1(t)))
+        ffn = lambda t: self.ls2(self.mlp(self.norm2(t)))
+        if self.training and self.sample_drop_ratio > 0.1:
+            x = drop_add_residual_stochastic_depth(x, attn, self.sample_drop_ratio)
+            return drop_add_residual_stochastic_depth(x, ffn, self.sample_drop_ratio)
+        if self.training and self.sample_drop_ratio > 0.0:
+            x = x + self.drop_path1(attn(x))
+            return x + self.drop_path1(ffn(x))          # the reference reuses drop_path1 (block.py:104, "FIXME")
+        x = x + attn(x)
+        return x + ffn(x)
+
+    def forward(self, x_or_x_list):
+        if isinstance(x_or_x_list, torch.Tensor):
+            return self._one(x_or_x_list)
+        if isinstance(x_or_x_list, list):
+            return [self._one(x) for x in x_or_x_list]
+        raise AssertionError
+
+
+class OcticDinoVisionTransformer(OcticVisionTransformer):
+    """dinov2_models.py:41-267."""
+
+    def __init__(self, img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 num_register_tokens=0, drop_path_rate=0.0, octic_block_layers=NestedTensorBlockD8,
+                 standard_block_layers=NestedTensorBlock, invariant=False, **kwargs):
+        super().__init__(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depth=depth,
+                         num_heads=num_heads, mlp_ratio=mlp_ratio, num_register_tokens=0,
+                         octic_block_layers=octic_block_layers, standard_block_layers=standard_block_layers,
+                         drop_path_rate=drop_path_rate, invariant=invariant, qkv_bias=True, ffn_bias=True,
+                         proj_bias=True)
+        self.depth = depth
+        self.num_register_tokens = num_register_tokens
+        c = embed_dim // 8
+        g2 = img_size // patch_size // 2
+        self.cls_token = nn.ParameterList([nn.Parameter(torch.zeros(1, 1, c), requires_grad=(i == 0)) for i in range(8)])
+        self.pos_embed = nn.ParameterList([nn.Parameter(torch.empty(g2, g2, c)) for _ in range(6)])
+        assert num_register_tokens >= 0
+        self.register_tokens = (nn.ParameterList(
+            [nn.Parameter(torch.zeros(1, num_register_tokens, c), requires_grad=(i == 0)) for i in range(8)])
+            if num_register_tokens else None)
+        assert depth % 2 == 0, "depth should be even!"
+        self.chunked_blocks = False
+        self.mask_token = nn.ParameterList([nn.Parameter(torch.zeros(1, c), requires_grad=(i == 0)) for i in range(8)])
+        self.head = nn.Identity()
+        self.init_weights()
+
+    def init_weights(self):
+        std = 8 * 0.02
+        for p in self.pos_embed:
+            trunc_normal_(p, std=std * SQRT2_OVER_2)
+        nn.init.normal_(self.cls_token[0], std=1e-6)
+        if self.register_tokens is not None:
+            nn.init.normal_(self.register_tokens[0], std=1e-6)
+        for m in self.modules():                      # named_apply(init_weights_vit_timm): Linear layers only
+            if isinstance(m, nn.Linear):
+                trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def prepare_tokens_with_masks(self, x, masks=None):
+        B, _, h, w = x.shape
+        xs = convert_5tuple_to_8tuple(self.patch_embed(x))
+        if masks is not None:
+            xs = tuple(torch.where(masks.unsqueeze(-1), self.mask_token[i].to(xs[i].dtype).unsqueeze(0), xs[i])
+                       for i in range(8))
+        pos = isotypic_dim_interpolation(tuple(self.pos_embed), dim=0)
+        pos = interpolate_spatial_tuple(xs, pos, h, w, self.patch_embed.patch_size)
+        xs = tuple(t + v.flatten(0, 1) for t, v in zip(xs, pos))
+        xs = tuple(torch.cat((self.cls_token[i].expand(B, -1, -1), xs[i]), dim=1) for i in range(8))
+        if self.register_tokens is not None:
+            xs = tuple(torch.cat((xs[i][:, :1], self.register_tokens[i].expand(B, -1, -1), xs[i][:, 1:]), dim=1)
+                       for i in range(8))
+        return convert_8tuple_to_5tuple(xs)
+
+    def _hand_off(self, xs):
+        if self.invariant:
+            return self.invariant_proj(self.invariantization(xs))
+        return torch.cat(convert_5tuple_to_8tuple(xs), dim=-1)
+
+    def _out(self, x, masks):
+        x_norm = self.norm(x)
+        r = self.num_register_tokens
+        return {"x_norm_clstoken": x_norm[:, 0], "x_norm_regtokens": x_norm[:, 1:r + 1],
+                "x_norm_patchtokens": x_norm[:, r + 1:], "x_prenorm": x, "masks": masks}
+
+    def forward_features_list(self, x_list, masks_list):
+        xs = [self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)]
+        for blk in self.blocks[:self.depth // 2]:
+            xs = blk(xs)
+        x = [self._hand_off(t) for t in xs]
+        for blk in self.blocks[self.depth // 2:]:
+            x = blk(x)
+        return [self._out(t, m) for t, m in zip(x, masks_list)]
+
+    def forward_features(self, x, masks=None):
+        if isinstance(x, list):
+            return self.forward_features_list(x, masks)
+        xs = self.prepare_tokens_with_masks(x, masks)
+        for blk in self.blocks[:self.depth // 2]:
+            xs = blk(xs)
+        x = self._hand_off(xs)
+        for blk in self.blocks[self.depth // 2:]:
+            x = blk(x)
+        return self._out(x, masks)
+
+    def get_intermediate_layers(self, x, n=1, reshape=False, return_class_token=False, norm=True):
+        xs = self.prepare_tokens_with_masks(x)
+        total = len(self.blocks)
+        take = range(total - n, total) if isinstance(n, int) else n
+        assert all(i > self.depth // 2 for i in take), f"All block indices must be > half depth, got {take}"
+        for blk in self.blocks[:self.depth // 2]:
+            xs = blk(xs)
+        t = self._hand_off(xs)
+        outputs = []
+        for i, blk in enumerate(self.blocks[self.depth // 2:], start=self.depth // 2):
+            t = blk(t)
+            if i in take:
+                outputs.append(t)
+        assert len(outputs) == len(take), f"only {len(outputs)} / {len(take)} blocks found"
+        if norm:
+            outputs = [self.norm(o) for o in outputs]
+        cls = [o[:, 0] for o in outputs]
+        outputs = [o[:, 1 + self.num_register_tokens:] for o in outputs]
+        if reshape:
+            B, _, w, h = x.shape
+            p = self.patch_embed.patch_size
+            p = p[0] if isinstance(p, (tuple, list)) else p      # the reference divides by the tuple here (TypeError)
+            outputs = [o.reshape(B, w // p, h // p, -1).permute(0, 3, 1, 2).contiguous() for o in outputs]
+        return tuple(zip(outputs, cls)) if return_class_token else tuple(outputs)
+
+    def forward(self, *args, is_training=False, **kwargs):
+        ret = self.forward_features(*args, **kwargs)
+        return ret if is_training else self.head(ret["x_norm_clstoken"])
+
+
 _REGISTRY = {}
 
 
@@ -948,3 +1120,32 @@ def d8_inv_early_deit_huge_patch14(img_size=224, **kw):  # deit_models.py:42-56
 @register_model
 def d8_inv_early_deit_large_patch16(img_size=224, **kw):  # deit_models.py:58-72
     return _deit(img_size, 16, 1024, 24, 16, True, **kw)
+
+
+def _dinov2(patch_size, dim, depth, heads, invariant, num_register_tokens, kw):
+    from functools import partial
+    return OcticDinoVisionTransformer(
+        patch_size=patch_size, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4, invariant=invariant,
+        standard_block_layers=partial(NestedTensorBlock, init_values=1.0e-05),
+        octic_block_layers=partial(NestedTensorBlockD8, init_values=1.0e-05),
+        num_register_tokens=num_register_tokens, **kw)
+
+
+@register_model
+def hybrid_dinov2_vit_large_patch16(patch_size=16, num_register_tokens=0, **kw):  # dinov2_models.py:269-282
+    return _dinov2(patch_size, 1024, 24, 16, False, num_register_tokens, kw)
+
+
+@register_model
+def hybrid_dinov2_vit_huge_patch16(patch_size=16, num_register_tokens=0, **kw):  # dinov2_models.py:284-297
+    return _dinov2(patch_size, 1280, 32, 16, False, num_register_tokens, kw)
+
+
+@register_model
+def d8_inv_early_dinov2_vit_large_patch16(patch_size=16, num_register_tokens=0, **kw):  # dinov2_models.py:299-313
+    return _dinov2(patch_size, 1024, 24, 16, True, num_register_tokens, kw)
+
+
+@register_model
+def d8_inv_early_dinov2_vit_huge_patch16(patch_size=16, num_register_tokens=0, **kw):  # dinov2_models.py:315-329
+    return _dinov2(patch_size, 1280, 32, 16, True, num_register_tokens, kw)

@@ -34,6 +34,19 @@ def reference_namespace():
     return ns
 
 
+def dino_namespace():
+    """The reference's DINOv2 entry points (octic_vits/dinov2_models.py) and the dinov2.layers block they use."""
+    import importlib
+    from functools import partial
+    load_reference()
+    dm = importlib.import_module("octic_vits.dinov2_models")
+    ns = types.SimpleNamespace()
+    ns.OcticDinoVisionTransformer = dm.OcticDinoVisionTransformer
+    ns.NestedTensorBlockD8 = dm.BlockD8
+    ns.DinoBlock = partial(dm.Block, attn_class=dm.MemEffAttention)
+    return ns
+
+
 def main():
     torch.set_num_threads(8)
     ns = reference_namespace()
@@ -46,6 +59,14 @@ def main():
         print(f"{name:28s} {len(res):4d} arrays  {os.path.getsize(path) / 1024:8.1f} KiB")
     for name in cases.FUNC_CASES:
         res = cases.run_func_case(ns, name)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **res)
+        total += os.path.getsize(path)
+        print(f"{name:28s} {len(res):4d} arrays  {os.path.getsize(path) / 1024:8.1f} KiB")
+    import dino_cases
+    dns = dino_namespace()
+    for name in dino_cases.DINO_CASES:
+        res = dino_cases.run_dino_case(dns, name)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **res)
         total += os.path.getsize(path)

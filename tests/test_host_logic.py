@@ -90,3 +90,31 @@ def test_product_refuses_cpu_execution():
     xs = cases.tuple5("cpu", 2, 3, 8)
     with pytest.raises(RuntimeError, match="GPU only"):
         lin(xs)
+
+
+def test_dinov2_entrypoints_keep_the_reference_state_dict():
+    """OcticDinoVisionTransformer (dinov2_models.py:41-267): same parameter names / shapes as the oracle restatement
+    (itself pinned to the real class by tests/golden/dino_*.npz), factories registered under the reference's names,
+    hybrid_dinov2_vit_large_patch16 = 170,296,704 parameters (measured on the reference)."""
+    import torch
+    from functools import partial
+
+    from oracle import octic_ref as R
+    from octic_vits_amd import d8_layers, deit_models, dinov2_models, vit
+    kw = dict(img_size=32, patch_size=4, embed_dim=64, depth=4, num_heads=2, num_register_tokens=2)
+    a = dinov2_models.OcticDinoVisionTransformer(
+        **kw, octic_block_layers=partial(d8_layers.NestedTensorBlockD8, init_values=1e-5),
+        standard_block_layers=partial(vit.NestedTensorBlock, attn_class=vit.MemEffAttention, init_values=1e-5))
+    b = R.OcticDinoVisionTransformer(**kw, octic_block_layers=partial(R.NestedTensorBlockD8, init_values=1e-5),
+                                     standard_block_layers=partial(R.NestedTensorBlock, init_values=1e-5))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sorted(sa) == sorted(sb)
+    assert all(sa[k].shape == sb[k].shape for k in sa)
+    assert sorted(n for n, p in a.named_parameters() if p.requires_grad) == \
+        sorted(n for n, p in b.named_parameters() if p.requires_grad)
+    for name in ("hybrid_dinov2_vit_large_patch16", "hybrid_dinov2_vit_huge_patch16",
+                 "d8_inv_early_dinov2_vit_large_patch16", "d8_inv_early_dinov2_vit_huge_patch16"):
+        assert name in deit_models._LOCAL_REGISTRY
+    with torch.device("meta"):
+        big = deit_models.create_model("hybrid_dinov2_vit_large_patch16")
+    assert sum(p.numel() for p in big.parameters()) == 170296704

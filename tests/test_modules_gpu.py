@@ -150,3 +150,52 @@ def test_reference_state_dict_loads_into_product_model():
     with torch.no_grad():
         a, b = mine(img.cuda()).cpu(), ref(img)
     assert torch.allclose(a, b, atol=1e-3 * float(b.abs().max()), rtol=1e-3)
+
+
+# ---- DINOv2 entry points (first slice): product vs goldens from the real reference
+import dino_cases  # noqa: E402
+
+
+def _product_dino_ns():
+    import types
+    from functools import partial
+
+    from octic_vits_amd import d8_layers, dinov2_models, vit
+    ns = types.SimpleNamespace()
+    ns.OcticDinoVisionTransformer = dinov2_models.OcticDinoVisionTransformer
+    ns.NestedTensorBlockD8 = d8_layers.NestedTensorBlockD8
+    ns.DinoBlock = partial(vit.NestedTensorBlock, attn_class=vit.MemEffAttention)
+    return ns
+
+
+@pytest.mark.parametrize("name", list(dino_cases.DINO_CASES))
+def test_dino_fp32_matches_reference_golden(name):
+    """Forward (cls feature, feature dict with mask / register tokens, intermediate layers) within the north-star 1e-3;
+    parameter gradients by norm and strided sample."""
+    got = dino_cases.run_dino_case(_product_dino_ns(), name, device="cuda")
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    assert set(got) == set(want.files), sorted(set(got) ^ set(want.files))
+    for k in want.files:
+        w = want[k].astype(np.float64)
+        assert got[k].shape == w.shape, f"{name}:{k}"
+        if w.size == 0:
+            continue
+        scale = max(1.0, float(np.abs(w).max()))
+        assert np.allclose(got[k].astype(np.float64), w, rtol=1e-3, atol=1e-3 * scale), \
+            f"{name}:{k} max err {float(np.abs(got[k] - w).max()):.3e} (scale {scale:.3g})"
+
+
+def test_dino_list_forward_and_bf16():
+    """List-of-crops forward equals the per-crop forward; bf16 autocast stays within 5e-2 of the f32 features."""
+    m = dino_cases.build(_product_dino_ns(), dict(num_register_tokens=1, invariant=False)).cuda()
+    a, b = cases.randn("dino.list.a", 2, 3, 32, 32).cuda(), cases.randn("dino.list.b", 3, 3, 32, 32).cuda()
+    with torch.no_grad():
+        outs = m.forward_features([a, b], [None, None])
+        for o, x in zip(outs, (a, b)):
+            ref = m.forward_features(x)
+            for k in ("x_norm_clstoken", "x_norm_patchtokens", "x_prenorm"):
+                torch.testing.assert_close(o[k], ref[k], rtol=1e-5, atol=1e-5)
+        f32 = m.forward_features(a)["x_norm_patchtokens"]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            b16 = m.forward_features(a)["x_norm_patchtokens"].float()
+    assert float((b16 - f32).abs().max()) < 5e-2 * max(1.0, float(f32.abs().max()))

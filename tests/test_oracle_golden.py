@@ -64,3 +64,38 @@ def test_model_facts():
         assert len(list(m.parameters())) == int(facts[mname + ".tensors"][0])
         keys = sorted(m.state_dict().keys())
         assert zlib.crc32("\n".join(keys).encode()) == int(facts[mname + ".keys_crc"][0])
+
+
+# ---- DINOv2 entry points (first slice): goldens from the real OcticDinoVisionTransformer
+import types as _types
+
+import dino_cases
+
+
+def _oracle_dino_ns():
+    ns = _types.SimpleNamespace()
+    ns.OcticDinoVisionTransformer = octic_ref.OcticDinoVisionTransformer
+    ns.NestedTensorBlockD8 = octic_ref.NestedTensorBlockD8
+    ns.DinoBlock = octic_ref.NestedTensorBlock
+    return ns
+
+
+@pytest.mark.parametrize("name", list(dino_cases.DINO_CASES))
+def test_dino_case(name):
+    got = dino_cases.run_dino_case(_oracle_dino_ns(), name)
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    assert set(got) == set(want.files), sorted(set(got) ^ set(want.files))
+    for k in want.files:
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-4, atol=2e-4, err_msg=f"{name}:{k}")
+
+
+def test_dino_list_forward_equals_per_crop_forward():
+    """The reference's list path needs xformers (parity unpinned); what it computes is the per-crop forward."""
+    m = dino_cases.build(_oracle_dino_ns(), dict(num_register_tokens=1, invariant=False))
+    a, b = cases.randn("dino.list.a", 2, 3, 32, 32), cases.randn("dino.list.b", 3, 3, 32, 32)
+    with torch.no_grad():
+        outs = m.forward_features([a, b], [None, None])
+        for o, x in zip(outs, (a, b)):
+            ref = m.forward_features(x)
+            for k in ("x_norm_clstoken", "x_norm_patchtokens", "x_prenorm"):
+                torch.testing.assert_close(o[k], ref[k])
