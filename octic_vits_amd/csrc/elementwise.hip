@@ -1,6 +1,7 @@
 // HBM-bound elementwise / permutation kernels of the octic block engine (gfx950).
 // All of them move 16 bytes per lane per access (8 bf16 or 4+4 f32) over the token-row layout;
 // arithmetic is f32 in registers.  Roofline: HBM (bytes moved / 8 TB/s); see DESIGN.md.
+#include <stdlib.h>
 #include "octic_common.hpp"
 
 namespace octic {
@@ -475,7 +476,8 @@ template <typename T, int V, int DIR>
 static int heads_launch(View vv, HeadPtrs hp, int64_t B, int64_t T_, int H, int c, int n_s, hipStream_t s) {
   const int w = c / H, hd = 8 * w;
   const size_t row_bytes = (size_t)n_s * 8 * c * sizeof(T);
-  int TT = 8;
+  static const int tt_env = getenv("OCTIC_HEADS_TT") ? atoi(getenv("OCTIC_HEADS_TT")) : 4;   // 4 tokens = 30 KiB of LDS at ViT-H: five workgroups per CU (8: 78/90 us, 4: 61/45 us pack/unpack)
+  int TT = tt_env;
   while (TT > 1 && TT * row_bytes > 64 * 1024) TT >>= 1;
   if (TT * row_bytes > 160 * 1024) return OCTIC_ESHAPE;
   const size_t smem = TT * row_bytes;
