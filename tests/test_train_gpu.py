@@ -93,3 +93,41 @@ def test_weight_caches_follow_fused_optimizer():
                     setattr(m, k, type(v)())
         fresh = net(x).float()
     assert torch.equal(cached, fresh)
+
+
+def test_ddp_wrapped_trainer_matches_plain_trainer():
+    """The data-parallel path (DistributedDataParallel over RCCL, gradients as bucket views, fused LAMB reading the
+    bucket views, bf16 weight copies handed to the caches) on a one-rank process group: same losses as the plain
+    trainer.  More than one rank cannot run on a one-GPU box; tests/test_distributed_cpu.py covers world_size 2."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.train import Trainer, synthetic_batch
+    from octic_vits_amd.vit import Layer_scale_init_Block
+
+    def make():
+        torch.manual_seed(7)
+        return OcticVisionTransformer(img_size=56, patch_size=14, num_classes=100, embed_dim=128, depth=4, num_heads=4,
+                                      qkv_bias=True, drop_path_rate=0.0, octic_block_layers=Layer_scale_init_BlockD8,
+                                      standard_block_layers=Layer_scale_init_Block).cuda()
+
+    x, y = synthetic_batch(8, 100, "cuda", 11, img_size=56)
+    plain = Trainer(make())
+    want = [float(plain.step(x, y).detach()) for _ in range(4)]
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ddp = Trainer(make(), distributed=True, local_rank=0)
+        got = [float(ddp.step(x, y).detach()) for _ in range(4)]
+    finally:
+        dist.destroy_process_group()
+    assert got == pytest.approx(want, rel=1e-5, abs=1e-6)
+    assert want[-1] < want[0]
