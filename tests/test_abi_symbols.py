@@ -48,3 +48,12 @@ def test_ops_refuse_cpu_tensors():
     from octic_vits_amd import ops
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.pview(torch.zeros(2, 3, 64), 8)
+
+
+def test_every_exported_symbol_is_documented_for_integrators():
+    """INTEGRATION.md names, for every entry point of include/octic_hip.h, the reference code it stands in for."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [s for s in _lib.header_symbols() if s not in text]
+    assert not missing, missing
