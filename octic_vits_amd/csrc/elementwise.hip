@@ -466,6 +466,31 @@ __global__ __launch_bounds__(256) void linear_prep_kernel(PrepArgs a, T* wb, T* 
   }
 }
 
+// All layers' preparations in one launch (after an optimizer step): items sorted by block_begin.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_prep_batch_kernel(const octic_prep_item* __restrict__ items, int n_items) {
+  const int b = blockIdx.x;
+  int it = 0;
+  for (int i = 1; i < n_items; ++i)
+    if (b >= items[i].block_begin) it = i;
+  const octic_prep_item& I = items[it];
+  const int cin = I.cin, cout = I.cout;
+  T* wb = (T*)I.wb;
+  T* wt = (T*)I.wt;
+  const int64_t small = (int64_t)cin * cout;
+  const int64_t total = 8 * small;
+  for (int64_t idx = (int64_t)(b - I.block_begin) * 256 + threadIdx.x; idx < total; idx += (int64_t)I.block_count * 256) {
+    const int g = idx < 4 * small ? (int)(idx / small) : 4;
+    const int64_t base = g < 4 ? g * small : 4 * small;
+    const int K = g < 4 ? cin : 2 * cin, N = g < 4 ? cout : 2 * cout;
+    const int64_t loc = idx - base;
+    const int n = (int)(loc / K), k = (int)(loc - (int64_t)n * K);
+    const float v = I.w[g][loc];
+    if (wb) wb[idx] = (T)v;
+    if (wt) wt[base + (int64_t)k * N + n] = (T)(I.cs[g] ? I.cs[g][n] * v : v);
+  }
+}
+
 inline int grid_for(int64_t total) {
   int64_t g = (total + 255) / 256;
   const int64_t cap = 256 * 16;  // 16 blocks per CU, grid-stride beyond
@@ -629,6 +654,15 @@ int octic_linear_d8_prep(const float* const w32[5], const float* const cs[5], in
   const int grid = grid_for((int64_t)8 * cin * cout);
   if (dtype == OCTIC_F32) linear_prep_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(a, (float*)wb, (float*)wt, cin, cout);
   else if (dtype == OCTIC_BF16) linear_prep_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(a, (bf16*)wb, (bf16*)wt, cin, cout);
+  else return OCTIC_EDTYPE;
+  return launch_status();
+}
+
+int octic_linear_d8_prep_batch(const octic_prep_item* items_dev, int n_items, int total_blocks, int dtype, void* stream) {
+  if (!items_dev) return OCTIC_ENULL;
+  if (n_items <= 0 || total_blocks <= 0) return OCTIC_ESHAPE;
+  if (dtype == OCTIC_BF16) linear_prep_batch_kernel<bf16><<<total_blocks, 256, 0, (hipStream_t)stream>>>(items_dev, n_items);
+  else if (dtype == OCTIC_F32) linear_prep_batch_kernel<float><<<total_blocks, 256, 0, (hipStream_t)stream>>>(items_dev, n_items);
   else return OCTIC_EDTYPE;
   return launch_status();
 }

@@ -140,10 +140,15 @@ class WeightPrep:
     def __init__(self):
         self.key = None
         self.wb = self.wt = None
+        self.last = None            # (w5, cs5, dtype, cin, cout) of the latest call: what a PrepBatch needs
+
+    @staticmethod
+    def _key(w5, cs5, dtype):
+        return (dtype, tuple((w.data_ptr(), w._version) for w in w5),
+                None if cs5 is None else tuple((s.data_ptr(), s._version) for s in cs5))
 
     def get(self, w5, cs5, dtype, cin, cout):
-        key = (dtype, tuple((w.data_ptr(), w._version) for w in w5),
-               None if cs5 is None else tuple((s.data_ptr(), s._version) for s in cs5))
+        key = self._key(w5, cs5, dtype)
         if key != self.key:
             with torch.no_grad():
                 w32 = [_c(w.detach().float()) for w in w5]
@@ -151,7 +156,57 @@ class WeightPrep:
                 wb, self.wt = ops.linear_prep(w32, cs32, cin, cout, dtype, want_wb=(dtype != torch.float32))
                 self.wb = wb if wb is not None else w32   # f32: the master weights are the forward operand
             self.key = key
+        self.last = (w5, cs5, dtype, cin, cout)
         return self.wb, self.wt
+
+    def adopt(self, wb, wt):
+        """Copies produced elsewhere (PrepBatch) are current for the parameters' present versions."""
+        w5, cs5, dtype, _, _ = self.last
+        self.wb, self.wt = wb, wt
+        self.key = self._key(w5, cs5, dtype)
+
+
+class PrepBatch:
+    """All bf16 LinearD8 weight preparations of a model in ONE launch (octic_linear_d8_prep_batch), run by the fused
+    optimizer right after its update instead of 64 per-layer launches at the next forward."""
+
+    def __init__(self, preps):
+        import numpy as np
+        self.preps = [p for p in preps if p.last is not None and p.last[2] == torch.bfloat16
+                      and all(t.dtype == torch.float32 and t.is_contiguous() for t in p.last[0])
+                      and (p.last[1] is None or all(t.dtype == torch.float32 and t.is_contiguous() for t in p.last[1]))]
+        if not self.preps:
+            self.items = None
+            return
+        dev = self.preps[0].last[0][0].device
+        dt = np.dtype([("w", "<u8", 5), ("cs", "<u8", 5), ("wb", "<u8"), ("wt", "<u8"), ("cin", "<i4"), ("cout", "<i4"),
+                       ("block_begin", "<i4"), ("block_count", "<i4")])
+        tab = np.zeros(len(self.preps), dtype=dt)
+        self.bufs, blocks = [], 0
+        for i, p in enumerate(self.preps):
+            w5, cs5, dtype, cin, cout = p.last
+            n = 8 * cin * cout
+            wb = torch.empty(n, dtype=dtype, device=dev)
+            wt = torch.empty(n, dtype=dtype, device=dev)
+            self.bufs.append((ops.prep_views(wb, cin, cout, False), ops.prep_views(wt, cin, cout, True)))
+            cnt = max(1, min((n + 255) // 256, 128))
+            tab[i]["w"] = [t.data_ptr() for t in w5]
+            tab[i]["cs"] = [0] * 5 if cs5 is None else [t.data_ptr() for t in cs5]
+            tab[i]["wb"], tab[i]["wt"] = wb.data_ptr(), wt.data_ptr()
+            tab[i]["cin"], tab[i]["cout"] = cin, cout
+            tab[i]["block_begin"], tab[i]["block_count"] = blocks, cnt
+            blocks += cnt
+        self.total_blocks = blocks
+        self.items = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        self._keep = [p.last for p in self.preps]        # the parameters whose addresses are in the table
+
+    def run(self):
+        if self.items is None:
+            return
+        ops.check(ops.lib().octic_linear_d8_prep_batch(ops._p(self.items), len(self.preps), self.total_blocks,
+                                                       ops.dt_code(torch.bfloat16), ops._stream(self.items)))
+        for p, (wb, wt) in zip(self.preps, self.bufs):
+            p.adopt(wb, wt)
 
 
 class LinearD8Fn(torch.autograd.Function):

@@ -328,16 +328,17 @@ def linear_prep(w5, cs5, cin, cout, dtype, want_wb=True):
     wt = torch.empty(n, dtype=dtype, device=dev)
     check(lib().octic_linear_d8_prep(_arr5(w5), _arr5(cs5) if cs5 is not None else None, cin, cout, _p(wb), _p(wt),
                                      dt_code(dtype), _stream(w5[0])))
+    return prep_views(wb, cin, cout, False), prep_views(wt, cin, cout, True)
+
+
+def prep_views(flat, cin, cout, transposed):
+    """The five per-irrep matrices inside a flat prepared-weight buffer ([cout,cin] or, transposed, [cin,cout])."""
+    if flat is None:
+        return None
     small = cin * cout
-
-    def views(flat, transposed):
-        if flat is None:
-            return None
-        out = [flat[i * small:(i + 1) * small].view((cin, cout) if transposed else (cout, cin)) for i in range(4)]
-        out.append(flat[4 * small:].view((2 * cin, 2 * cout) if transposed else (2 * cout, 2 * cin)))
-        return out
-
-    return views(wb, False), views(wt, True)
+    out = [flat[i * small:(i + 1) * small].view((cin, cout) if transposed else (cout, cin)) for i in range(4)]
+    out.append(flat[4 * small:].view((2 * cin, 2 * cout) if transposed else (2 * cout, 2 * cin)))
+    return out
 
 
 def attn_fwd(q, k, v, scale):

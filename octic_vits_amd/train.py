@@ -80,7 +80,7 @@ class FusedLamb:
     CHUNK = 65536
 
     def __init__(self, param_groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0, ema_decay=None,
-                 shadow_layers=()):
+                 shadow_layers=(), prep_source=None):
         """shadow_layers: (nn.Linear, functional.DenseWeightCache) pairs; their weights/biases get a bf16 copy
         written by the update kernel itself, handed to the cache after every step (no per-step cast launches)."""
         from . import _lib
@@ -143,6 +143,9 @@ class FusedLamb:
         self.ws = torch.zeros(int(_lib.lib().octic_lamb_workspace_floats(self.ntensors, self.nchunks)),
                               dtype=torch.float32, device=dev)
         self.step_count = 0
+        # prep_source(): the functional.WeightPrep caches of the model's LinearD8 layers; once they have all been used
+        # (first forward) their per-layer preparation launches are replaced by one batched launch after each step
+        self._prep_source, self._prep_batch = prep_source, None
 
     @property
     def last_grad_norm(self):
@@ -189,6 +192,11 @@ class FusedLamb:
             tuple(self.params), tuple(p._version + 1 for p in self.params))
         for lin, cache, wb, bb in self._shadows:     # the bf16 copies written above are current for the new versions
             cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16)
+        if self._prep_source is not None:
+            if self._prep_batch is None:
+                from .functional import PrepBatch
+                self._prep_batch = PrepBatch(self._prep_source())
+            self._prep_batch.run()
 
 
 def param_groups_weight_decay(model, weight_decay, no_decay_names=()):
@@ -256,6 +264,12 @@ def library_gemm_layers(model):
     return out
 
 
+def octic_weight_preps(model):
+    """The functional.WeightPrep cache of every LinearD8 of the model."""
+    from .d8_layers import LinearD8
+    return [m._prep for m in model.modules() if isinstance(m, LinearD8)]
+
+
 class Trainer:
     def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
                  fused_optimizer=True, tuned_gemms=True):
@@ -270,7 +284,8 @@ class Trainer:
         groups = param_groups_weight_decay(model, weight_decay, model.no_weight_decay())
         if fused_optimizer:
             # LAMB and EMA in one fused step; it also refreshes the bf16 weights of the library-GEMM layers
-            self.optimizer = FusedLamb(groups, lr=lr, ema_decay=ema_decay, shadow_layers=library_gemm_layers(model))
+            self.optimizer = FusedLamb(groups, lr=lr, ema_decay=ema_decay, shadow_layers=library_gemm_layers(model),
+                                       prep_source=lambda: octic_weight_preps(model))
             self.ema = None
         else:
             self.optimizer = Lamb(groups, lr=lr, weight_decay=weight_decay)
