@@ -9,8 +9,8 @@
 
 namespace octic {
 
-constexpr int kDenseWaves = 8;          // waves per workgroup of the backward kernels
-constexpr int kDenseMaxBlocks = 512;    // partial-sum slabs per launch
+constexpr int kDenseWaves = 16;         // waves per workgroup of the backward kernels (16 x 256 = the same 4096 waves as 8 x 512, half the slabs)
+constexpr int kDenseMaxBlocks = 256;    // partial-sum slabs per launch
 
 template <typename T> struct Row4;
 template <> struct Row4<float> {
