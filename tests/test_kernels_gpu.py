@@ -139,7 +139,8 @@ def _linear_ref(xs, W, bias, resid=None, rs=None, cs=None, T=None):
     return ys
 
 
-LIN_SHAPES = [(2, 5, 8, 16), (2, 17, 16, 8), (3, 50, 48, 144), (2, 257, 160, 480), (1, 130, 160, 160), (2, 60, 640, 160)]
+LIN_SHAPES = [(2, 5, 8, 16), (2, 17, 16, 8), (3, 50, 48, 144), (2, 257, 160, 480), (1, 130, 160, 160), (2, 60, 640, 160),
+              (2, 197, 128, 384), (1, 197, 512, 128)]      # the last two: ViT-L/16 (c = 128) qkv and fc2 shapes
 
 
 @pytest.mark.parametrize("B,T,cin,cout", LIN_SHAPES)
