@@ -199,6 +199,14 @@ class PrepBatch:
         self.total_blocks = blocks
         self.items = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
         self._keep = [p.last for p in self.preps]        # the parameters whose addresses are in the table
+        self._ptrs = self._current_ptrs()
+
+    def _current_ptrs(self):
+        return tuple(t.data_ptr() for p in self.preps for t in (tuple(p.last[0]) + tuple(p.last[1] or ())))
+
+    def stale(self):
+        """True when a parameter was re-allocated since the table was built (the table holds raw addresses)."""
+        return self.items is not None and self._current_ptrs() != self._ptrs
 
     def run(self):
         if self.items is None:

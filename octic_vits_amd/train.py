@@ -173,6 +173,10 @@ class FusedLamb:
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = p.grad = g.float().contiguous()
             grads.append(g)
+        if self.step_count == 0 or (self.step_count & 63) == 0:      # the tables hold raw parameter addresses
+            if tuple(p.data_ptr() for p in self.params) != tuple(self.p_ptrs.tolist()):
+                raise RuntimeError("FusedLamb: a parameter was re-allocated after the optimizer was built "
+                                   "(move the model to its device before constructing the optimizer)")
         key = tuple(g.data_ptr() for g in grads)
         if key != self._g_key:
             self.g_ptrs.copy_(torch.tensor(key, dtype=torch.int64), non_blocking=False)
@@ -193,7 +197,7 @@ class FusedLamb:
         for lin, cache, wb, bb in self._shadows:     # the bf16 copies written above are current for the new versions
             cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16)
         if self._prep_source is not None:
-            if self._prep_batch is None:
+            if self._prep_batch is None or self._prep_batch.stale():
                 from .functional import PrepBatch
                 self._prep_batch = PrepBatch(self._prep_source())
             self._prep_batch.run()
