@@ -109,7 +109,8 @@ int octic_linear_d8_fwd(const octic_view* x, const void* const w[5], const float
 int octic_linear_d8_prep(const float* const w32[5], const float* const cs[5], int cin, int cout, void* wb, void* wt,
                          int dtype, void* stream);
 /* The same for many layers in ONE launch (after an optimizer step).  items_dev: device array sorted by block_begin;
- * item i owns workgroups [block_begin, block_begin + block_count) of the total_blocks launched; wb / wt / cs[] entries
+ * item i owns workgroups [block_begin, block_begin + block_count) of the total_blocks launched, with block_count =
+ * octic_linear_d8_prep_batch_blocks(cin, cout) (one 64 x 64 tile of one irrep's matrix each); wb / wt / cs[] entries
  * may be NULL as in octic_linear_d8_prep.                                                              */
 typedef struct octic_prep_item {
   const float* w[5];
@@ -119,6 +120,7 @@ typedef struct octic_prep_item {
   int32_t cin, cout;
   int32_t block_begin, block_count;
 } octic_prep_item;
+int octic_linear_d8_prep_batch_blocks(int cin, int cout);
 int octic_linear_d8_prep_batch(const octic_prep_item* items_dev, int n_items, int total_blocks, int dtype, void* stream);
 
 /* Output-tile width (32*NT) the launcher picks for this problem; the kernel instantiation that runs is

@@ -62,6 +62,7 @@ _PROTOS = {
     "octic_colsum_a1": (c_int, [VP, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "octic_cast_rowscale": (c_int, [VP, VP, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p]),
     "octic_linear_d8_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "octic_linear_d8_prep_batch_blocks": (c_int, [c_int, c_int]),
     "octic_linear_d8_prep_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "octic_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int,
                                c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_float, c_void_p]),

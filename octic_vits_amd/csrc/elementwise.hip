@@ -466,28 +466,55 @@ __global__ __launch_bounds__(256) void linear_prep_kernel(PrepArgs a, T* wb, T* 
   }
 }
 
-// All layers' preparations in one launch (after an optimizer step): items sorted by block_begin.
+// All layers' preparations in one launch (after an optimizer step): items sorted by block_begin.  A workgroup owns one
+// 64 x 64 tile of one irrep's [N,K] matrix: rows are read and the bf16 copy written along k (coalesced), the
+// transposed, layer-scaled copy is written along n out of an LDS tile (the per-layer kernel above scatters 2-byte
+// stores instead; fine for one layer, 0.4 ms for all 64).
+__host__ __device__ inline int prep_tiles(int cin, int cout) {
+  const int t1 = ((cout + 63) / 64) * ((cin + 63) / 64), te = ((2 * cout + 63) / 64) * ((2 * cin + 63) / 64);
+  return 4 * t1 + te;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void linear_prep_batch_kernel(const octic_prep_item* __restrict__ items, int n_items) {
+  __shared__ float tile[64][65];
   const int b = blockIdx.x;
   int it = 0;
   for (int i = 1; i < n_items; ++i)
     if (b >= items[i].block_begin) it = i;
   const octic_prep_item& I = items[it];
   const int cin = I.cin, cout = I.cout;
+  int lt = b - I.block_begin;
+  const int t1 = ((cout + 63) / 64) * ((cin + 63) / 64);
+  const int g = lt < 4 * t1 ? lt / t1 : 4;
+  lt -= g < 4 ? g * t1 : 4 * t1;
+  const int K = g < 4 ? cin : 2 * cin, N = g < 4 ? cout : 2 * cout;
+  const int kt = (K + 63) / 64;
+  const int n0 = (lt / kt) * 64, k0 = (lt % kt) * 64;
+  const int64_t base = (int64_t)(g < 4 ? g : 4) * cin * cout;
+  const float* w = I.w[g];
+  const float* cs = I.cs[g];
   T* wb = (T*)I.wb;
   T* wt = (T*)I.wt;
-  const int64_t small = (int64_t)cin * cout;
-  const int64_t total = 8 * small;
-  for (int64_t idx = (int64_t)(b - I.block_begin) * 256 + threadIdx.x; idx < total; idx += (int64_t)I.block_count * 256) {
-    const int g = idx < 4 * small ? (int)(idx / small) : 4;
-    const int64_t base = g < 4 ? g * small : 4 * small;
-    const int K = g < 4 ? cin : 2 * cin, N = g < 4 ? cout : 2 * cout;
-    const int64_t loc = idx - base;
-    const int n = (int)(loc / K), k = (int)(loc - (int64_t)n * K);
-    const float v = I.w[g][loc];
-    if (wb) wb[idx] = (T)v;
-    if (wt) wt[base + (int64_t)k * N + n] = (T)(I.cs[g] ? I.cs[g][n] * v : v);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int n = n0 + r, k = k0 + tx;
+    float v = 0.f;
+    if (n < N && k < K) {
+      v = w[(int64_t)n * K + k];
+      if (wb) wb[base + (int64_t)n * K + k] = (T)v;
+      if (cs) v *= cs[n];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (wt) {
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+      const int k = k0 + r, n = n0 + tx;
+      if (k < K && n < N) wt[base + (int64_t)k * N + n] = (T)tile[tx][r];
+    }
   }
 }
 
@@ -657,6 +684,8 @@ int octic_linear_d8_prep(const float* const w32[5], const float* const cs[5], in
   else return OCTIC_EDTYPE;
   return launch_status();
 }
+
+int octic_linear_d8_prep_batch_blocks(int cin, int cout) { return prep_tiles(cin, cout); }
 
 int octic_linear_d8_prep_batch(const octic_prep_item* items_dev, int n_items, int total_blocks, int dtype, void* stream) {
   if (!items_dev) return OCTIC_ENULL;

@@ -386,8 +386,18 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinArgs a) {
   const float s = G.cs ? G.cs[n] : 1.0f;
   float dot = 0.f;
   for (int k = lane * 4; k < G.K; k += 256) {
+    // slabs summed in a fixed order (bitwise reproducible), eight loads in flight at a time
     f32x4 v = {0, 0, 0, 0};
-    for (int sp = 0; sp < G.splits; ++sp) v += *(const f32x4*)(a.slabs + (int64_t)sp * a.slab_elems + G.slab_off + (int64_t)n * G.K + k);
+    const float* sp0 = a.slabs + G.slab_off + (int64_t)n * G.K + k;
+    int sp = 0;
+    for (; sp + 8 <= G.splits; sp += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(sp0 + (int64_t)(sp + u) * a.slab_elems);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; sp < G.splits; ++sp) v += *(const f32x4*)(sp0 + (int64_t)sp * a.slab_elems);
     if (G.cs) {
       const f32x4 w = *(const f32x4*)(G.w32 + (int64_t)n * G.K + k);
       dot += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];

@@ -189,7 +189,7 @@ class PrepBatch:
             wb = torch.empty(n, dtype=dtype, device=dev)
             wt = torch.empty(n, dtype=dtype, device=dev)
             self.bufs.append((ops.prep_views(wb, cin, cout, False), ops.prep_views(wt, cin, cout, True)))
-            cnt = max(1, min((n + 255) // 256, 128))
+            cnt = ops.lib().octic_linear_d8_prep_batch_blocks(cin, cout)   # one 64 x 64 tile per workgroup
             tab[i]["w"] = [t.data_ptr() for t in w5]
             tab[i]["cs"] = [0] * 5 if cs5 is None else [t.data_ptr() for t in cs5]
             tab[i]["wb"], tab[i]["wt"] = wb.data_ptr(), wt.data_ptr()
