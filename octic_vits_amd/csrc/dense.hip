@@ -211,8 +211,15 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
   const int cx = threadIdx.x & 15, gy = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + cx;
   float s = 0.f;
-  if (j < 2 * d)
-    for (int b = gy; b < nblocks; b += 16) s += partials[(long)b * 2 * d + j];
+  if (j < 2 * d) {
+    int b = gy;                                   // fixed summation order, four loads in flight
+    for (; b + 48 < nblocks; b += 64) {
+      const float t0 = partials[(long)b * 2 * d + j], t1 = partials[(long)(b + 16) * 2 * d + j],
+                  t2 = partials[(long)(b + 32) * 2 * d + j], t3 = partials[(long)(b + 48) * 2 * d + j];
+      s += t0; s += t1; s += t2; s += t3;
+    }
+    for (; b < nblocks; b += 16) s += partials[(long)b * 2 * d + j];
+  }
   red[gy][cx] = s;
   __syncthreads();
   if (gy == 0 && j < 2 * d) {

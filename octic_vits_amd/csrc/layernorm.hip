@@ -282,7 +282,17 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* partial
   if (j < 7 * c) {
     const int c0 = j < 6 * c ? j : D + (j - 6 * c);
     const int c1 = (j >= 4 * c && j < 6 * c) ? j + 2 * c : -1;
-    for (int b = bl; b < nblk; b += 16) {
+    int b = bl;                                   // fixed summation order, four slabs in flight
+    for (; b + 48 < nblk; b += 64) {
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* row = partials + (size_t)(b + 16 * u) * 2 * D;
+        t[u] = row[c0] + (c1 >= 0 ? row[c1] : 0.f);
+      }
+      s += t[0]; s += t[1]; s += t[2]; s += t[3];
+    }
+    for (; b < nblk; b += 16) {
       const float* row = partials + (size_t)b * 2 * D;
       s += row[c0] + (c1 >= 0 ? row[c1] : 0.f);
     }
