@@ -181,3 +181,20 @@ def test_dense_gelu_bwd_and_bias_grad(rows, d):
     torch.testing.assert_close(db.cpu().double(), dh.cpu().double().sum(0), rtol=1e-4, atol=1e-3 * float(rows) ** 0.5)
     dh2, db2 = ops().dense_gelu_bwd(h.to(DEV), g.to(DEV), want_colsum=False)
     assert db2 is None and torch.equal(dh2, dh)
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Negative OCTIC_E* codes, never a slower path: shapes the kernels do not cover, null tables."""
+    import ctypes
+
+    from octic_vits_amd import _lib
+    L = _lib.lib()
+    h = torch.zeros(4, 12, device=DEV, dtype=torch.bfloat16)          # d % 8 != 0
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.octic_dense_gelu_bwd(p(h), p(h), p(h), None, 4, 12, None) == -1          # OCTIC_ESHAPE
+    assert L.octic_dense_gelu_bwd(None, p(h), p(h), None, 4, 16, None) == -4          # OCTIC_ENULL
+    assert L.octic_linear_d8_prep_batch(None, 1, 1, 1, None) == -4
+    assert L.octic_linear_d8_prep_batch(p(h), 0, 1, 1, None) == -1
+    x = torch.zeros(4, 16, device=DEV)
+    assert L.octic_scale_residual_fwd(p(x), p(x), 7, None, None, 1, p(x), 4, 16, None) == -3   # OCTIC_EDTYPE
+    assert L.octic_linear_d8_prep_batch_blocks(160, 640) == 4 * 3 * 10 + 5 * 20
