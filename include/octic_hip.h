@@ -227,8 +227,13 @@ int octic_lift_wgrad(const void* patches, const void* dout, float* dw, float* wo
  * overwritten (they hold the update between the two passes).  Tables are device arrays: per-tensor
  * pointers p,g,m,v,ema (ema may be NULL), per-tensor weight decay, and a chunk list
  * (tensor id, element offset, length) with tensor_chunk_begin[ntensors+1] giving each tensor's chunk
- * range.  workspace: octic_lamb_workspace_floats() f32; workspace[1] holds the global grad norm after the
- * call (the number deit/engine.py:84 logs).  bf16_shadow (may be NULL; entries may be NULL): per-tensor bf16
+ * range.  workspace: octic_lamb_workspace_floats() f32, zero-initialised by the caller once; after the call
+ * workspace[1] = global grad norm (the number deit/engine.py:84 logs), workspace[2] = 1 if the step was SKIPPED
+ * because that norm is not finite (parameters, moments, EMA and bf16 copies untouched: the reference exits
+ * before optimizer.step() on a non-finite loss, deit/engine.py:67-71), workspace[3] = applied steps,
+ * workspace[6] = skipped steps so far.  step > 0: the bias-correction step t given by the host; step == 0: t is
+ * the device-side counter workspace[3] (+1 per applied step), so a hipGraph capture of the call replays
+ * correctly.  bf16_shadow (may be NULL; entries may be NULL): per-tensor bf16
  * buffers that receive a rounded copy of the updated parameter in the same pass - the compute-dtype weights
  * torch.autocast would otherwise re-cast at every use.                                              */
 int64_t octic_lamb_workspace_floats(int ntensors, int nchunks);

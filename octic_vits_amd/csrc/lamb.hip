@@ -55,23 +55,38 @@ __global__ __launch_bounds__(256) void lamb_gradsq_kernel(LambTables t, float* p
   if (threadIdx.x == 0) part_g2[ch] = s;
 }
 
-// scal[0] = clip multiplier (1 / max(1, gnorm / max_norm)), scal[1] = gnorm
-__global__ __launch_bounds__(256) void lamb_scalars_kernel(const float* part_g2, int nchunks, float max_norm, float* scal) {
+// scal[0] = clip multiplier (1 / max(1, gnorm / max_norm)), scal[1] = gnorm, scal[2] = 1 when this step is skipped
+// (non-finite gradient norm: parameters, moments, EMA and bf16 copies are left untouched; the reference exits before
+// optimizer.step() on a non-finite loss, deit/engine.py:67-71), scal[3] = number of applied steps (the device-side
+// step counter used when the host passes step = 0, so a captured hipGraph replays with the right bias correction),
+// scal[4] = 1 - beta1^t, scal[5] = 1 / sqrt(1 - beta2^t), scal[6] = number of skipped steps so far.
+__global__ __launch_bounds__(256) void lamb_scalars_kernel(const float* part_g2, int nchunks, float max_norm, float b1,
+                                                           float b2, int host_step, float* scal) {
   __shared__ float red[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < nchunks; i += 256) s += part_g2[i];
   s = block_sum(s, red);
   if (threadIdx.x == 0) {
     const float gn = sqrtf(s);
+    const bool ok = isfinite(gn);
     scal[1] = gn;
     scal[0] = (max_norm > 0.f && gn > max_norm) ? max_norm / gn : 1.0f;
+    scal[2] = ok ? 0.f : 1.f;
+    if (!ok) scal[6] += 1.f;
+    float t = host_step > 0 ? (float)host_step : scal[3] + (ok ? 1.f : 0.f);
+    if (host_step > 0 || ok) scal[3] = t;
+    t = t < 1.f ? 1.f : t;
+    scal[4] = 1.f - powf(b1, t);
+    scal[5] = 1.0f / sqrtf(1.f - powf(b2, t));
   }
 }
 
 __global__ __launch_bounds__(256) void lamb_stage1_kernel(LambTables t, const float* scal, float b1, float b2, float eps,
-                                                          float bc1, float rsqrt_bc2_inv, float* part_p2, float* part_u2) {
+                                                          float* part_p2, float* part_u2) {
   __shared__ float red[4];
   const int ch = blockIdx.x;
+  if (scal[2] != 0.f) return;                  // skipped step (uniform over the grid)
+  const float bc1 = scal[4], rsqrt_bc2_inv = scal[5];
   const int ti = t.chunk_tensor[ch];
   const int64_t off = t.chunk_off[ch];
   float* p = t.p[ti] + off;
@@ -135,8 +150,10 @@ __global__ __launch_bounds__(256) void lamb_ratio_kernel(LambTables t, int ntens
   ratio[ti] = (t.wd[ti] != 0.f && wn > 0.f && un > 0.f) ? wn / un : 1.0f;
 }
 
-__global__ __launch_bounds__(256) void lamb_stage2_kernel(LambTables t, const float* ratio, float lr, float ema_w) {
+__global__ __launch_bounds__(256) void lamb_stage2_kernel(LambTables t, const float* scal, const float* ratio, float lr,
+                                                          float ema_w) {
   const int ch = blockIdx.x;
+  if (scal[2] != 0.f) return;                  // skipped step: weights, EMA and bf16 copies stay as they are
   const int ti = t.chunk_tensor[ch];
   const int64_t off = t.chunk_off[ch];
   float* p = t.p[ti] + off;
@@ -180,28 +197,27 @@ int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const*
                     void* stream) {
   if (!p || !g || !m || !v || !wd || !chunk_tensor || !chunk_off || !chunk_len || !tensor_chunk_begin || !workspace)
     return OCTIC_ENULL;
-  if (ntensors <= 0 || nchunks <= 0 || step <= 0) return OCTIC_ESHAPE;
+  if (ntensors <= 0 || nchunks <= 0 || step < 0) return OCTIC_ESHAPE;
   LambTables t;
   t.p = (float* const*)p; t.g = (float* const*)g; t.m = (float* const*)m; t.v = (float* const*)v;
   t.ema = (float* const*)ema; t.shadow = (bf16* const*)bf16_shadow; t.wd = wd;
   t.chunk_tensor = chunk_tensor; t.chunk_off = chunk_off; t.chunk_len = chunk_len;
   t.tensor_chunk_begin = tensor_chunk_begin;
-  // workspace layout: [2] scalars | [nchunks] g2 | [nchunks] p2 | [nchunks] u2 | [ntensors] ratio
+  // workspace layout: [8] scalars (see lamb_scalars_kernel) | [nchunks] g2 | [nchunks] p2 | [nchunks] u2 | [ntensors] ratio
   float* scal = workspace;
-  float* g2 = scal + 4;
+  float* g2 = scal + 8;
   float* p2 = g2 + nchunks;
   float* u2 = p2 + nchunks;
   float* ratio = u2 + nchunks;
   hipStream_t s = (hipStream_t)stream;
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   lamb_gradsq_kernel<<<nchunks, 256, 0, s>>>(t, g2);
-  lamb_scalars_kernel<<<1, 256, 0, s>>>(g2, nchunks, max_grad_norm, scal);
-  lamb_stage1_kernel<<<nchunks, 256, 0, s>>>(t, scal, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), p2, u2);
+  lamb_scalars_kernel<<<1, 256, 0, s>>>(g2, nchunks, max_grad_norm, beta1, beta2, step, scal);
+  lamb_stage1_kernel<<<nchunks, 256, 0, s>>>(t, scal, beta1, beta2, eps, p2, u2);
   lamb_ratio_kernel<<<(ntensors + 255) / 256, 256, 0, s>>>(t, ntensors, p2, u2, ratio);
-  lamb_stage2_kernel<<<nchunks, 256, 0, s>>>(t, ratio, lr, ema ? 1.0f - ema_decay : 0.f);
+  lamb_stage2_kernel<<<nchunks, 256, 0, s>>>(t, scal, ratio, lr, ema ? 1.0f - ema_decay : 0.f);
   return launch_status();
 }
 
-int64_t octic_lamb_workspace_floats(int ntensors, int nchunks) { return 4 + 3 * (int64_t)nchunks + ntensors; }
+int64_t octic_lamb_workspace_floats(int ntensors, int nchunks) { return 8 + 3 * (int64_t)nchunks + ntensors; }
 
 }  // extern "C"

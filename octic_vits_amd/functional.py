@@ -511,6 +511,30 @@ class LinearScaleResidualFn(torch.autograd.Function):
         return gout, ga, gw, colsum, dgamma, None, None, None, None
 
 
+def invalidate_weight_caches(model):
+    """Drop every cached compute-dtype weight copy below ``model`` (LinearD8 ``WeightPrep``s, the standard half's
+    ``DenseWeightCache``s): the next forward re-casts from the master parameters.
+
+    The caches key on ``(data_ptr, tensor._version)``.  An optimizer that writes through ``p.data`` or raw pointers
+    (apex FusedLAMB — the reference recipe's optimizer — updates ``p.data`` in a multi-tensor kernel) does not bump
+    ``_version``, so such optimizers MUST call this after every step; ``track_optimizer`` installs it as a
+    step post-hook.  The repo's own ``FusedLamb`` advances the version counters itself."""
+    n = 0
+    for m in model.modules():
+        for attr in ("_prep", "_c1", "_c2"):
+            c = getattr(m, attr, None)
+            if isinstance(c, (WeightPrep, DenseWeightCache)):
+                c.key = None
+                n += 1
+    return n
+
+
+def track_optimizer(model, optimizer):
+    """Register ``invalidate_weight_caches(model)`` as a post-step hook of a torch.optim.Optimizer (any optimizer,
+    including ones that update ``p.data`` behind autograd's back).  Returns the hook handle."""
+    return optimizer.register_step_post_hook(lambda *_a, **_k: invalidate_weight_caches(model))
+
+
 # -------------------------------------------------------------------------------------- hand-off
 class HandoffCatFn(torch.autograd.Function):
     @staticmethod

@@ -131,6 +131,11 @@ class OcticVisionTransformer(nn.Module):
             x = F.dropout(x, p=float(self.dropout_rate), training=self.training)
         return self.head(x)
 
+    def invalidate_weight_caches(self):
+        """See functional.invalidate_weight_caches: required after an optimizer that updates ``p.data`` / raw
+        pointers (apex FusedLAMB) — such writes do not bump the version counters the bf16 weight caches key on."""
+        return OF.invalidate_weight_caches(self)
+
     @torch.jit.ignore
     def no_weight_decay(self):
         base_names = [f'pos_embed.{i}' for i in range(6)] + ['cls_token.0']

@@ -22,7 +22,7 @@ class Lamb(torch.optim.Optimizer):
     """LAMB as used by the reference recipe (timm/apex 'fusedlamb': grad-norm clipping to 1.0, bias-corrected
     Adam update + weight decay, per-tensor trust ratio).  Multi-tensor (torch._foreach) implementation."""
 
-    def __init__(self, params, lr=3e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.02, max_grad_norm=1.0):
+    def __init__(self, params, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02, max_grad_norm=1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm))
         self.last_grad_norm = None
 
@@ -32,6 +32,9 @@ class Lamb(torch.optim.Optimizer):
         norms = torch._foreach_norm(grads_all)
         gnorm = torch.linalg.vector_norm(torch.stack(norms))
         self.last_grad_norm = gnorm
+        if not bool(torch.isfinite(gnorm)):       # same guard as the fused step: a non-finite step changes nothing
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+            return
         mg = self.param_groups[0]["max_grad_norm"]
         clip = torch.clamp(gnorm / mg, min=1.0) if mg is not None else None
         for group in self.param_groups:
@@ -79,7 +82,7 @@ class FusedLamb:
 
     CHUNK = 65536
 
-    def __init__(self, param_groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0, ema_decay=None,
+    def __init__(self, param_groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, ema_decay=None,
                  shadow_layers=(), prep_source=None):
         """shadow_layers: (nn.Linear, functional.DenseWeightCache) pairs; their weights/biases get a bf16 copy
         written by the update kernel itself, handed to the cache after every step (no per-step cast launches)."""
@@ -143,6 +146,8 @@ class FusedLamb:
         self.ws = torch.zeros(int(_lib.lib().octic_lamb_workspace_floats(self.ntensors, self.nchunks)),
                               dtype=torch.float32, device=dev)
         self.step_count = 0
+        # bias-correction step counted on the device (skipped steps do not advance it; replayable from a hipGraph)
+        self.device_step = True
         # prep_source(): the functional.WeightPrep caches of the model's LinearD8 layers; once they have all been used
         # (first forward) their per-layer preparation launches are replaced by one batched launch after each step
         self._prep_source, self._prep_batch = prep_source, None
@@ -150,6 +155,11 @@ class FusedLamb:
     @property
     def last_grad_norm(self):
         return self.ws[1]
+
+    @property
+    def skipped_steps(self):
+        """Steps the kernels refused because the gradient norm was not finite (device counter; reading it syncs)."""
+        return int(self.ws[6].item())
 
     def ema_state(self):
         """EMA weights as {param index: tensor view} (same order as the parameters)."""
@@ -188,7 +198,8 @@ class FusedLamb:
             vp(self.p_ptrs), vp(self.g_ptrs), vp(self.m_ptrs), vp(self.v_ptrs), vp(self.e_ptrs), vp(self.wd),
             vp(self.chunk_tensor), vp(self.chunk_off), vp(self.chunk_len), vp(self.tensor_chunk_begin),
             self.ntensors, self.nchunks, vp(self.ws), float(self.lr), float(self.betas[0]), float(self.betas[1]),
-            float(self.eps), float(self.max_grad_norm or 0.0), self.step_count, float(self.ema_decay or 0.0),
+            float(self.eps), float(self.max_grad_norm or 0.0), 0 if self.device_step else self.step_count,
+            float(self.ema_decay or 0.0),
             vp(self.s_ptrs), stream))
         # the kernels wrote the parameters behind autograd's back: advance their version counters so that every
         # cache keyed on them (the compute-dtype weight copies of functional.WeightPrep) is refreshed
@@ -275,42 +286,88 @@ def octic_weight_preps(model):
 
 
 class Trainer:
+    """One DeiT-III iteration (deit/engine.py:43-87).  ``accum_steps`` micro-batches per optimizer step express the
+    reference's global batch on fewer GPUs (configs[2]: 2048 = 8 GPUs x 64 x 4 micro-batches; the reference ran
+    32 GPUs x 64, experiments/train_deit.py:7-12,66): gradients of the micro-batch mean losses are averaged, the
+    all-reduce runs once, in the last micro-batch's backward (``no_sync`` before).  ``opt_eps`` is the recipe's
+    ``--opt-eps`` (deit/main.py:68, default 1e-8, which timm forwards to apex FusedLAMB).  ``bf16_buckets`` halves
+    the all-reduce payload (DDP's bf16 compression hook: buckets are cast to bf16, summed, cast back)."""
+
     def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
-                 fused_optimizer=True, tuned_gemms=True):
+                 fused_optimizer=True, tuned_gemms=True, opt_eps=1e-8, accum_steps=1, bf16_buckets=False,
+                 autocast=True, check_every=1, device_type=None):
         self.raw_model = model
         self.tuned_gemms = use_tuned_gemms() if (tuned_gemms and torch.cuda.is_available()) else False
         self.model = model
+        self.accum_steps = int(accum_steps)
+        self.device_type = device_type or next(model.parameters()).device.type
+        self.autocast = autocast
+        self.check_every = max(1, int(check_every))
+        self._steps = 0
         if distributed:
             # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)
             self.model = nn.parallel.DistributedDataParallel(
-                model, device_ids=[local_rank], bucket_cap_mb=128, gradient_as_bucket_view=True,
-                find_unused_parameters=False, static_graph=False)
+                model, device_ids=[local_rank] if self.device_type == "cuda" else None, bucket_cap_mb=128,
+                gradient_as_bucket_view=True, find_unused_parameters=False, static_graph=False)
+            if bf16_buckets:
+                from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+                self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
         groups = param_groups_weight_decay(model, weight_decay, model.no_weight_decay())
         if fused_optimizer:
             # LAMB and EMA in one fused step; it also refreshes the bf16 weights of the library-GEMM layers
-            self.optimizer = FusedLamb(groups, lr=lr, ema_decay=ema_decay, shadow_layers=library_gemm_layers(model),
+            self.optimizer = FusedLamb(groups, lr=lr, eps=opt_eps, ema_decay=ema_decay,
+                                       shadow_layers=library_gemm_layers(model),
                                        prep_source=lambda: octic_weight_preps(model))
             self.ema = None
         else:
-            self.optimizer = Lamb(groups, lr=lr, weight_decay=weight_decay)
+            self.optimizer = Lamb(groups, lr=lr, eps=opt_eps, weight_decay=weight_decay)
             self.ema = ModelEma(model, ema_decay) if ema_decay else None
         self.criterion = nn.BCEWithLogitsLoss()
         self._pending_loss = None
 
+    def _forward_loss(self, samples, targets):
+        if self.autocast:
+            with torch.autocast(self.device_type, dtype=torch.bfloat16):
+                outputs = self.model(samples)
+                return self.criterion(outputs.float(), targets)
+        return self.criterion(self.model(samples).float(), targets)
+
     def step(self, samples, targets):
         self.model.train()
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            outputs = self.model(samples)
-            loss = self.criterion(outputs.float(), targets)
-        if self._pending_loss is not None and not math.isfinite(self._pending_loss.item()):
-            raise FloatingPointError("Loss is not finite, stopping training")   # engine.py:67-71, one step late
+        # engine.py:67-71 one step late (the host never blocks on the step in flight); the optimizer kernels refuse a
+        # non-finite step on their own, so the weights are still intact when this raises
+        self._steps += 1
+        if self._pending_loss is not None and self._steps % self.check_every == 0 \
+                and not math.isfinite(self._pending_loss.item()):
+            raise FloatingPointError("Loss is not finite, stopping training")
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        k = self.accum_steps
+        if k == 1:
+            loss = self._forward_loss(samples, targets)
+            loss.backward()
+        else:
+            xs, ys = samples.chunk(k), targets.chunk(k)
+            loss = None
+            for i, (x, y) in enumerate(zip(xs, ys)):
+                last = i == len(xs) - 1
+                ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and not last) else _null()
+                with ctx:
+                    li = self._forward_loss(x, y) / len(xs)
+                    li.backward()
+                loss = li.detach() if loss is None else loss + li.detach()
         self.optimizer.step()
         if self.ema is not None:
             self.ema.update(self.raw_model)
         self._pending_loss = loss.detach()
         return loss
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def init_distributed():
