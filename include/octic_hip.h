@@ -276,6 +276,24 @@ int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const f
 int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, void* stream);
 
+/* ---- hand-written dense bf16 GEMMs of the standard half -------------------------------------
+ * The four projections of the reference's standard block (deit/vit.py:14-56 Attention.qkv / .proj, timm Mlp fc1 / fc2
+ * used by Layer_scale_init_Block, deit/vit.py:90-134) and their input gradients are "NT" problems
+ *     C[M,N] = A[M,K] . B[N,K]^T          A, B bf16 with K contiguous (lda, ldb = row strides in elements),
+ * M token rows, f32 accumulation on v_mfma_f32_16x16x32_bf16, K % 128 == 0, N % 4 == 0.  `mode` selects the fused tail:
+ *   0 PLAIN : C = acc + bias                                   (qkv forward; input gradients: bias = NULL)
+ *   1 GELU  : C = acc + bias (pre-activation, kept for backward), C2 = gelu(C) exact erf (fc1 + nn.GELU, vit.py:131-134)
+ *   2 RESID : C = acc + bias (branch output, kept for d gamma),  OUT = X + rs[row / rows_per_sample] * gamma * C
+ *             = x + drop_path(gamma * f(x)) of deit/vit.py:131-134 with f32 residual stream X / OUT [M,N] dense
+ *   3 DGELU : C = gelu'(H) * acc   with H the saved pre-activation (fc2 input gradient fused with GELU backward)
+ * C / C2 / H are bf16 [M,N] with row stride ldc.  bias, gamma [N] f32 and rs f32 may be NULL.  workspace:
+ * octic_dense_gemm_workspace_bytes(M,N,K) bytes (split-K slabs of the last partial round of tiles + tickets).  */
+int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K);
+int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
+                        void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs,
+                        int64_t rows_per_sample, const float* X, float* OUT, const void* H, void* workspace,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -525,3 +525,45 @@ def dense_gelu_bwd(h, g, want_colsum=True):
     check(lib().octic_dense_finish(_p(partials), nblk, half, _p(out), ctypes.c_void_p(out.data_ptr() + 4 * half),
                                    _p(None), _stream(h)))
     return dh, out
+
+
+# ------------------------------------------------------------------------------------------ dense MFMA GEMMs
+_DG_WS = {}
+
+
+def _dense_ws(M, N, K, dev):
+    """Split-K workspace of one (M,N,K) problem, cached per stream-ordered use (launches on one stream are serial)."""
+    key = (M, N, K, dev)
+    ws = _DG_WS.get(key)
+    if ws is None:
+        ws = _DG_WS[key] = torch.empty(int(lib().octic_dense_gemm_workspace_bytes(M, N, K)), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def dense_gemm_ok(M, N, K):
+    return K % 128 == 0 and N % 4 == 0 and M > 0
+
+
+def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None):
+    """C[M,N] = a[M,K] @ b[N,K]^T on the hand-written MFMA kernel (csrc/dense_gemm.hip) with a fused tail:
+    mode 0 -> c ; 1 -> (c, gelu(c)) ; 2 -> (c, x + rs*gamma*c) ; 3 -> gelu'(h) * c.  a, b bf16 2-D, K contiguous."""
+    _require_cuda(a)
+    M, K = a.shape
+    N = b.shape[0]
+    if a.stride(1) != 1 or b.stride(1) != 1 or b.shape[1] != K:
+        raise ValueError("dense_gemm_nt: operands must be [M,K] / [N,K] with contiguous K")
+    c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    c2 = torch.empty_like(c) if mode == 1 else None
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device) if mode == 2 else None
+    ws = _dense_ws(M, N, K, a.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_gemm_nt(_p(a), _p(b), M, N, K, a.stride(0), b.stride(0), mode, _p(c), _p(c2), N, _p(bias),
+                                    _p(gamma), _p(rs), int(rps), _p(x), _p(out), _p(h), _p(ws), _stream(a)))
+    if t is not None:
+        nb = 2 * (M * K + N * K + M * N * (2 if mode in (1, 3) else 1)) + (8 * M * N if mode == 2 else 0)
+        KERNEL_TIMER.stop(t, name or f"dense_nt_kernel<{mode}>", nb, 2.0 * M * N * K)
+    if mode == 1:
+        return c, c2
+    if mode == 2:
+        return c, out
+    return c

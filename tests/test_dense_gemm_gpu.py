@@ -1,0 +1,98 @@
+"""Hand-written dense bf16 MFMA GEMM (csrc/dense_gemm.hip) through the C ABI vs torch fp32/fp64 matmul on the same
+bf16-rounded operands.  Tolerance: bf16 output (8-bit mantissa) of an f32-accumulated sum -> 1e-2 of the output scale
+(plus exact-path checks on integer-valued operands, where every product and partial sum is representable: bit exact)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from octic_vits_amd import ops as o
+    return o
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=DEV) * scale).to(dtype)
+
+
+def close(got, want, tol, msg):
+    got, want = got.double(), want.double()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, f"{msg}: max err {err:.3e} > {tol:g} x {scale:.3g}"
+
+
+# ViT-H standard block at B = 64 (M = 16448): forward (N,K) and input-gradient shapes; plus ragged edges
+FULL = [(16448, 3840, 1280), (16448, 1280, 1280), (16448, 5120, 1280), (16448, 1280, 5120), (16448, 1280, 3840)]
+SMALL = [(256, 256, 128), (300, 264, 256), (1000, 520, 384), (77, 1280, 1280), (4112, 1024, 1024), (513, 8, 128), (2000, 264, 192)]
+
+
+@pytest.mark.parametrize("M,N,K", SMALL + FULL)
+def test_dense_nt_plain(M, N, K):
+    o = ops()
+    a, b = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    bias = rnd((N,), 3, dtype=torch.float32)
+    c = o.dense_gemm_nt(a, b, 0, bias=bias)
+    want = a.double() @ b.double().t() + bias.double()
+    close(c, want, 1e-2, f"plain {M}x{N}x{K}")
+    c0 = o.dense_gemm_nt(a, b, 0)
+    close(c0, a.double() @ b.double().t(), 1e-2, f"plain no bias {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 256), (16448, 1280, 1280), (16448, 5120, 1280)])
+def test_dense_nt_integer_operands_bit_exact(M, N, K):
+    """Small-integer operands: products and f32 partial sums are exact, so any dropped / doubled K-slice, swapped
+    fragment or mis-addressed row shows up as a wrong integer (asymmetric operands, cdna guide 'A=I check')."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g, device=DEV).to(torch.bfloat16)
+    b = torch.randint(-2, 3, (N, K), generator=g, device=DEV).to(torch.bfloat16)
+    c = o.dense_gemm_nt(a, b, 0)
+    want = (a.float() @ b.float().t()).to(torch.bfloat16)
+    assert torch.equal(c, want), f"{int((c != want).sum())} wrong elements"
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 256), (16448, 5120, 1280)])
+def test_dense_nt_gelu(M, N, K):
+    o = ops()
+    a, b = rnd((M, K), 11), rnd((N, K), 12, K ** -0.5)
+    bias = rnd((N,), 13, dtype=torch.float32)
+    h, y = o.dense_gemm_nt(a, b, 1, bias=bias)
+    want = a.double() @ b.double().t() + bias.double()
+    close(h, want, 1e-2, "gelu: pre-activation")
+    assert torch.equal(y, torch.nn.functional.gelu(h.float()).to(torch.bfloat16)) or \
+        float((y.float() - torch.nn.functional.gelu(h.float())).abs().max()) <= 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,T", [(3 * 50, 264, 256, 50), (16448, 1280, 5120, 257), (16448, 1280, 1280, 257)])
+def test_dense_nt_resid(M, N, K, T):
+    o = ops()
+    a, b = rnd((M, K), 21), rnd((N, K), 22, K ** -0.5)
+    bias = rnd((N,), 23, dtype=torch.float32)
+    gamma = rnd((N,), 24, dtype=torch.float32) * 0.2 + 0.5
+    rs = (torch.rand(M // T, generator=torch.Generator().manual_seed(3)) > 0.5).float().to(DEV) * 2.0
+    x = rnd((M, N), 25, dtype=torch.float32)
+    y, out = o.dense_gemm_nt(a, b, 2, bias=bias, gamma=gamma, rs=rs, rps=T, x=x)
+    want_y = a.double() @ b.double().t() + bias.double()
+    close(y, want_y, 1e-2, "resid: branch")
+    want = x.double() + rs.double().repeat_interleave(T)[:, None] * gamma.double() * y.double()
+    close(out, want, 1e-5, "resid: stream (from the rounded branch)")
+    # no gamma / no rs variants
+    y2, out2 = o.dense_gemm_nt(a, b, 2, bias=None, gamma=None, rs=None, x=x)
+    close(out2, x.double() + y2.double(), 1e-5, "resid: plain residual")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 256), (16448, 5120, 1280)])
+def test_dense_nt_dgelu(M, N, K):
+    o = ops()
+    a, b = rnd((M, K), 31), rnd((N, K), 32, K ** -0.5)
+    h = rnd((M, N), 33)
+    d = o.dense_gemm_nt(a, b, 3, h=h)
+    g = (a.double() @ b.double().t()).to(torch.bfloat16)
+    hf = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(hf).backward(g.double())
+    close(d, hf.grad, 1e-2, "dgelu")

@@ -294,7 +294,11 @@ def test_two_rank_ddp_on_one_gpu(tmp_path, buckets):
     tol = 1e-4 if buckets == "f32" else 2e-2
     assert b["skipped"] == 0
     assert a["losses"] == pytest.approx(b["losses"], rel=tol, abs=tol)
-    assert torch.allclose(a["params"], b["params"], rtol=tol, atol=tol * 0.1), (a["params"] - b["params"]).abs().max()
+    # bf16-compressed buckets round every gradient to 8 bits: elements whose gradient is rounding noise (the K third
+    # of the qkv biases: exactly zero in exact arithmetic) are moved by Adam's normalisation by up to lr per step in a
+    # rounding-dependent direction -> 2 * lr * steps absolute for that mode
+    atol = 1e-5 if buckets == "f32" else 2 * 3e-3 * 3
+    assert torch.allclose(a["params"], b["params"], rtol=tol, atol=atol), (a["params"] - b["params"]).abs().max()
 
 
 @pytest.mark.timeout(900)
