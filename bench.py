@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--model", default="hybrid_deit_huge_patch14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dense-hip", default=None,
+                    help="developer A/B: comma list of standard-half GEMMs on csrc/dense_gemm.hip (default: functional.DENSE_HIP; 'none' = library)")
     args = ap.parse_args()
 
     from octic_vits_amd import ops
@@ -99,6 +101,9 @@ def main():
     from octic_vits_amd.train import Trainer, init_distributed, synthetic_batch
     import torch.distributed as dist
 
+    if args.dense_hip is not None:
+        from octic_vits_amd import functional as _OF
+        _OF.DENSE_HIP = set() if args.dense_hip == "none" else set(args.dense_hip.split(","))
     world, rank, local_rank = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

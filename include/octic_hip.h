@@ -276,6 +276,20 @@ int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const f
 int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, void* stream);
 
+/* bf16 operand copies of nn.Linear weights [N,K] for octic_dense_gemm_nt, all layers in one launch (what autocast's
+ * per-use weight casts amount to, deit/engine.py:56): wb = bf16(src) [N,K] (may be NULL) and wt = bf16(src)^T [K,N]
+ * (the input-gradient GEMM dX = dY W is then an NT problem too).  src is the f32 master or an existing bf16 copy
+ * (src_dtype).  block_begin = running sum of octic_dense_prep_batch_blocks(N, K) over the items.            */
+typedef struct octic_dense_prep_item {
+  const void* src;
+  void* wb;
+  void* wt;
+  int32_t N, K;
+  int32_t block_begin, pad;
+} octic_dense_prep_item;
+int octic_dense_prep_batch_blocks(int N, int K);
+int octic_dense_prep_batch(const octic_dense_prep_item* items_dev, int n_items, int total_blocks, int src_dtype, void* stream);
+
 /* ---- hand-written dense bf16 GEMMs of the standard half -------------------------------------
  * The four projections of the reference's standard block (deit/vit.py:14-56 Attention.qkv / .proj, timm Mlp fc1 / fc2
  * used by Layer_scale_init_Block, deit/vit.py:90-134) and their input gradients are "NT" problems

@@ -309,6 +309,45 @@ static inline int dense_blocks(long rows) {
     default: { constexpr int NV = 8; CALL; } break; \
   }
 
+// Compute-dtype copies of all nn.Linear weights of the standard half in ONE launch, run after the optimizer step:
+// wb = bf16(W) [N,K] (forward operand) and wt = bf16(W)^T [K,N] (operand of the input-gradient GEMM, which is then an
+// NT problem like the forward).  One 64 x 64 tile per workgroup, transposed through LDS.
+template <typename TS>
+__global__ __launch_bounds__(256) void dense_prep_batch_kernel(const octic_dense_prep_item* __restrict__ items, int n_items) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.x;
+  int it = 0;
+  for (int i = 1; i < n_items; ++i)
+    if (b >= items[i].block_begin) it = i;
+  const octic_dense_prep_item& I = items[it];
+  const int N = I.N, K = I.K;
+  const int lt = b - I.block_begin;
+  const int kt = (K + 63) / 64;
+  const int n0 = (lt / kt) * 64, k0 = (lt % kt) * 64;
+  const TS* w = (const TS*)I.src;
+  bf16* wb = (bf16*)I.wb;
+  bf16* wt = (bf16*)I.wt;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int n = n0 + r, k = k0 + tx;
+    float v = 0.f;
+    if (n < N && k < K) {
+      v = (float)w[(int64_t)n * K + k];
+      if (wb) wb[(int64_t)n * K + k] = (bf16)v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (wt) {
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+      const int k = k0 + r, n = n0 + tx;
+      if (k < K && n < N) wt[(int64_t)k * N + n] = (bf16)tile[tx][r];
+    }
+  }
+}
+
 }  // namespace octic
 
 using namespace octic;
@@ -411,6 +450,17 @@ int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, cons
     DENSE_NV_SWITCH(dense_nv(d), (scale_residual_bwd_kernel<float, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>(gout, (const float*)y, gamma, rs,
                                                      rows_per_scale, (float*)gy, partials, rows, d)));
   }
+  return launch_status();
+}
+
+int octic_dense_prep_batch_blocks(int N, int K) { return ((N + 63) / 64) * ((K + 63) / 64); }
+
+int octic_dense_prep_batch(const octic_dense_prep_item* items_dev, int n_items, int total_blocks, int src_dtype, void* stream) {
+  if (!items_dev) return OCTIC_ENULL;
+  if (n_items <= 0 || total_blocks <= 0) return OCTIC_ESHAPE;
+  if (src_dtype == OCTIC_F32) dense_prep_batch_kernel<float><<<total_blocks, 256, 0, (hipStream_t)stream>>>(items_dev, n_items);
+  else if (src_dtype == OCTIC_BF16) dense_prep_batch_kernel<bf16><<<total_blocks, 256, 0, (hipStream_t)stream>>>(items_dev, n_items);
+  else return OCTIC_EDTYPE;
   return launch_status();
 }
 

@@ -25,15 +25,36 @@
 // the tiles of that round are split along K over `split` workgroups each (f32 partial slabs + a ticket; the last
 // arriver of a tile reduces and runs the epilogue) - see dense_plan().
 #include <type_traits>
+#ifndef DG_DMA_IN_MMA
+#define DG_DMA_IN_MMA 0      // 0: DMA issued in the R interval (beside the partner's MFMAs); 1: mid-MFMA; 2: M start
+#endif
 #include "octic_common.hpp"
 
 namespace octic {
 
 constexpr int DG_BM = 256, DG_BN = 256, DG_BK = 64;
 constexpr int DG_UNIT = 128 * 128;            // bytes per unit
-constexpr int DG_SLOTS = 8;
-constexpr int DG_D = 6;                       // prefetch distance in units
-constexpr int DG_LDS = 8 * 128 * 144;         // max(ring 8 x 16 KiB, epilogue tiles 8 x 18 KiB)
+#ifndef DG_NSLOT
+#define DG_NSLOT 8
+#endif
+#ifndef DG_DIST
+#define DG_DIST 6
+#endif
+#ifndef DG_PRIO
+#define DG_PRIO 2       // measured on MI355X (A/B in one process): 2 > 0 > 1 by ~5 %
+#endif
+#ifndef DG_ABL
+#define DG_ABL 0
+#endif
+#ifndef DG_READS_FIRST
+#define DG_READS_FIRST 0
+#endif
+#ifndef DG_BALANCED
+#define DG_BALANCED 0    // 1: first row half of the next K-tile is read in phase 3 (reads 4/4/8/8 instead of 12/4/8/0)
+#endif
+constexpr int DG_SLOTS = DG_NSLOT;            // ring slots (10 x 16 KiB = all 160 KiB of the CU's LDS)
+constexpr int DG_D = DG_DIST;                 // prefetch distance in units: unit g+D is issued in R_g (D <= slots - 2)
+constexpr int DG_LDS = DG_SLOTS * DG_UNIT > 8 * 128 * 144 ? DG_SLOTS * DG_UNIT : 8 * 128 * 144;   // ring | 8 x 18 KiB epilogue tiles
 
 struct DgArgs {
   const bf16* A;      // [M, K], row stride lda
@@ -62,15 +83,61 @@ struct DgArgs {
 
 enum DgMode { DG_PLAIN = 0, DG_GELU = 1, DG_RESID = 2, DG_DGELU = 3 };
 
-__device__ inline void dg_wait_vmcnt(int n) {
+__device__ inline void dg_wait_vmcnt(int n) {      // n even, wave-uniform; anything unexpected drains (always safe)
   switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
+}
+
+#ifdef DG_TRACE
+// developer-only timeline (tools/dense_trace.py builds with -DDG_TRACE): s_memtime stamps of workgroup 0
+__device__ unsigned long long g_dg_trace[8 * 256];
+extern "C" void* octic_dbg_dense_trace(void) {
+  void* p = nullptr;
+  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_dg_trace));
+  return p;
+}
+#define DGT()                                                                                        \
+  do {                                                                                               \
+    if (blockIdx.x == 0 && lane == 0 && dgt_i < 256) g_dg_trace[wid * 256 + dgt_i++] = __builtin_readcyclecounter(); \
+    if (blockIdx.x == 0 && lane == 0 && dgt_i == 200) g_dg_trace[wid * 256 + 255] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define DGT() do {} while (0)
+#endif
+
+// GELU for the fused epilogues.  The epilogue runs after the main loop with nothing to hide its VALU work behind (one
+// workgroup per CU), and libm's erff costs ~40 instructions per element (~100 us for the 84 M elements of fc1).  erf by
+// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, one v_exp + one v_rcp + 6 fma) is far inside the bf16 output's 2^-9.
+__device__ inline float dg_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ inline float dg_gelu(float x) { return 0.5f * x * (1.0f + dg_erf(x * kSqrt1Over2)); }
+__device__ inline float dg_gelu_grad(float x) {
+  return 0.5f * (1.0f + dg_erf(x * kSqrt1Over2)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+template <int N>
+__device__ inline void dg_wait_imm() {
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int MODE>
@@ -82,6 +149,11 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const int wr = wid >> 2, wc = wid & 3;
   const bool hi = wr != 0;              // waves 4-7 run one barrier interval behind waves 0-3 (see the loop)
   const int fr = lane & 15, kg = lane >> 4;
+#ifdef DG_TRACE
+  int dgt_i = 0;
+  if (blockIdx.x == 0 && lane == 0) g_dg_trace[wid * 256 + 254] = __builtin_amdgcn_s_memrealtime();
+#endif
+  DGT();
 
   // ---- work item -> (tile, k-range)
   const int bid = blockIdx.x;
@@ -140,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr bool isA = KIND == 0 || KIND == 3;
     constexpr bool second = KIND >= 2;
-    char* dst = lds + (u_issue & (DG_SLOTS - 1)) * DG_UNIT + wid * 2048;
+    char* dst = lds + (u_issue % DG_SLOTS) * DG_UNIT + wid * 2048;
     const int so = kbase + (u_issue >> 2) * (DG_BK * 2) + (second ? (isA ? halfA : halfB) : 0);
     if constexpr (isA) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA, so, 0, 0);
@@ -160,7 +232,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const int a_row0 = wr * 64;          // unit rows of this wave inside units 0 / 3
   const int b_row0 = wc * 32;          // inside units 1 / 2
 
-  bf16x8 Af[2][2][4];                  // [row half][kstep][m-tile]
+  bf16x8 Af[1 + DG_BALANCED][2][4];    // [row half (one set unless DG_BALANCED)][kstep][m-tile]
   bf16x8 Bf[2][2][2];                  // [n-half][kstep][n-tile]
   f32x4 acc[2][2][4][2];               // [m-half][n-half][m-tile][n-tile]
 #pragma unroll
@@ -173,15 +245,21 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
         for (int q = 0; q < 2; ++q) acc[i][j][p][q] = f32x4{0, 0, 0, 0};
 
   auto readA = [&](int mh, int unit) {
-    const char* base = lds + (unit & (DG_SLOTS - 1)) * DG_UNIT + a_row0 * 128;
+#if DG_ABL & 2
+    if (unit > 3) return;
+#endif
+    const char* base = lds + (unit % DG_SLOTS) * DG_UNIT + a_row0 * 128;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      Af[mh][0][mi] = *(const bf16x8*)(base + mi * 2048 + rdo0);
-      Af[mh][1][mi] = *(const bf16x8*)(base + mi * 2048 + rdo1);
+      Af[mh * DG_BALANCED][0][mi] = *(const bf16x8*)(base + mi * 2048 + rdo0);
+      Af[mh * DG_BALANCED][1][mi] = *(const bf16x8*)(base + mi * 2048 + rdo1);
     }
   };
   auto readB = [&](int nh, int unit) {
-    const char* base = lds + (unit & (DG_SLOTS - 1)) * DG_UNIT + b_row0 * 128;
+#if DG_ABL & 2
+    if (unit > 3) return;
+#endif
+    const char* base = lds + (unit % DG_SLOTS) * DG_UNIT + b_row0 * 128;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       Bf[nh][0][ni] = *(const bf16x8*)(base + ni * 2048 + rdo0);
@@ -191,9 +269,14 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   // 16 MFMAs of one quadrant; the DMA of the next unit is issued from inside the block (the matrix pipe is busy for 16
   // cycles per MFMA, the issue slots in between are free), which keeps the R intervals short
   auto mma = [&](int mh, int nh, auto kind_c) {
+#if DG_DMA_IN_MMA == 2
+    if (u_issue < nunits) issue_unit(kind_c);     // right after the barrier, ahead of the MFMAs
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#if DG_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -201,14 +284,18 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
           acc[mh][nh][mi][ni] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[nh][ks][ni], Af[mh][ks][mi], acc[mh][nh][mi][ni], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[nh][ks][ni], Af[mh * DG_BALANCED][ks][mi], acc[mh][nh][mi][ni], 0, 0, 0);
+#if DG_DMA_IN_MMA
       if (ks == 0) {
         __builtin_amdgcn_sched_barrier(0);
         if (u_issue < nunits) issue_unit(kind_c);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
+#if DG_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -227,58 +314,124 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     int need = g + 2;
     need = need < nunits - 1 ? need : nunits - 1;
     const int ok = (u_issue - 1) - need;
-    if (ok == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ok == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (ok == DG_D - 2) dg_wait_imm<2 * (DG_D - 2)>();       // steady state: one compare
     else dg_wait_vmcnt(ok > 0 ? 2 * ok : 0);
   };
 
-  // ---- prologue: 6 units in flight; units 0, 1 landed before anyone reads
-  issue_unit(DG_IC(0));
-  issue_unit(DG_IC(1));
-  issue_unit(DG_IC(2));
-  issue_unit(DG_IC(3));
-  issue_unit(DG_IC(0));                // nkt >= 2: units 4, 5 exist
-  issue_unit(DG_IC(1));
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // ---- prologue: the whole ring in flight
+  // (a K range shorter than the ring simply has fewer units: the guards keep u_issue <= nunits)
+#define DG_PRO(i) if constexpr ((i) < DG_D) { if (u_issue < nunits) issue_unit(DG_IC((i) & 3)); }
+  DG_PRO(0) DG_PRO(1) DG_PRO(2) DG_PRO(3) DG_PRO(4) DG_PRO(5) DG_PRO(6) DG_PRO(7) DG_PRO(8) DG_PRO(9)
+#undef DG_PRO
+  {
+    // units 0, 1 landed before anyone reads.  Unit 0 of the first K-tile is read here by everybody (all later "first
+    // row half" units are read in phase 3 of the previous K-tile): with the ring completely in flight (D = slots) the
+    // slot of unit v is refilled in M_v, which is only safe because every unit is read in a phase < v.
+    const int ok = (u_issue - 1) - 1;
+    dg_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+#if DG_BALANCED
+    __builtin_amdgcn_s_barrier();
+    readA(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  }
   if (hi) __builtin_amdgcn_s_barrier();
 
-#pragma unroll 1
-  for (int t = 0; t < nkt; ++t) {
+  // One K-tile = four phases.  STEADY: every unit issued here exists and the ring is full, so the DMA issue and the
+  // landed-wait need no conditions (one immediate vmcnt); the last K-tiles of the range take the guarded path.
+  auto ktile = [&](int t, auto steady_c) {
+    constexpr bool STEADY = decltype(steady_c)::value != 0;
     const int u0 = 4 * t;
-    // phase 0: first row half x first column half   (reads per R interval: 4 / 4 / 8 / 8)
+    auto dma = [&](auto kind_c) {
+#if DG_ABL & 1   // timing-only ablation: no DMA in the loop (results are garbage)
+      ++u_issue;
+#else
+      if (STEADY || u_issue < nunits) issue_unit(kind_c);
+#endif
+    };
+    auto landed = [&]() {
+#if DG_ABL & 1
+      return;
+#endif
+      if constexpr (STEADY) dg_wait_imm<2 * (DG_D - 2)>();
+      else wait_landed();
+    };
+#if DG_PRIO == 2    // the R interval (DMA issue + LDS reads) is the long one: give IT the issue priority
+#define DG_RP(x) do { __builtin_amdgcn_s_setprio(x); } while (0)
+#else
+#define DG_RP(x) do {} while (0)
+#endif
+#if DG_READS_FIRST
+#define DG_R(q, reads) do { DG_RP(2); reads; dma(DG_IC(((q) + DG_D) & 3)); DG_RP(0); } while (0)
+#else
+#define DG_R(q, reads) do { DG_RP(2); dma(DG_IC(((q) + DG_D) & 3)); reads; DG_RP(0); } while (0)
+#endif
+    // phase 0: first row half x first column half
     __builtin_amdgcn_s_barrier();
-    if (t == 0) readA(0, 0);
-    readB(0, u0 + 1);
-    if (hi) wait_landed();
+    DGT();
+#if DG_BALANCED
+    DG_R(0, readB(0, u0 + 1));
+#else
+    DG_R(0, readA(0, u0); readB(0, u0 + 1));
+#endif
+    if (hi) landed();
+    DGT();
     __builtin_amdgcn_s_barrier();
-    mma(0, 0, DG_IC(2));
-    if (!hi) wait_landed();
+    DGT();
+    mma(0, 0, DG_IC((0 + DG_D) & 3));
+    DGT();
+    if (!hi) landed();
     ++g;
     // phase 1: first row half x second column half
     __builtin_amdgcn_s_barrier();
-    readB(1, u0 + 2);
-    if (hi) wait_landed();
+    DGT();
+    DG_R(1, readB(1, u0 + 2));
+    if (hi) landed();
+    DGT();
     __builtin_amdgcn_s_barrier();
-    mma(0, 1, DG_IC(3));
-    if (!hi) wait_landed();
+    DGT();
+    mma(0, 1, DG_IC((1 + DG_D) & 3));
+    DGT();
+    if (!hi) landed();
     ++g;
     // phase 2: second row half x second column half
     __builtin_amdgcn_s_barrier();
-    readA(1, u0 + 3);
-    if (hi) wait_landed();
+    DGT();
+    DG_R(2, readA(1, u0 + 3));
+    if (hi) landed();
+    DGT();
     __builtin_amdgcn_s_barrier();
-    mma(1, 1, DG_IC(0));
-    if (!hi) wait_landed();
+    DGT();
+    mma(1, 1, DG_IC((2 + DG_D) & 3));
+    DGT();
+    if (!hi) landed();
     ++g;
-    // phase 3: second row half x first column half; the first row half of the next K-tile is read meanwhile
+    // phase 3: second row half x first column half (fragments already in registers)
     __builtin_amdgcn_s_barrier();
-    if (t + 1 < nkt) readA(0, u0 + 4);
-    if (hi) wait_landed();
+    DGT();
+#if DG_BALANCED
+    DG_R(3, if (t + 1 < nkt) readA(0, u0 + 4));
+#else
+    DG_R(3, (void)0);
+#endif
+    if (hi) landed();
+    DGT();
     __builtin_amdgcn_s_barrier();
-    mma(1, 0, DG_IC(1));
-    if (!hi) wait_landed();
+    DGT();
+    mma(1, 0, DG_IC((3 + DG_D) & 3));
+    DGT();
+    if (!hi) landed();
     ++g;
-  }
+#undef DG_R
+#undef DG_RP
+  };
+  // steady while the last unit issued in the K-tile, 4 t + 3 + D, exists
+  const int t_steady = (nunits - 4 - DG_D) >= 0 ? (nunits - 4 - DG_D) / 4 + 1 : 0;
+  int t = 0;
+#pragma unroll 1
+  for (; t < t_steady; ++t) ktile(t, DG_IC(1));
+#pragma unroll 1
+  for (; t < nkt; ++t) ktile(t, DG_IC(0));
   if (!hi) __builtin_amdgcn_s_barrier();   // re-align the two groups
   __builtin_amdgcn_s_barrier();            // every wave is done with the ring: LDS is free for the epilogue
 
@@ -359,7 +512,25 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     gm0 = *(const f32x4*)(a.gamma + n);
     gm1 = *(const f32x4*)(a.gamma + n + 4);
   }
-#pragma unroll 4
+  // the accumulators are dead now: every global operand of the row-wise pass is requested up front (16 rows x 32 B of x
+  // or 16 B of h per lane in flight), so the pass pays the memory latency once instead of once per row
+  f32x4 xin[MODE == DG_RESID ? 16 : 1][2];
+  bf16x8 hin[MODE == DG_DGELU ? 16 : 1];
+  if (MODE == DG_RESID || MODE == DG_DGELU) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int m = m0 + wr * 128 + it * 8 + srow;
+      const bool ok = m < a.M && nok;
+      if (MODE == DG_RESID) {
+        const float* xp = a.X + (int64_t)(ok ? m : 0) * a.N + (ok ? n : 0);
+        xin[it][0] = *(const f32x4*)xp;
+        xin[it][1] = *(const f32x4*)(xp + 4);
+      } else {
+        hin[it] = *(const bf16x8*)(a.H + (int64_t)(ok ? m : 0) * a.ldc + (ok ? n : 0));
+      }
+    }
+  }
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int row = it * 8 + srow;
     const int m = m0 + wr * 128 + row;
@@ -373,13 +544,12 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
       *(u32x4*)cp = raw;                     // pre-activation, kept for the backward
       bf16x8 y;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = (bf16)gelu_exact((float)cb[e]);        // F.gelu of the bf16-rounded h
+      for (int e = 0; e < 8; ++e) y[e] = (bf16)dg_gelu((float)cb[e]);           // F.gelu of the bf16-rounded h
       *(bf16x8*)(a.C2 + (int64_t)m * a.ldc + n) = y;
     } else if (MODE == DG_RESID) {
       *(u32x4*)cp = raw;                     // branch output, needed for d gamma
       const float rsv = a.rs ? a.rs[m / a.rps] : 1.0f;
-      const float* xp = a.X + (int64_t)m * a.N + n;
-      f32x4 x0 = *(const f32x4*)xp, x1 = *(const f32x4*)(xp + 4);
+      f32x4 x0 = xin[it][0], x1 = xin[it][1];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         x0[e] += rsv * gm0[e] * (float)cb[e];
@@ -389,10 +559,10 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
       *(f32x4*)op = x0;
       *(f32x4*)(op + 4) = x1;
     } else {                                 // DG_DGELU: dh = gelu'(h) * g
-      const bf16x8 h = *(const bf16x8*)(a.H + (int64_t)m * a.ldc + n);
+      const bf16x8 h = hin[it];
       bf16x8 d;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d[e] = (bf16)(gelu_grad((float)h[e]) * (float)cb[e]);
+      for (int e = 0; e < 8; ++e) d[e] = (bf16)(dg_gelu_grad((float)h[e]) * (float)cb[e]);
       *(bf16x8*)cp = d;
     }
   }

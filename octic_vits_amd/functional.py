@@ -390,11 +390,22 @@ class DenseWeightCache:
             self.key = key
         return self.w, self.b
 
-    def adopt(self, w, b, w_copy, b_copy, dtype):
+    def adopt(self, w, b, w_copy, b_copy, dtype, wt_copy=None):
         """Take compute-dtype copies produced elsewhere (the fused optimizer writes them in its update pass) as the
         current cache content for the parameters' present versions."""
         self.w, self.b = w_copy, b_copy
         self.key = self._key(w, b, dtype)
+        if wt_copy is not None:
+            self.wt, self.wt_key = wt_copy, self.key
+
+    def get_nt(self, w, b):
+        """(bf16 W [N,K], bf16 W^T [K,N]) for the hand-written dense GEMMs (forward / input-gradient operands)."""
+        wb, _ = self.get(w, b, torch.bfloat16)
+        if getattr(self, "wt_key", None) != self.key:
+            with torch.no_grad():
+                self.wt = wb.t().contiguous()
+            self.wt_key = self.key
+        return wb, self.wt
 
 
 class DenseLayerNormFn(torch.autograd.Function):
@@ -533,6 +544,152 @@ def track_optimizer(model, optimizer):
     """Register ``invalidate_weight_caches(model)`` as a post-step hook of a torch.optim.Optimizer (any optimizer,
     including ones that update ``p.data`` behind autograd's back).  Returns the hook handle."""
     return optimizer.register_step_post_hook(lambda *_a, **_k: invalidate_weight_caches(model))
+
+
+# --------------------------------------------------------------- standard half on the hand-written MFMA GEMMs
+# Which GEMMs of a standard block run on csrc/dense_gemm.hip (the others stay on the BLAS library + the row kernels of
+# csrc/dense.hip).  Measured in the train step on MI355X (same device, back to back; DESIGN.md section 3.4): the
+# hand-written kernel wins where the tile count fills whole rounds of the 256 CUs or the fused tail removes a full pass
+# (qkv forward and input gradient, fc1 + GELU); on the N = 1280 problems (325 tiles = 1.27 rounds at B = 64) the library's
+# stream-K kernels are ahead and a fused heavy epilogue cannot overlap with anything (one workgroup per CU).
+DENSE_HIP = {"qkv", "dqkv", "fc1"}          # subset of {"qkv", "dqkv", "proj", "dproj", "fc1", "dfc1", "fc2", "dfc2"}
+
+
+def dense_hip_ok(x, w, which=None):
+    """bf16 autocast on the GPU, a shape csrc/dense_gemm.hip covers (K % 64 == 0, K >= 128, N % 8 == 0) and routed."""
+    return ((which is None or which in DENSE_HIP) and x.is_cuda and w.shape[1] % 64 == 0 and w.shape[1] >= 128
+            and w.shape[0] % 8 == 0 and w.shape[0] % 64 == 0)
+
+
+def _f32(t):
+    return None if t is None else _c(t.detach().float())
+
+
+def _wgrad_lib(g2, x2):
+    """dW = g^T x (f32 result).  Weight gradients of the standard half stay on the BLAS library."""
+    with torch.autocast("cuda", enabled=False):
+        return (g2.t() @ x2).float()
+
+
+def _mm_lib(a2, bt):
+    """a2 @ bt with bt given as [K, N] ... library matmul of bf16 2-D tensors (no autocast re-casts)."""
+    with torch.autocast("cuda", enabled=False):
+        return a2 @ bt
+
+
+class DenseLinearNTFn(torch.autograd.Function):
+    """nn.Linear (bf16 operands, f32 accumulate, f32 bias added before the one rounding to bf16): forward and input
+    gradient on csrc/dense_gemm.hip.  deit/vit.py:33 (``self.qkv(x)``)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cache, tag):
+        xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
+        wb, wt = cache.get_nt(w, b)
+        x2 = xb.reshape(-1, wb.shape[1])
+        if tag in DENSE_HIP:
+            y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b), name="dense_nt_kernel<plain>")
+        else:
+            with torch.autocast("cuda", enabled=False):
+                y = torch.nn.functional.linear(x2, wb, None if b is None else cache.b)
+        ctx.save_for_backward(x2, wb, wt)
+        ctx.meta = (b is not None, x.dtype, x.shape, tag)
+        return y.view(*x.shape[:-1], wb.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, wb, wt = ctx.saved_tensors
+        has_b, x_dtype, x_shape, tag = ctx.meta
+        g2 = _c(gy).reshape(-1, wt.shape[1])
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (ops.dense_gemm_nt(g2, wt, 0, name="dense_nt_kernel<dgrad>") if ("d" + tag) in DENSE_HIP
+                  else _mm_lib(g2, wb)).view(x_shape).to(x_dtype)
+        gb = g2.sum(0, dtype=torch.float32) if has_b else None
+        return gx, _wgrad_lib(g2, x2), gb, None, None
+
+
+class DenseProjResidFn(torch.autograd.Function):
+    """out = x + rs * gamma * (a W^T + b): the tail of a standard-block branch (deit/vit.py:131-134) as ONE GEMM with a
+    fused epilogue; backward = one HIP row pass (gy, d gamma, bias gradient) + the input-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, a, w, b, gamma, rs, rps, cache):
+        x = _c(x)
+        ab = _c(a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16))
+        wb, wt = cache.get_nt(w, b)
+        a2 = ab.reshape(-1, wb.shape[1])
+        g32, rs32 = _f32(gamma), _f32(rs)
+        y, out = ops.dense_gemm_nt(a2, wb, 2, bias=_f32(b), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, wb.shape[0]),
+                                   name="dense_nt_kernel<resid>")
+        ctx.save_for_backward(a2, wb, wt, y, g32, rs32)
+        ctx.meta = (rps, b is not None, gamma is not None, a.dtype, a.shape)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a2, wb, wt, y, g32, rs32 = ctx.saved_tensors
+        rps, has_b, has_gamma, a_dtype, a_shape = ctx.meta
+        gout = _c(gout.float())
+        gy, dgamma, colsum = ops.scale_residual_bwd(gout.view(y.shape), y, g32, rs32, rps, want_gamma=has_gamma,
+                                                    want_colsum=has_b)
+        ga = None
+        if ctx.needs_input_grad[1]:
+            ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if "dproj" in DENSE_HIP
+                  else _mm_lib(gy, wb)).view(a_shape).to(a_dtype)
+        return gout, ga, _wgrad_lib(gy, a2), colsum, dgamma, None, None, None
+
+
+class DenseMlpFn(torch.autograd.Function):
+    """x + rs * gamma * fc2(gelu(fc1(y))) of a standard block (timm Mlp inside deit/vit.py:131-134).  Per GEMM, routed by
+    DENSE_HIP: fc1 with bias + exact-erf GELU in the epilogue (pre-activation kept for the backward), fc2 with bias, layer
+    scale, stochastic depth and the f32 residual in the epilogue, fc2's input gradient with GELU' in its epilogue, fc1's
+    input gradient; otherwise the BLAS library with the row kernels of csrc/dense.hip around it.  Weight gradients stay
+    on the library."""
+
+    @staticmethod
+    def forward(ctx, y, x, w1, b1, w2, b2, gamma, rs, rps, c1, c2):
+        x = _c(x)
+        yb = _c(y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16))
+        w1b, w1t = c1.get_nt(w1, b1)
+        w2b, w2t = c2.get_nt(w2, b2)
+        y2 = yb.reshape(-1, w1b.shape[1])
+        g32, rs32 = _f32(gamma), _f32(rs)
+        if "fc1" in DENSE_HIP:
+            h, a = ops.dense_gemm_nt(y2, w1b, 1, bias=_f32(b1), name="dense_nt_kernel<gelu>")
+        else:
+            with torch.autocast("cuda", enabled=False):
+                h = torch.nn.functional.linear(y2, w1b, None if b1 is None else c1.b)
+                a = torch.nn.functional.gelu(h)
+        if "fc2" in DENSE_HIP:
+            br, out = ops.dense_gemm_nt(a, w2b, 2, bias=_f32(b2), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, w2b.shape[0]),
+                                        name="dense_nt_kernel<resid>")
+        else:
+            with torch.autocast("cuda", enabled=False):
+                br = torch.nn.functional.linear(a, w2b, None if b2 is None else c2.b)
+            out = ops.scale_residual_fwd(x.view(-1, w2b.shape[0]), br, g32, rs32, rps)
+        ctx.save_for_backward(y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32)
+        ctx.meta = (rps, b1 is not None, b2 is not None, gamma is not None, y.dtype, y.shape)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gout):
+        y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32 = ctx.saved_tensors
+        rps, has_b1, has_b2, has_gamma, y_dtype, y_shape = ctx.meta
+        gout = _c(gout.float())
+        gbr, dgamma, db2 = ops.scale_residual_bwd(gout.view(br.shape), br, g32, rs32, rps, want_gamma=has_gamma,
+                                                  want_colsum=has_b2)
+        if "dfc2" in DENSE_HIP:
+            dh = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>")     # gelu'(h) * (gbr W2)
+            db1 = dh.sum(0, dtype=torch.float32) if has_b1 else None
+        else:
+            dh, db1 = ops.dense_gelu_bwd(h, _mm_lib(gbr, w2b), want_colsum=has_b1)
+        gw2 = _wgrad_lib(gbr, a)
+        gw1 = _wgrad_lib(dh, y2)
+        gy = None
+        if ctx.needs_input_grad[0]:
+            gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>") if "dfc1" in DENSE_HIP
+                  else _mm_lib(dh, w1b)).view(y_shape).to(y_dtype)
+        return gy, gout, gw1, db1, gw2, db2, dgamma, None, None, None, None
 
 
 # -------------------------------------------------------------------------------------- hand-off

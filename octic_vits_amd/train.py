@@ -141,6 +141,23 @@ class FusedLamb:
                 sh_ptrs[index[id(b)]] = bb.data_ptr()
             self._shadows.append((lin, cache, wb, bb))
         self.s_ptrs = torch.tensor(sh_ptrs, dtype=i64, device=dev) if self._shadows else None
+        # transposed bf16 copies (operand of the hand-written input-gradient GEMMs): one batched launch per step
+        self._wt, self._wt_items, self._wt_blocks = [], None, 0
+        if self._shadows:
+            import numpy as np
+            dt = np.dtype([("src", "<u8"), ("wb", "<u8"), ("wt", "<u8"), ("N", "<i4"), ("K", "<i4"),
+                           ("block_begin", "<i4"), ("pad", "<i4")])
+            tab = np.zeros(len(self._shadows), dtype=dt)
+            blocks = 0
+            for i, (lin, cache, wb, bb) in enumerate(self._shadows):
+                N, K = wb.shape
+                wt = torch.empty((K, N), dtype=torch.bfloat16, device=dev)
+                self._wt.append(wt)
+                tab[i]["src"], tab[i]["wb"], tab[i]["wt"] = wb.data_ptr(), 0, wt.data_ptr()
+                tab[i]["N"], tab[i]["K"], tab[i]["block_begin"] = N, K, blocks
+                blocks += int(_lib.lib().octic_dense_prep_batch_blocks(N, K))
+            self._wt_items = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+            self._wt_blocks = blocks
         self._g_key = None
         self.ntensors, self.nchunks = len(self.params), len(ct)
         self.ws = torch.zeros(int(_lib.lib().octic_lamb_workspace_floats(self.ntensors, self.nchunks)),
@@ -205,8 +222,11 @@ class FusedLamb:
         # cache keyed on them (the compute-dtype weight copies of functional.WeightPrep) is refreshed
         torch._C._autograd._unsafe_set_version_counter(
             tuple(self.params), tuple(p._version + 1 for p in self.params))
-        for lin, cache, wb, bb in self._shadows:     # the bf16 copies written above are current for the new versions
-            cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16)
+        if self._wt_items is not None:
+            self._lib.check(self._lib.lib().octic_dense_prep_batch(vp(self._wt_items), len(self._shadows), self._wt_blocks,
+                                                                   self._lib.BF16, stream))
+        for (lin, cache, wb, bb), wt in zip(self._shadows, self._wt):   # the bf16 copies are current for the new versions
+            cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16, wt_copy=wt)
         if self._prep_source is not None:
             if self._prep_batch is None or self._prep_batch.stale():
                 from .functional import PrepBatch

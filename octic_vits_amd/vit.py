@@ -49,6 +49,10 @@ class Mlp(nn.Module):
 
     def forward_fused(self, y, xres, gamma, rs, dtype):
         """xres + rs*gamma*fc2(gelu(fc1(y))) with y already normalised and in the compute dtype."""
+        if (dtype == torch.bfloat16 and _OF.dense_hip_ok(y, self.fc1.weight) and _OF.dense_hip_ok(y, self.fc2.weight)
+                and ({"fc1", "fc2", "dfc1", "dfc2"} & _OF.DENSE_HIP)):
+            return _OF.DenseMlpFn.apply(y, xres, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gamma,
+                                        rs, y.shape[1], self._c1, self._c2)
         if dtype == torch.bfloat16 and self.fc1.out_features % 8 == 0:
             h = _OF.DenseLinearGeluFn.apply(y, self.fc1.weight, self.fc1.bias, self._c1)
         else:
@@ -80,8 +84,14 @@ class Attention(nn.Module):
         """xres + rs*gamma*proj(attention(qkv(y))) with y already normalised and in the compute dtype."""
         B, N, C = y.shape
         hd = C // self.num_heads
-        qkv = _OF.DenseLinearFn.apply(y, self.qkv.weight, self.qkv.bias, dtype, self._c1)
+        bf = dtype == torch.bfloat16
+        if bf and _OF.dense_hip_ok(y, self.qkv.weight) and ({"qkv", "dqkv"} & _OF.DENSE_HIP):
+            qkv = _OF.DenseLinearNTFn.apply(y, self.qkv.weight, self.qkv.bias, self._c1, "qkv")
+        else:
+            qkv = _OF.DenseLinearFn.apply(y, self.qkv.weight, self.qkv.bias, dtype, self._c1)
         a = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
+        if bf and _OF.dense_hip_ok(y, self.proj.weight, "proj"):
+            return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2)
         return _OF.LinearScaleResidualFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, dtype, self._c2)
 
     def forward(self, x):

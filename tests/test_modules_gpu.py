@@ -92,23 +92,49 @@ def test_bf16_autocast_close_to_reference_golden(name):
     if not name.startswith("model"):
         _check(name, got, want, 5e-2, 5e-2)
         return
-    # whole models: outputs elementwise at 5e-2 of scale.  Gradients are compared in relative L2 (<= 0.2; <= 0.5 for
-    # the invariant model, whose PowerSpectrum |.| hand-off makes upstream A2/B1/B2 gradients sign-sensitive):
-    # bf16 rounding moves activations by ~1e-2, which flips sign(x) at the |.| kinks of PowerSpectrum / the
-    # GELU slope for individual elements, so a few entries of a weight gradient can move by O(their size)
-    # while the tensor as a whole stays within a few percent (the fp32 path pins the same gradients to 1e-3).
+    # Whole models.  The yardstick for "what bf16 costs" is the reference itself under bf16 autocast: the oracle (pinned to the
+    # reference by the f32 goldens) is run on the CPU under torch.autocast(bfloat16) - the same operands rounded at the
+    # same places - and the product's distance to the f32 golden must stay within max(3e-2, 2 x the oracle's own distance),
+    # per tensor, in relative L2 (measured on MI355X, round 2: product median 1.6e-2 / max 3.9e-2, oracle median 1.8e-2 /
+    # max 4.1e-2 on model_hybrid).
+    # One documented exception: in the invariant model the A2 / B1 / B2 streams reach the head through |x| (PowerSpectrum,
+    # d8_invariantization.py:49-64), whose cotangent is g * sign(x).  The head reads the cls token only, so g is concentrated
+    # on the cls row - whose A2/B1/B2 components start as frozen zeros (model.py:99-105) and are of the size of bf16 rounding
+    # noise at the hand-off: sign(x) of those few dozen elements is decided by rounding, differently in any two bf16
+    # implementations (tools/inv_diag.py: cotangent at the invariant output within 0.8 %, kernel dx equal to the formula on
+    # its own (g, x) to 1e-8, yet 9-21 % on the A2/B1 stream cotangent).  Those tensors are held to 0.35.
+    from oracle import octic_ref as R
+
+    class _CpuAutocast(torch.nn.Module):
+        def __init__(self, mod):
+            super().__init__()
+            self.mod = mod
+
+        def named_parameters(self, *a, **k):
+            return self.mod.named_parameters(*a, **k)
+
+        def forward(self, x):
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                return self.mod(x)
+
+    yard = cases.run_module_case(R, name, device="cpu", to_module=_CpuAutocast)
     assert set(got) == set(want.files)
+    abs_irreps = ("_A2", "_B1", "_B2")
     for k in want.files:
-        g, w = got[k].astype(np.float64), want[k].astype(np.float64)
+        g, w, y = got[k].astype(np.float64), want[k].astype(np.float64), yard[k].astype(np.float64)
         if k.startswith("out."):
             scale = max(1.0, float(np.abs(w).max()))
             assert np.allclose(g, w, rtol=5e-2, atol=5e-2 * scale), f"{name}:{k}"
-        elif k.startswith("gpar_norm."):
-            assert abs(g[0] - w[0]) <= (0.5 if name == "model_invariant" else 0.2) * max(w[0], 1e-3), f"{name}:{k} {g[0]} vs {w[0]}"
-        else:
-            rel = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3)
-            lim = 0.5 if name == "model_invariant" else 0.2
-            assert rel <= lim, f"{name}:{k} rel L2 err {rel:.3f}"
+            continue
+        den = max(np.linalg.norm(w), 1e-3) if not k.startswith("gpar_norm.") else max(abs(w[0]), 1e-3)
+        rel = (np.linalg.norm(g - w) if not k.startswith("gpar_norm.") else abs(g[0] - w[0])) / den
+        rel_oracle = (np.linalg.norm(y - w) if not k.startswith("gpar_norm.") else abs(y[0] - w[0])) / den
+        lim = max(3e-2, 2.0 * rel_oracle)
+        # everything upstream of the |.|: the A2/B1/B2 linears / norms / lift kernels and the shared positional embeddings
+        fragile = name == "model_invariant" and (any(t in k for t in abs_irreps) or "pos_embed" in k)
+        if fragile:
+            lim = max(lim, 0.35)
+        assert rel <= lim, f"{name}:{k} rel L2 err {rel:.4f} > {lim:.4f} (reference under bf16 autocast: {rel_oracle:.4f})"
 
 
 def test_gelu_function_is_a_drop_in_for_the_reference_custom_op():
