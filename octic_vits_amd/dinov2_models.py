@@ -73,9 +73,15 @@ class OcticDinoVisionTransformer(OcticVisionTransformer):
         B, _, h, w = x.shape
         gh, gw = self.pos_embed[0].shape[0] * 2, self.pos_embed[0].shape[1] * 2
         ps = self.patch_embed.patch_size
-        if (h // ps[0], w // ps[1]) != (gh, gw):
-            raise NotImplementedError("non-native resolutions (the reference raises TypeError there, d8_utils.py:475)")
         pos = packed_pos_embed(self.pos_embed)                       # [G*G, 8c]
+        if (h // ps[0], w // ps[1]) != (gh, gw) or h != w:
+            # d8_utils.interpolate_spatial_tuple (:453-499): bicubic resize of the unfolded grids to the crop's token grid
+            # (channel-wise, so the packed tensor is resized in one call).  The reference divides by the TUPLE patch size
+            # there and raises TypeError as shipped; the integer patch side is the evident intent (the
+            # DINOv2 multi-crop recipe needs 96 x 96 local crops on a 224 model).  Parity: oracle only.
+            pos = torch.nn.functional.interpolate(pos.float().view(1, gh, gw, -1).permute(0, 3, 1, 2),
+                                                  size=(h // ps[0], w // ps[1]), mode="bicubic", antialias=False)
+            pos = pos.permute(0, 2, 3, 1).reshape(-1, pos.shape[1])
         cls_row = _pack8([t.flatten() for t in self.cls_token])
         c = self.embed_dim // 8
         if masks is None and self.register_tokens is None:
