@@ -340,7 +340,7 @@ template <int KS, int DT>
 static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
   // the forward is light on registers: one wave per tile even for nine tiles (three waves on one SIMD hide the
   // softmax latency better than the shared-tile split does: 78 vs 85 us at T = 257); the kernel supports both
-  const int nt = (a.T + 31) / 32, W = getenv("OCTIC_ATTN_FWD_SHARED") ? attn_waves(nt) : nt;
+  const int nt = (a.T + 31) / 32, W = nt;
   const int rsk = attn_rsk(a.hd), rsv = attn_rsv(DT * 32);
   size_t smem = (size_t)nt * 32 * (rsk + rsv);
   const size_t comb = ((size_t)W * 32 * (DT * 32 + kPartPad) + (2 * W + 1) * 32) * sizeof(float);
@@ -619,7 +619,7 @@ template <int KS, int DT>
 static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream_t s) {
   // dkv (two accumulator sets) needs the 256-register budget of the eight-wave split (105 vs 156 us with spills);
   // dq runs the same either way (~106 us) and follows it
-  const int nt = (a.T + 31) / 32, W = attn_waves(nt), Wq = getenv("OCTIC_ATTN_DQ_PER_TILE") ? nt : W;
+  const int nt = (a.T + 31) / 32, W = attn_waves(nt), Wq = W;
   // the row images are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16); rows are padded so the
   // b128 reads are conflict-free, the transposed reads then see at most 2-way conflicts.  The tr fragments reach
   // DT*32 columns, so rows must hold that many (the pad columns meet zero accumulator columns / are discarded).

@@ -608,7 +608,7 @@ template <typename T, int V, int DIR>
 static int heads_launch(View vv, HeadPtrs hp, int64_t B, int64_t T_, int H, int c, int n_s, hipStream_t s) {
   const int w = c / H, hd = 8 * w;
   const size_t row_bytes = (size_t)n_s * 8 * c * sizeof(T);
-  static const int tt_env = getenv("OCTIC_HEADS_TT") ? atoi(getenv("OCTIC_HEADS_TT")) : 4;   // 4 tokens = 30 KiB of LDS at ViT-H: five workgroups per CU (8: 78/90 us, 4: 61/45 us pack/unpack)
+  constexpr int tt_env = 4;   // 4 tokens = 30 KiB of LDS at ViT-H: five workgroups per CU (8: 78/90 us, 4: 61/45 us pack/unpack)
   int TT = tt_env;
   while (TT > 1 && TT * row_bytes > 64 * 1024) TT >>= 1;
   if (TT * row_bytes > 160 * 1024) return OCTIC_ESHAPE;
@@ -696,7 +696,7 @@ int octic_gelu_d8_fwd(const octic_view* x, const octic_view* y, int64_t M, int c
   if (M <= 0) return OCTIC_ESHAPE;
   View vx = make_view<void>(x), vy = make_view<void>(y);
   // bf16: four channels per thread (111 VGPRs, four waves per SIMD: 81 -> 62 us in-step at ViT-H); f32 keeps eight
-  static const int ch4 = getenv("OCTIC_GELU_CH4") ? atoi(getenv("OCTIC_GELU_CH4")) : 1;
+  constexpr int ch4 = 1;      // four channels per thread (eight: 207-250 VGPRs, slower)
   if (ch4 && dtype == OCTIC_BF16) {
     gelu_fwd4_kernel<bf16><<<grid_for(M * (c / 4)), 256, 0, (hipStream_t)stream>>>(vx, vy, M, c);
     return launch_status();
@@ -716,7 +716,7 @@ int octic_gelu_d8_bwd(const octic_view* g, const octic_view* x, const octic_view
     return e;
   if (M <= 0) return OCTIC_ESHAPE;
   View vg = make_view<void>(g), vx = make_view<void>(x), vo = make_view<void>(gin);
-  static const int ch4 = getenv("OCTIC_GELU_CH4") ? atoi(getenv("OCTIC_GELU_CH4")) : 1;
+  constexpr int ch4 = 1;      // four channels per thread (eight: 207-250 VGPRs, slower)
   if (ch4 && dtype == OCTIC_BF16) {                       // 109 -> 95 us in-step
     gelu_bwd4_kernel<bf16><<<grid_for(M * (c / 4)), 256, 0, (hipStream_t)stream>>>(vg, vx, vo, M, c);
     return launch_status();

@@ -45,7 +45,6 @@ struct GemmArgs {
   // lift mode: output row = (row / lift_np) * (lift_np + lift_tok0) + lift_tok0 + row % lift_np ; resid row = row % lift_np
   int64_t lift_np;
   int lift_tok0;
-  int dbg;  // ablation bits (OCTIC_GEMM_DBG env, timing only): 1 = no global loads after step 0, 2 = no MFMA, 4 = no epilogue stores
 };
 
 template <typename T> struct Elem;
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void linear_d8_kernel(GemmArgs args) {
             if (has_cs) v *= sv;
             if (has_rs) v *= rsv[j];
             if (has_res) v += load_out4<TOUT>((const TOUT*)G.resid + roff[j] + n);
-            if (!(args.dbg & 4)) store_out4<TOUT>((TOUT*)G.y + yoff[j] + n, v);
+            store_out4<TOUT>((TOUT*)G.y + yoff[j] + n, v);
           }
         }
       }
@@ -289,27 +288,27 @@ __global__ __launch_bounds__(256, 2) void linear_d8_kernel(GemmArgs args) {
   lstore(0, rxA, rwA, mA);
   __syncthreads();
   for (int s = 0; s < steps; s += 2) {
-    if (s + 2 < steps && !(args.dbg & 1)) gload(rxA, rwA, mA);
+    if (s + 2 < steps) gload(rxA, rwA, mA);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(args.dbg & 2)) compute(0);
+    compute(0);
     __builtin_amdgcn_sched_barrier(0);
     if (++c_kt == nkt) {
       c_kt = 0;
-      if (!(args.dbg & 32)) epilogue();
+      epilogue();
     }
-    if (s + 1 < steps && !(args.dbg & 8)) lstore(1, rxB, rwB, mB);
-    if (!(args.dbg & 16)) __syncthreads();
+    if (s + 1 < steps) lstore(1, rxB, rwB, mB);
+    __syncthreads();
     if (s + 1 >= steps) break;
-    if (s + 3 < steps && !(args.dbg & 1)) gload(rxB, rwB, mB);
+    if (s + 3 < steps) gload(rxB, rwB, mB);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(args.dbg & 2)) compute(1);
+    compute(1);
     __builtin_amdgcn_sched_barrier(0);
     if (++c_kt == nkt) {
       c_kt = 0;
-      if (!(args.dbg & 32)) epilogue();
+      epilogue();
     }
-    if (s + 2 < steps && !(args.dbg & 8)) lstore(0, rxA, rwA, mA);
-    if (!(args.dbg & 16)) __syncthreads();
+    if (s + 2 < steps) lstore(0, rxA, rwA, mA);
+    __syncthreads();
   }
 }
 
@@ -860,8 +859,7 @@ int launch_xreg_k(GemmArgs& a, bool fused, int t, hipStream_t s) {
 // returns -100 when the problem does not qualify (caller falls through to the ring kernel)
 template <typename TOUT>
 int launch_xreg(GemmArgs& a, hipStream_t s) {
-  static const int use = getenv("OCTIC_GEMM_XREG") ? atoi(getenv("OCTIC_GEMM_XREG")) : 1;
-  if (!use || a.lift_np > 0) return -100;
+  if (a.lift_np > 0) return -100;
   int kmax = 0;
   for (int i = 0; i < a.ngroups; ++i) {
     if (a.g[i].K % 32) return -100;
@@ -872,11 +870,10 @@ int launch_xreg(GemmArgs& a, hipStream_t s) {
   bool fused = a.rs != nullptr;
   // n-tiles walked per workgroup: sized so the launch has ~2000 workgroups (measured sweet spot on MI355X: fewer,
   // longer workgroups lose to imbalance, more of them re-load the X fragments too often)
-  static const int force_tiles = getenv("OCTIC_XREG_TILES") ? atoi(getenv("OCTIC_XREG_TILES")) : 0;
   int64_t items = 0;
   for (int i = 0; i < a.ngroups; ++i)
     items += ((a.g[i].rows + kBM - 1) / kBM) * ((a.g[i].N + kRingBN - 1) / kRingBN);
-  int max_tiles = force_tiles ? force_tiles : (int)((items + 1024) / 2048);
+  int max_tiles = (int)((items + 1024) / 2048);
   max_tiles = max_tiles < 1 ? 1 : max_tiles;
   for (int i = 0; i < a.ngroups; ++i) {
     a.g[i].n_tiles = (a.g[i].N + kRingBN - 1) / kRingBN;
@@ -901,7 +898,7 @@ int launch_ring_nt(GemmArgs& a, hipStream_t s) {
   for (int i = 0; i < a.ngroups; ++i) {
     a.g[i].n_tiles = (a.g[i].N + BN - 1) / BN;
     a.g[i].m_tiles = (int)((a.g[i].rows + kBM - 1) / kBM);
-    static const int target_steps = getenv("OCTIC_RING_STEPS") ? atoi(getenv("OCTIC_RING_STEPS")) : 1;
+    constexpr int target_steps = 1;    // one output tile per workgroup (measured best in situ on MI355X)
     const int bke = 128 / (int)sizeof(TIN);
     const int nkt = (a.g[i].K + bke - 1) / bke;
     int chunk = target_steps / nkt;
@@ -929,16 +926,13 @@ int launch_ring_nt(GemmArgs& a, hipStream_t s) {
 template <typename TIN, typename TOUT>
 int launch_ring(GemmArgs& a, hipStream_t s) {
   // wide tile when every group's N is a multiple of 160 and the problem is long in K (the X panel dominates)
-  static const int wide = getenv("OCTIC_RING_WIDE") ? atoi(getenv("OCTIC_RING_WIDE")) : 1;
-  bool ok = wide && sizeof(TIN) == 2 && a.lift_np == 0;
+  bool ok = sizeof(TIN) == 2 && a.lift_np == 0;
   for (int i = 0; i < a.ngroups; ++i) ok = ok && (a.g[i].N % 160) == 0 && a.g[i].K >= 2 * a.g[i].N;
   if (ok) return launch_ring_nt<TIN, TOUT, 10, 2>(a, s);
   return launch_ring_nt<TIN, TOUT, 5, 3>(a, s);
 }
 
 inline bool ring_ok(const GemmArgs& a, int dtype) {
-  static const int use_ring = getenv("OCTIC_GEMM_RING") ? atoi(getenv("OCTIC_GEMM_RING")) : 1;
-  if (!use_ring) return false;
   const int kstep = dtype == OCTIC_BF16 ? 32 : 16;
   for (int i = 0; i < a.ngroups; ++i)
     if (a.g[i].K % kstep) return false;
@@ -976,7 +970,7 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
     const int bke = 128 / (int)sizeof(TIN);
     const int nkt = (a.g[i].K + bke - 1) / bke;
     // pipeline steps per workgroup; 1 = one output tile per workgroup (measured best in situ on MI355X)
-    static const int target_steps = getenv("OCTIC_GEMM_STEPS") ? atoi(getenv("OCTIC_GEMM_STEPS")) : 1;
+    constexpr int target_steps = 1;
     int chunk = target_steps / nkt;
     chunk = chunk < 1 ? 1 : (chunk > a.g[i].n_tiles ? a.g[i].n_tiles : chunk);
     a.g[i].chunk = chunk;
@@ -1006,8 +1000,6 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
 }
 
 inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
-  static const int dbg = getenv("OCTIC_GEMM_DBG") ? atoi(getenv("OCTIC_GEMM_DBG")) : 0;
-  a.dbg = dbg;
   if (dtype == OCTIC_BF16) {
     const int r = out_dtype == OCTIC_BF16 ? launch_xreg<bf16>(a, s) : (out_dtype == OCTIC_F32 ? launch_xreg<float>(a, s) : -100);
     if (r != -100) return r;

@@ -543,7 +543,7 @@ int octic_layernorm_d8_fwd(const octic_view* x, const octic_view* y, const float
   hipStream_t s = (hipStream_t)stream;
   if (out_dtype != OCTIC_F32 && out_dtype != OCTIC_BF16) return OCTIC_EDTYPE;
   const bool pk = view_is_packed(vx, c, 4) && view_is_packed(vy, c, elem_size(out_dtype));
-  if (pk && (c % 32) == 0 && c <= 256 && !getenv("OCTIC_LN_GENERIC")) {
+  if (pk && (c % 32) == 0 && c <= 256) {
     const float* xp = (const float*)vx.p[0];
 #define LN_FWD_G8(T, N) ln_fwd_g8_kernel<T, N><<<grid, 256, 0, s>>>(xp, vx.ld[0], (T*)vy.p[0], vy.ld[0], a[0], a[1], a[2], a[3], a[4], beta, stats, M, c, eps)
 #define LN_FWD_G8_NV(T) switch (c / 32) { case 1: LN_FWD_G8(T, 1); break; case 2: LN_FWD_G8(T, 2); break; case 3: LN_FWD_G8(T, 3); break; \
@@ -590,7 +590,7 @@ int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float
   const bool pk = view_is_packed(vg, c, elem_size(g_dtype)) && view_is_packed(vx, c, 4) && view_is_packed(vd, c, 4) &&
                   view_is_packed(vr, c, 4);
   const int hd = dres ? 1 : 0;
-  if (pk && (c % 32) == 0 && c <= 256 && !getenv("OCTIC_LN_GENERIC")) {
+  if (pk && (c % 32) == 0 && c <= 256) {
     const float* rp = dres ? (const float*)vr.p[0] : nullptr;
     const size_t smem_g8 = (size_t)(3 * 8 * c + kLnBwdWaves * c) * sizeof(float);
 #define LN_BWD_G8(T, N) ln_bwd_g8_kernel<T, N><<<grid, kLnBwdWaves * 64, smem_g8, s>>>((const T*)vg.p[0], vg.ld[0], (const float*)vx.p[0], vx.ld[0], stats, a[0], a[1], a[2], a[3], a[4], rp, vr.ld[0], (float*)vd.p[0], vd.ld[0], partials, M, c)

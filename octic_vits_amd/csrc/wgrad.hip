@@ -466,7 +466,6 @@ int launch_wgrad_tt(WgArgs& a, hipStream_t s) {
 }
 
 inline bool wgrad_ring_ok(const WgArgs& a) {
-  if (getenv("OCTIC_WGRAD_CLASSIC")) return false;
   for (int i = 0; i < a.ngroups; ++i) {
     const WgGroup& g = a.g[i];
     if ((g.K % 160) || (g.N % 160)) return false;
@@ -518,7 +517,7 @@ int64_t octic_linear_d8_wgrad_workspace_bytes(int cin, int cout, int splits) {
 }
 
 int octic_linear_d8_wgrad_has_colsum(int cin, int cout, int dtype) {
-  return dtype == OCTIC_BF16 && (cin % 160) == 0 && (cout % 160) == 0 && !getenv("OCTIC_WGRAD_CLASSIC");
+  return dtype == OCTIC_BF16 && (cin % 160) == 0 && (cout % 160) == 0;
 }
 
 int octic_linear_d8_wgrad_tile(int64_t M, int cin, int cout) {
@@ -545,7 +544,7 @@ int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
   const int bw = 32 * pick_tt(a);
   const int tiles_e = ((2 * cin + bw - 1) / bw) * ((2 * cout + bw - 1) / bw);
   const int tiles_1 = 4 * ((cin + bw - 1) / bw) * ((cout + bw - 1) / bw);
-  static const double target = getenv("OCTIC_WGRAD_WGS") ? atof(getenv("OCTIC_WGRAD_WGS")) : 512.0;
+  constexpr double target = 512.0;
   int s = (int)((target / (tiles_e + 0.5 * tiles_1)) + 0.5);
   const int64_t max_by_rows = (2 * M + 255) / 256;
   if (s > max_by_rows) s = (int)max_by_rows;

@@ -276,8 +276,6 @@ def use_tuned_gemms(table=None):
     is shipped as a lookup table; this only loads it (tuning itself stays off, so a step never searches).  Shapes that
     are not in the table, or a library build whose validators differ, fall back to the library default."""
     import torch.cuda.tunable as tunable
-    if os.environ.get("OCTIC_TUNED_GEMMS", "1") == "0":
-        return False
     table = table or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunable", "gfx950_vit_huge_b64.csv")
     if not os.path.exists(table):
         return False
