@@ -6,8 +6,9 @@ on synthetic batches, 1/2/4/8 MI355X (BASELINE.json `metric`, configs[1]: batch 
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` is whole-job images/s (weak scaling: 64 images per GPU).
-`roofline` is for the dominant hand-written kernel (the irrep-blocked MFMA linear), timed live with HIP events
-on the stream it is launched on during the timed steps; `cpu_baseline` is the CPU oracle timed on this box's
+`roofline` is for the dominant kernel of the WHOLE step — the engine's launches and the BLAS-library GEMMs of the
+standard half alike — timed live with HIP events on the stream they are launched on during the timed steps
+(`roofline_hbm_kernel`: the dominant HBM-bound one when the dominant one is MFMA-bound); `cpu_baseline` is the CPU oracle timed on this box's
 host cores on a bounded sample (rank 0, N=1 only).  See DESIGN.md §measurement.
 """
 import argparse
@@ -92,6 +93,7 @@ def main():
     ap.add_argument("--model", default="hybrid_deit_huge_patch14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-forward-only", action="store_true")
     ap.add_argument("--dense-hip", default=None,
                     help="developer A/B: comma list of standard-half GEMMs on csrc/dense_gemm.hip (default: functional.DENSE_HIP; 'none' = library)")
     args = ap.parse_args()
@@ -152,6 +154,32 @@ def main():
     ms = elapsed / args.steps * 1e3
     ips = world * args.batch * args.steps / elapsed
 
+    # ---- forward-only throughput in the reference's own protocol (experiments/complexity.py:13-15,40-56,60-95): eval,
+    # no_grad, batch 64, 10 warm-up + 100 timed forwards each followed by a synchronize, mean time -> images/s.  The
+    # reference runs torch.amp.autocast (fp16) + torch.compile; here bf16 autocast (the engine's compute dtype) and the
+    # HIP kernels.  Reported under "extra", outside the timed train region.
+    fwd_only = None
+    if rank == 0 and not args.no_forward_only:
+        model.eval()
+        times = []
+        with torch.no_grad():
+            img = torch.randn(64, 3, 224, 224, device=dev)
+            for i in range(10 + 100):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    t1 = time.time()
+                    model(img)
+                    torch.cuda.synchronize()
+                    if i >= 10:
+                        times.append(time.time() - t1)
+        model.train()
+        mean = sum(times) / len(times)
+        fwd_only = {"images_per_s": round(64 / mean, 1), "ms_per_forward": round(mean * 1e3, 3),
+                    "protocol": "experiments/complexity.py: eval, no_grad, batch 64, 224x224, 10 warm-up + 100 forwards, "
+                                "synchronize after each, mean; bf16 autocast (reference: fp16 autocast + torch.compile)"}
+        log(f"forward-only (reference protocol): {fwd_only['images_per_s']} img/s")
+    if world > 1:
+        dist.barrier()
+
     n_oct = model.octic_equi_break_layer
     n_std = len(model.blocks) - n_oct
     if rank == 0:
@@ -202,6 +230,15 @@ def main():
             if kh is not None and kh["name"] != k["name"]:
                 line["roofline_hbm_kernel"] = roof(kh)
             line["kernels"] = ops.KERNEL_TIMER.summary()
+            # how much of a step the per-kernel table explains: engine kernels + the BLAS-library GEMMs are timed
+            # individually; the rest is ATen glue (casts, reductions, RNG, copies) and the fused optimizer
+            timed_us = sum(v["total_us"] for v in line["kernels"].values()) / sampled_steps
+            line["step_breakdown"] = {"timed_kernels_ms": round(timed_us / 1e3, 2),
+                                      "other_ms": round(ms - timed_us / 1e3, 2),
+                                      "note": "timed = engine kernels + BLAS-library GEMMs of the standard half, HIP events in "
+                                              "sampled steps (which run slower than the average step); other = ATen glue + optimizer"}
+        if fwd_only is not None:
+            line["extra"] = {"forward_only": fwd_only}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #endif
     };
     auto landed = [&]() {
-#if DG_ABL & 1
+#if DG_ABL & 5   // bit 2: DMA is issued but never waited for (timing-only: separates issue cost from memory waits)
       return;
 #endif
       if constexpr (STEADY) dg_wait_imm<2 * (DG_D - 2)>();

@@ -500,8 +500,7 @@ class LinearScaleResidualFn(torch.autograd.Function):
         x = _c(x)
         ab = _c(a if a.dtype == dtype else a.to(dtype))
         wb, bb = cache.get(w, b, dtype)
-        with torch.autocast("cuda", enabled=False):
-            y = torch.nn.functional.linear(ab, wb, bb)
+        y = _linear_lib(ab.reshape(-1, wb.shape[1]), wb, bb).view(*ab.shape[:-1], wb.shape[0])
         g32 = None if gamma is None else _c(gamma.detach().float())
         rs32 = None if rs is None else _c(rs.detach().float())
         out = ops.scale_residual_fwd(x, y, g32, rs32, rps)
@@ -516,9 +515,8 @@ class LinearScaleResidualFn(torch.autograd.Function):
         gout = _c(gout.float())
         gy, dgamma, colsum = ops.scale_residual_bwd(gout, y, g32, rs32, rps, want_gamma=has_gamma, want_colsum=has_b)
         g2, a2 = gy.reshape(-1, wb.shape[0]), ab.reshape(-1, wb.shape[1])
-        with torch.autocast("cuda", enabled=False):
-            ga = (g2 @ wb).view(ab.shape).to(a_dtype) if ctx.needs_input_grad[1] else None
-            gw = (g2.t() @ a2).float()
+        ga = _mm_lib(g2, wb).view(ab.shape).to(a_dtype) if ctx.needs_input_grad[1] else None
+        gw = _wgrad_lib(g2, a2)
         return gout, ga, gw, colsum, dgamma, None, None, None, None
 
 
@@ -565,16 +563,32 @@ def _f32(t):
     return None if t is None else _c(t.detach().float())
 
 
+def _timed_lib(kind, fn, M, N, K):
+    """Run a BLAS-library GEMM under the kernel timer (bench.py's `kernels` / `roofline` cover the whole step, not only
+    the engine's own launches): name = library_gemm<kind N x K>, 2 M N K flops, operand + result bytes."""
+    t = ops.KERNEL_TIMER.start()
+    out = fn()
+    if t is not None:
+        ops.KERNEL_TIMER.stop(t, f"library_gemm<{kind} {N}x{K}>", 2 * (M * K + N * K + M * N), 2.0 * M * N * K)
+    return out
+
+
 def _wgrad_lib(g2, x2):
     """dW = g^T x (f32 result).  Weight gradients of the standard half stay on the BLAS library."""
     with torch.autocast("cuda", enabled=False):
-        return (g2.t() @ x2).float()
+        w = _timed_lib("wgrad", lambda: g2.t() @ x2, g2.shape[0], g2.shape[1], x2.shape[1])
+        return w.float()
 
 
-def _mm_lib(a2, bt):
-    """a2 @ bt with bt given as [K, N] ... library matmul of bf16 2-D tensors (no autocast re-casts)."""
+def _mm_lib(a2, b):
+    """a2 [M,N] @ b [N,K]: library input-gradient GEMM of bf16 2-D tensors (no autocast re-casts)."""
     with torch.autocast("cuda", enabled=False):
-        return a2 @ bt
+        return _timed_lib("dgrad", lambda: a2 @ b, a2.shape[0], b.shape[1], b.shape[0])
+
+
+def _linear_lib(x2, wb, bias):
+    with torch.autocast("cuda", enabled=False):
+        return _timed_lib("fwd", lambda: torch.nn.functional.linear(x2, wb, bias), x2.shape[0], wb.shape[0], wb.shape[1])
 
 
 class DenseLinearNTFn(torch.autograd.Function):
@@ -589,8 +603,7 @@ class DenseLinearNTFn(torch.autograd.Function):
         if tag in DENSE_HIP:
             y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b), name="dense_nt_kernel<plain>")
         else:
-            with torch.autocast("cuda", enabled=False):
-                y = torch.nn.functional.linear(x2, wb, None if b is None else cache.b)
+            y = _linear_lib(x2, wb, None if b is None else cache.b)
         ctx.save_for_backward(x2, wb, wt)
         ctx.meta = (b is not None, x.dtype, x.shape, tag)
         return y.view(*x.shape[:-1], wb.shape[0])
@@ -657,15 +670,13 @@ class DenseMlpFn(torch.autograd.Function):
         if "fc1" in DENSE_HIP:
             h, a = ops.dense_gemm_nt(y2, w1b, 1, bias=_f32(b1), name="dense_nt_kernel<gelu>")
         else:
-            with torch.autocast("cuda", enabled=False):
-                h = torch.nn.functional.linear(y2, w1b, None if b1 is None else c1.b)
-                a = torch.nn.functional.gelu(h)
+            h = _linear_lib(y2, w1b, None if b1 is None else c1.b)
+            a = torch.nn.functional.gelu(h)
         if "fc2" in DENSE_HIP:
             br, out = ops.dense_gemm_nt(a, w2b, 2, bias=_f32(b2), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, w2b.shape[0]),
                                         name="dense_nt_kernel<resid>")
         else:
-            with torch.autocast("cuda", enabled=False):
-                br = torch.nn.functional.linear(a, w2b, None if b2 is None else c2.b)
+            br = _linear_lib(a, w2b, None if b2 is None else c2.b)
             out = ops.scale_residual_fwd(x.view(-1, w2b.shape[0]), br, g32, rs32, rps)
         ctx.save_for_backward(y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32)
         ctx.meta = (rps, b1 is not None, b2 is not None, gamma is not None, y.dtype, y.shape)

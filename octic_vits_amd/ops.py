@@ -64,16 +64,20 @@ class KernelTimer:
     def bound_of(name):
         """Roofline that bounds a kernel family: the attention kernels are MFMA/VALU-bound (q,k,v,o are read once,
         14 T^2 hd flops per head), every other kernel of the engine moves more bytes than it can compute on."""
-        return "mfma" if name.startswith("attn_") else "hbm"
+        return "mfma" if name.startswith(("attn_", "dense_nt_kernel", "library_gemm")) else "hbm"
 
     def dominant(self, bound=None):
         agg = [a for a in self._agg().values() if bound is None or self.bound_of(a["name"]) == bound]
         return max(agg, key=lambda a: a["total_us"]) if agg else None
 
     def summary(self):
-        return {k: {"launches": a["launches"], "total_us": round(a["total_us"], 1), "avg_us": round(a["avg_us"], 2),
-                    "GBps": round(a["alg_bytes_per_launch"] / a["avg_us"] / 1e3, 1)}
-                for k, a in sorted(self._agg().items(), key=lambda kv: -kv[1]["total_us"])}
+        out = {}
+        for k, a in sorted(self._agg().items(), key=lambda kv: -kv[1]["total_us"]):
+            out[k] = {"launches": a["launches"], "total_us": round(a["total_us"], 1), "avg_us": round(a["avg_us"], 2),
+                      "GBps": round(a["alg_bytes_per_launch"] / a["avg_us"] / 1e3, 1)}
+            if a["flops_per_launch"]:
+                out[k]["TFLOPs"] = round(a["flops_per_launch"] / a["avg_us"] / 1e6, 1)
+        return out
 
 
 KERNEL_TIMER = KernelTimer()
