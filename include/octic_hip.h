@@ -308,6 +308,15 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
                         int64_t rows_per_sample, const float* X, float* OUT, const void* H, void* workspace,
                         void* stream);
 
+/* Weight gradient of an nn.Linear of the standard half (the autograd of deit/vit.py:33,46 and of timm Mlp.fc1 / fc2):
+ *     dW[N,K] = dY[M,N]^T . X[M,K]     f32, nn.Linear layout
+ * dY, X bf16 row-major (ldy, ldx row strides in elements), N % 256 == 0, K % 256 == 0, (N/256)(K/256) <= 256.  The
+ * reduction over the M token rows is split stream-K style over 256 workgroups; partial tiles are summed in a fixed order
+ * (bitwise reproducible).  workspace: octic_dense_wgrad_workspace_bytes(M,N,K).                              */
+int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K);
+int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
+                         void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,404 @@
+// Weight gradients of the standard half's nn.Linear layers (deit/vit.py:14-56 Attention.qkv / .proj, timm Mlp.fc1 / .fc2):
+//
+//   TN problem:  dW[N,K] = dY[M,N]^T · X[M,K]
+//
+// bf16 operands exactly as they lie in HBM (token rows M are the slow, strided dimension of BOTH operands), f32 result
+// in the nn.Linear layout [N,K] — no transposed copy of the activations, no bf16 round trip of the gradient.
+//
+// Same machinery as the forward kernel (csrc/dense_gemm.hip): 256 x 256 output tile per workgroup, 8 waves as 2 x 4 with
+// 128 (n) x 64 (k) per wave on v_mfma_f32_16x16x32_bf16, reduction walked in steps of 64 token rows, each step cut into
+// four 16 KiB units that stream through an 8-slot LDS ring by buffer-addressed LDS-DMA with counted vmcnt waits, the
+// two wave groups alternating between "read fragments + issue DMA" and "16 MFMAs" intervals.  What differs:
+//   * a unit is 64 token rows x 128 columns (256-byte rows); MFMA operands need 8 consecutive token rows per lane, i.e. a
+//     COLUMN of the staged tile: fragments come from ds_read_b64_tr_b16 (transposing read, 4 rows x 16 columns per
+//     16-lane group).  32-byte slots are XOR-swizzled with ((row & 3) | ((row >> 3) & 1) << 2) on the DMA source side and
+//     in the read address, so the 8 (row, slot) pieces a half-wave touches land in 8 different bank groups;
+//   * the output is small (N x K) and the reduction long (M = 16 448 rows = 257 steps): there are only 25-100 tiles for
+//     256 CUs, so the work is cut stream-K style — the tiles x steps units are dealt to `grid` workgroups in equal
+//     contiguous ranges; a range that covers only part of a tile leaves an f32 partial slab, and the LAST workgroup to
+//     finish a tile (agent-scope ticket) adds the other slabs in a fixed order and writes dW (bitwise reproducible);
+//     (Bias gradients come from the row kernels that already stream dY: csrc/dense.hip.)
+#include <type_traits>
+#include "octic_common.hpp"
+
+namespace octic {
+
+constexpr int DW_T = 256;                     // output tile side
+constexpr int DW_BR = 64;                     // token rows per reduction step
+constexpr int DW_UNIT = 64 * 256;             // bytes per unit: 64 rows x 128 bf16 columns
+constexpr int DW_SLOTS = 8;
+constexpr int DW_D = 6;
+
+struct DwArgs {
+  const bf16* Y;      // dY [M, N]
+  const bf16* X;      // X  [M, K]
+  int64_t ldy, ldx;
+  int M, N, K;
+  float* W;           // dW [N, K]
+  int tiles_k;        // K / 256
+  int tiles;          // (N / 256) * (K / 256), tile = tn * tiles_k + tk
+  int steps;          // ceil(M / 64) reduction steps per tile
+  float* slabs;       // [2 * grid] x 256 x 256 f32 partial tiles
+  int* tickets;       // [tiles], zeroed per launch
+};
+
+__device__ inline void dw_wait_vmcnt(int n) {
+  switch (n) {
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // DW_SLOTS x 16 KiB
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 2, wc = wid & 3;      // wr: 128-wide n half of the tile, wc: 64-wide k quarter
+  const bool hi = wr != 0;
+  const int fr = lane & 15, kg = lane >> 4;
+
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (int)((int64_t)a.M * a.ldy * 2), 0x27000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)((int64_t)a.M * a.ldx * 2), 0x27000);
+
+  // ---- DMA lane constants.  A wave-instruction fills 4 unit rows (256 B each): lane -> row (lane >> 4), 16-byte chunk
+  // position (lane & 15) = 32-byte slot (lane >> 1) & 7, half (lane & 1); the slot holds source slot ^ f(row), with
+  // f(row) = (row & 3) | ((row >> 3) & 1) << 2 and row = 8 * wid + 4 * j + (lane >> 4) for instruction j of the wave.
+  // Unit column c (0..127) of dY-units = tile column (c >> 6) * 128 + (c & 63) (+64 for the second halves); of X-units =
+  // (c >> 5) * 64 + (c & 31) (+32).
+  const int drow = lane >> 4;                 // 0..3
+  const int dpos = lane & 15;
+  unsigned voY[2], voX[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * wid + 4 * j + drow;                         // unit row 0..63
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    const int src_slot = ((dpos >> 1) & 7) ^ f;
+    const int c = src_slot * 16 + (dpos & 1) * 8;                    // first unit column of this lane's 8 bf16
+    voY[j] = (unsigned)(((int64_t)row * a.ldy + (c >> 6) * 128 + (c & 63)) * 2);
+    voX[j] = (unsigned)(((int64_t)row * a.ldx + (c >> 5) * 64 + (c & 31)) * 2);
+  }
+
+  // ---- fragment read constants (transposing reads): lane fr = 4 q + p of a 16-lane group addresses row q, columns
+  // 4 p .. 4 p + 3 of a 4 x 16 block and receives column fr of its 4 rows
+  const int frow = kg * 8 + (fr >> 2);
+  const int ff = ((fr >> 2) & 3) | ((kg & 1) << 2);                  // f(row) for rows frow (+4) (+32 ks)
+  int offY[4], offX[2];                                              // byte offsets inside a unit, k-step 0, "lo" rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offY[j] = frow * 256 + (((wr * 4 + j) ^ ff) << 5) + (fr & 3) * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offX[i] = frow * 256 + (((wc * 2 + i) ^ ff) << 5) + (fr & 3) * 8;
+
+  // ---- this workgroup's share of the tiles x steps units (stream-K)
+  const int64_t U = (int64_t)a.tiles * a.steps;
+  int64_t u0 = U * blockIdx.x / gridDim.x;
+  const int64_t u1 = U * (blockIdx.x + 1) / gridDim.x;
+  int seg = 0;
+  while (u0 < u1) {
+    const int tile = (int)(u0 / a.steps);
+    const int s0 = (int)(u0 - (int64_t)tile * a.steps);
+    const int s1 = (int)((u1 - u0) < (a.steps - s0) ? s0 + (u1 - u0) : a.steps);
+    u0 += s1 - s0;
+    const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+    const int n0 = tn * DW_T, k0 = tk * DW_T;
+    const int nkt = s1 - s0;
+    const int nunits = 4 * nkt;
+
+    f32x4 acc[2][2][4][2];               // [n-half][k-half][n-tile][k-tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) acc[i][j][p][q] = f32x4{0, 0, 0, 0};
+
+    // scalar offsets of this segment: first token row, tile columns
+    const int sbY = (int)(((int64_t)s0 * DW_BR * a.ldy + n0) * 2);
+    const int sbX = (int)(((int64_t)s0 * DW_BR * a.ldx + k0) * 2);
+    const int stepY = (int)(a.ldy * DW_BR * 2), stepX = (int)(a.ldx * DW_BR * 2);
+
+    int u_issue = 0;
+    // KIND 0 / 3: first / second 64-column halves of the dY tile halves; KIND 1 / 2: first / second 32-column halves of X
+    auto issue_unit = [&](auto kind_c) {
+      constexpr int KIND = decltype(kind_c)::value;
+      constexpr bool isY = KIND == 0 || KIND == 3;
+      constexpr bool second = KIND >= 2;
+      char* dst = lds + (u_issue & (DW_SLOTS - 1)) * DW_UNIT + wid * 2048;
+      const int t = u_issue >> 2;
+      if constexpr (isY) {
+        const int so = sbY + t * stepY + (second ? 128 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)dst, 16, voY[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voY[1], so, 0, 0);
+      } else {
+        const int so = sbX + t * stepX + (second ? 64 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, voX[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voX[1], so, 0, 0);
+      }
+      ++u_issue;
+    };
+#define DW_IC(v) std::integral_constant<int, v>()
+
+    bf16x8 Yf[2][4];                     // [k-step][n-tile]   (the n half in use)
+    bf16x8 Xf[2][2][2];                  // [k-half][k-step][k-tile]
+    auto tr8 = [&](const char* p) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * 256));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    auto readY = [&](int unit) {
+      const char* base = lds + (unit & (DW_SLOTS - 1)) * DW_UNIT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Yf[ks][j] = tr8(base + ks * (32 * 256) + offY[j]);
+    };
+    auto readX = [&](int kh, int unit) {
+      const char* base = lds + (unit & (DW_SLOTS - 1)) * DW_UNIT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) Xf[kh][ks][i] = tr8(base + ks * (32 * 256) + offX[i]);
+    };
+    auto mma = [&](int nh, int kh) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[nh][kh][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Xf[kh][ks][i], Yf[ks][j], acc[nh][kh][j][i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int g = 0;
+    auto wait_landed = [&]() {
+      int need = g + 2;
+      need = need < nunits - 1 ? need : nunits - 1;
+      const int ok = (u_issue - 1) - need;
+      if (ok == DW_D - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else dw_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+    };
+    static_assert(DW_D == 6, "steady-state vmcnt immediate is 2 * (D - 2) = 8");
+
+    // ---- prologue (see csrc/dense_gemm.hip for the protocol)
+#define DW_PRO(i) if (u_issue < nunits) issue_unit(DW_IC((i) & 3));
+    DW_PRO(0) DW_PRO(1) DW_PRO(2) DW_PRO(3) DW_PRO(4) DW_PRO(5)
+#undef DW_PRO
+    {
+      const int ok = (u_issue - 1) - 1;
+      dw_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+    }
+    if (hi) __builtin_amdgcn_s_barrier();
+
+    auto ktile = [&](int t, auto steady_c) {
+      constexpr bool STEADY = decltype(steady_c)::value != 0;
+      const int b0 = 4 * t;
+      auto dma = [&](auto kind_c) {
+        if (STEADY || u_issue < nunits) issue_unit(kind_c);
+      };
+      auto landed = [&]() {
+        if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else wait_landed();
+      };
+      // phase 0: first n half x first k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((0 + DW_D) & 3));
+      readY(b0);
+      readX(0, b0 + 1);
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(0, 0);
+      if (!hi) landed();
+      ++g;
+      // phase 1: first n half x second k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((1 + DW_D) & 3));
+      readX(1, b0 + 2);
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(0, 1);
+      if (!hi) landed();
+      ++g;
+      // phase 2: second n half x second k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((2 + DW_D) & 3));
+      readY(b0 + 3);
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(1, 1);
+      if (!hi) landed();
+      ++g;
+      // phase 3: second n half x first k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((3 + DW_D) & 3));
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(1, 0);
+      if (!hi) landed();
+      ++g;
+    };
+    const int t_steady = (nunits - 4 - DW_D) >= 0 ? (nunits - 4 - DW_D) / 4 + 1 : 0;
+    int t = 0;
+#pragma unroll 1
+    for (; t < t_steady; ++t) ktile(t, DW_IC(1));
+#pragma unroll 1
+    for (; t < nkt; ++t) ktile(t, DW_IC(0));
+    if (!hi) __builtin_amdgcn_s_barrier();   // re-align the two groups
+    __builtin_amdgcn_s_barrier();            // the ring is idle
+
+    // ---- partial tile: publish, last arriver of the tile reduces (plain stores -> drain -> barrier -> agent release ->
+    // ticket; reducer: agent acquire -> barrier).  The number of ranges touching a tile follows from the partition.
+    const bool whole = (s0 == 0 && s1 == a.steps);
+    bool reducer = whole;
+    if (!whole) {
+      float* slab = a.slabs + ((int64_t)blockIdx.x * 2 + seg) * (DW_T * DW_T);
+      f32x4* sw4 = (f32x4*)slab + (int64_t)wid * 32 * 64 + lane;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sw4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64] = acc[nh][kh][j][i];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* flag = (int*)lds;
+      // ranges covering this tile: workgroups w with [U w / G, U (w+1) / G) intersecting [tile * steps, (tile+1) * steps)
+      const int64_t tb = (int64_t)tile * a.steps, te = tb + a.steps;
+      const int G = gridDim.x;
+      int w_first = (int)((tb * G) / U);
+      while (U * (w_first + 1) / G <= tb) ++w_first;
+      while (w_first > 0 && U * w_first / G > tb) --w_first;
+      int w_last = (int)(((te - 1) * G) / U);
+      while (U * w_last / G >= te) --w_last;
+      while (w_last + 1 < G && U * (w_last + 1) / G < te) ++w_last;
+      const int count = w_last - w_first + 1;
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = (old == count - 1) ? 1 : 0;
+        if (old == count - 1) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      __syncthreads();
+      reducer = flag[0] != 0;
+      __syncthreads();
+      if (reducer) {
+        // fixed order: zero, then every contributing range from the first workgroup to the last (own slab re-read too)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) acc[nh][kh][j][i] = f32x4{0, 0, 0, 0};
+        for (int w = w_first; w <= w_last; ++w) {
+          // segment index of workgroup w on this tile: 0 if its range starts inside (or at the start of) the tile's part it
+          // processes first, i.e. if the tile contains the range start; else 1
+          const int64_t wu0 = U * w / G;
+          const int sidx = (wu0 >= tb) ? 0 : ((wu0 / a.steps == tile) ? 0 : 1);
+          const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)w * 2 + sidx) * (DW_T * DW_T)) + (int64_t)wid * 32 * 64 + lane;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[nh][kh][j][i] += o4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64];
+        }
+      }
+    }
+
+    // ---- epilogue: lane (fr, kg) of MFMA tile (n-tile j, k-tile i) holds dW[n = .. + fr][k = .. + 4 kg .. + 3]
+    if (reducer) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wr * 128 + nh * 64 + j * 16 + fr;
+          if (n < a.N) {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int k = k0 + wc * 64 + kh * 32 + i * 16 + kg * 4;
+                if (k < a.K) *(f32x4*)(a.W + (int64_t)n * a.K + k) = acc[nh][kh][j][i];
+              }
+          }
+        }
+    }
+    ++seg;
+    __syncthreads();                         // LDS (flag word, ring) is re-used by the next segment
+  }
+}
+
+}  // namespace octic
+
+using namespace octic;
+
+extern "C" {
+
+static int dw_grid(int64_t units) {
+  return units < 256 ? (int)units : 256;     // one workgroup per CU (every range non-empty); equal ranges: equally long
+}
+
+int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K) {
+  const int tiles = (N / DW_T) * (K / DW_T);
+  const int G = dw_grid((int64_t)tiles * ((M + DW_BR - 1) / DW_BR));
+  return (int64_t)2 * G * (DW_T * DW_T) * 4 + (int64_t)tiles * 4 + 256;
+}
+
+int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
+                         void* workspace, void* stream) {
+  if (!dY || !X || !dW || !workspace) return OCTIC_ENULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (N % DW_T) || (K % DW_T) || (ldy % 8) || (ldx % 8)) return OCTIC_ESHAPE;
+  if ((N / DW_T) * (K / DW_T) > 256) return OCTIC_ESHAPE;     // a workgroup's range must touch at most two tiles
+  if ((((uintptr_t)dY) | ((uintptr_t)X) | ((uintptr_t)dW)) & 15) return OCTIC_EALIGN;
+  DwArgs a = {};
+  a.Y = (const bf16*)dY; a.X = (const bf16*)X; a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  a.W = dW;
+  a.tiles_k = K / DW_T;
+  a.tiles = (N / DW_T) * a.tiles_k;
+  a.steps = (M + DW_BR - 1) / DW_BR;
+  const int G = dw_grid((int64_t)a.tiles * a.steps);
+  a.tickets = (int*)workspace;
+  char* p = (char*)workspace + (((int64_t)a.tiles * 4 + 255) & ~(int64_t)255);
+  a.slabs = (float*)p;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(a.tickets, 0, (size_t)a.tiles * 4, s);
+  const int smem = DW_SLOTS * DW_UNIT;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)dense_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  dense_tn_kernel<<<G, 512, smem, s>>>(a);
+  return launch_status();
+}
+
+}  // extern "C"
