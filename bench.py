@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true")
+    ap.add_argument("--wgrad-bf16-out", action="store_true", help="developer A/B: library weight gradients in bf16 + cast")
     ap.add_argument("--dense-hip", default=None,
                     help="developer A/B: comma list of standard-half GEMMs on csrc/dense_gemm.hip (default: functional.DENSE_HIP; 'none' = library)")
     args = ap.parse_args()
@@ -106,6 +107,9 @@ def main():
     if args.dense_hip is not None:
         from octic_vits_amd import functional as _OF
         _OF.DENSE_HIP = set() if args.dense_hip == "none" else set(args.dense_hip.split(","))
+    if args.wgrad_bf16_out:
+        from octic_vits_amd import functional as _OF
+        _OF.WGRAD_F32_OUT = False
     world, rank, local_rank = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

@@ -301,7 +301,8 @@ int octic_dense_prep_batch(const octic_dense_prep_item* items_dev, int n_items, 
  *             = x + drop_path(gamma * f(x)) of deit/vit.py:131-134 with f32 residual stream X / OUT [M,N] dense
  *   3 DGELU : C = gelu'(H) * acc   with H the saved pre-activation (fc2 input gradient fused with GELU backward)
  * C / C2 / H are bf16 [M,N] with row stride ldc.  bias, gamma [N] f32 and rs f32 may be NULL.  workspace:
- * octic_dense_gemm_workspace_bytes(M,N,K) bytes (split-K slabs of the last partial round of tiles + tickets).  */
+ * octic_dense_gemm_workspace_bytes(M,N,K) bytes (split-K slabs of the last partial round of tiles + tickets), ZEROED once
+ * by the caller when it is allocated (the kernels re-arm their tickets; calls sharing a workspace must be stream-ordered). */
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K);
 int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs,
@@ -312,7 +313,7 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
  *     dW[N,K] = dY[M,N]^T . X[M,K]     f32, nn.Linear layout
  * dY, X bf16 row-major (ldy, ldx row strides in elements), N % 256 == 0, K % 256 == 0, (N/256)(K/256) <= 256.  The
  * reduction over the M token rows is split stream-K style over 256 workgroups; partial tiles are summed in a fixed order
- * (bitwise reproducible).  workspace: octic_dense_wgrad_workspace_bytes(M,N,K).                              */
+ * (bitwise reproducible).  workspace: octic_dense_wgrad_workspace_bytes(M,N,K) bytes, zeroed once at allocation.      */
 int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K);
 int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
                          void* workspace, void* stream);

@@ -327,6 +327,36 @@ __global__ __launch_bounds__(256) void dense_prep_batch_kernel(const octic_dense
   const TS* w = (const TS*)I.src;
   bf16* wb = (bf16*)I.wb;
   bf16* wt = (bf16*)I.wt;
+  const bool vec = (N % 8) == 0 && (K % 8) == 0;             // 16-byte rows both ways (every nn.Linear of the models)
+  if (vec) {
+    // read: 8 consecutive k of one row n per thread (two rows per thread), write: 8 consecutive n of one row k
+    const int c8 = (threadIdx.x & 7) * 8, r = threadIdx.x >> 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + r + 32 * h, k = k0 + c8;
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (n < N && k < K) {
+        load8<TS>(w + (int64_t)n * K + k, v);
+        if (wb) store8<bf16>(wb + (int64_t)n * K + k, v);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tile[r + 32 * h][c8 + e] = v[e];
+    }
+    __syncthreads();
+    if (wt) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = k0 + r + 32 * h, n = n0 + c8;
+        if (k < K && n < N) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = tile[c8 + e][r + 32 * h];
+          store8<bf16>(wt + (int64_t)k * N + n, v);
+        }
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {

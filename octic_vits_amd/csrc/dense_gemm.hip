@@ -460,6 +460,9 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
       if (old == a.split - 1) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every slice of the tile has arrived: re-arm the ticket for the next launch (the workspace is zeroed once, when
+        // it is allocated; launches that share it are stream-ordered) - no per-launch memset node
+        __hip_atomic_store(a.tickets + rem_idx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();
@@ -630,7 +633,6 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
     if (!workspace) return OCTIC_ENULL;
     a.tickets = (int*)workspace;
     a.slabs = (float*)((char*)workspace + (((int64_t)p.rem * 4 + 255) & ~(int64_t)255));
-    (void)hipMemsetAsync(a.tickets, 0, (size_t)p.rem * 4, s);
   }
   const int smem = DG_LDS;
   static bool attr_done = false;

@@ -39,7 +39,7 @@ struct DwArgs {
   int tiles;          // (N / 256) * (K / 256), tile = tn * tiles_k + tk
   int steps;          // ceil(M / 64) reduction steps per tile
   float* slabs;       // [2 * grid] x 256 x 256 f32 partial tiles
-  int* tickets;       // [tiles], zeroed per launch
+  int* tickets;       // [tiles], zero when the workspace is created; the last arriver of a tile re-arms its ticket
 };
 
 __device__ inline void dw_wait_vmcnt(int n) {
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
         if (old == count - 1) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
         }
       }
       __syncthreads();
@@ -369,7 +370,8 @@ static int dw_grid(int64_t units) {
 int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K) {
   const int tiles = (N / DW_T) * (K / DW_T);
   const int G = dw_grid((int64_t)tiles * ((M + DW_BR - 1) / DW_BR));
-  return (int64_t)2 * G * (DW_T * DW_T) * 4 + (int64_t)tiles * 4 + 256;
+  (void)tiles;
+  return (int64_t)2 * G * (DW_T * DW_T) * 4 + 4096;      // [4 KiB tickets (<= 256 tiles) | slabs]
 }
 
 int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
@@ -386,10 +388,9 @@ int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int
   a.steps = (M + DW_BR - 1) / DW_BR;
   const int G = dw_grid((int64_t)a.tiles * a.steps);
   a.tickets = (int*)workspace;
-  char* p = (char*)workspace + (((int64_t)a.tiles * 4 + 255) & ~(int64_t)255);
+  char* p = (char*)workspace + 4096;         // fixed ticket region: a workspace shared by several shapes keeps its zeros
   a.slabs = (float*)p;
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(a.tickets, 0, (size_t)a.tiles * 4, s);
   const int smem = DW_SLOTS * DW_UNIT;
   static bool attr_done = false;
   if (!attr_done) {

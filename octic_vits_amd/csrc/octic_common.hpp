@@ -47,6 +47,36 @@ __device__ inline T* view_ptr(const View& v, int64_t m, int e, int c) {
 __device__ inline float bf2f(bf16 x) { return (float)x; }
 __device__ inline bf16 f2bf(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 
+// 8 consecutive elements <-> 8 floats (16-byte accesses)
+template <typename T>
+__device__ inline void load8(const T* p, float v[8]);
+template <>
+__device__ inline void load8<float>(const float* p, float v[8]) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <>
+__device__ inline void load8<bf16>(const bf16* p, float v[8]) {
+  bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <typename T>
+__device__ inline void store8(T* p, const float v[8]);
+template <>
+__device__ inline void store8<float>(float* p, const float v[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  *(f32x4*)p = a;
+  *(f32x4*)(p + 4) = b;
+}
+template <>
+__device__ inline void store8<bf16>(bf16* p, const float v[8]) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+  *(bf16x8*)p = a;
+}
+
 // 8-point D8 Fourier butterflies (reference d8_utils.py:276-344).  Unscaled; callers
 // multiply by (sqrt2/4) once.
 __device__ inline void iso_to_reg(const float x[8], float r[8]) {

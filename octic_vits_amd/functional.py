@@ -550,6 +550,8 @@ def track_optimizer(model, optimizer):
 # hand-written kernel wins where the tile count fills whole rounds of the 256 CUs or the fused tail removes a full pass
 # (qkv forward and input gradient, fc1 + GELU); on the N = 1280 problems (325 tiles = 1.27 rounds at B = 64) the library's
 # stream-K kernels are ahead and a fused heavy epilogue cannot overlap with anything (one workgroup per CU).
+WGRAD_F32_OUT = False      # True: library weight gradients as torch.mm(..., out_dtype=float32) (no bf16 rounding of
+                           # dW; measured equal in step time, but outside the shipped TunableOp table)
 DENSE_HIP = {"qkv", "dqkv", "fc1"}          # subset of {"qkv", "dqkv", "proj", "dproj", "fc1", "dfc1", "fc2", "dfc2"}
 
 
@@ -576,6 +578,10 @@ def _timed_lib(kind, fn, M, N, K):
 def _wgrad_lib(g2, x2):
     """dW = g^T x (f32 result).  Weight gradients of the standard half stay on the BLAS library."""
     with torch.autocast("cuda", enabled=False):
+        if WGRAD_F32_OUT:
+            # bf16 operands, f32 result straight from the GEMM: no bf16 rounding of the gradient, no cast launch
+            return _timed_lib("wgrad", lambda: torch.mm(g2.t(), x2, out_dtype=torch.float32), g2.shape[0], g2.shape[1],
+                              x2.shape[1])
         w = _timed_lib("wgrad", lambda: g2.t() @ x2, g2.shape[0], g2.shape[1], x2.shape[1])
         return w.float()
 

@@ -540,7 +540,7 @@ def _dense_ws(M, N, K, dev):
     key = (M, N, K, dev)
     ws = _DG_WS.get(key)
     if ws is None:
-        ws = _DG_WS[key] = torch.empty(int(lib().octic_dense_gemm_workspace_bytes(M, N, K)), dtype=torch.uint8, device=dev)
+        ws = _DG_WS[key] = torch.zeros(int(lib().octic_dense_gemm_workspace_bytes(M, N, K)), dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -590,7 +590,7 @@ def dense_wgrad_tn(dy, x, name=None):
     need = int(lib().octic_dense_wgrad_workspace_bytes(M, N, K))
     ws = _DW_WS.get(dy.device)
     if ws is None or ws.numel() < need:          # one workspace per device: launches on a stream are serial
-        ws = _DW_WS[dy.device] = torch.empty(need, dtype=torch.uint8, device=dy.device)
+        ws = _DW_WS[dy.device] = torch.zeros(need, dtype=torch.uint8, device=dy.device)
     dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     t = KERNEL_TIMER.start()
     check(lib().octic_dense_wgrad_tn(_p(dy), _p(x), M, N, K, dy.stride(0), x.stride(0), _p(dw), _p(ws), _stream(dy)))
