@@ -78,6 +78,7 @@ _PROTOS = {
                                 c_int, c_void_p]),
     "octic_lift_wgrad_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "octic_lift_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p]),
+    "octic_mlp_d8_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "octic_dense_prep_batch_blocks": (c_int, [c_int, c_int]),
     "octic_dense_prep_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "octic_dense_wgrad_workspace_bytes": (c_i64, [c_int, c_int, c_int]),

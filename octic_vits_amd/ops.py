@@ -596,3 +596,24 @@ def dense_wgrad_tn(dy, x, name=None):
     check(lib().octic_dense_wgrad_tn(_p(dy), _p(x), M, N, K, dy.stride(0), x.stride(0), _p(dw), _p(ws), _stream(dy)))
     KERNEL_TIMER.stop(t, name or f"dense_tn_kernel<{N}x{K}>", 2 * (M * N + M * K) + 4 * N * K, 2.0 * M * N * K)
     return dw
+
+
+# ------------------------------------------------------------------------------------------ fused MlpD8 front half
+def mlp_d8_gelu_ok(cin, cout, dtype):
+    return dtype == torch.bfloat16 and cin in (128, 160) and cout % 16 == 0
+
+
+def mlp_d8_gelu(x, w_flat, bias, cin, cout, mode, h=None):
+    """mode 0: (h, y) = (fc1(x), gelu_D8(h)); mode 1: dh = gelu_D8'(h; x W^T).  x packed [.., 8 cin] bf16, w_flat the flat
+    prepared weight buffer (wb of fc1 / wt of fc2), see octic_mlp_d8_gelu."""
+    _require_cuda(x)
+    M = x.numel() // (8 * cin)
+    out_shape = x.shape[:-1] + (8 * cout,)
+    y = torch.empty(out_shape, dtype=torch.bfloat16, device=x.device)
+    if mode == 0:
+        h = torch.empty(out_shape, dtype=torch.bfloat16, device=x.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_mlp_d8_gelu(_p(x), _p(w_flat), _p(bias), _p(h), _p(y), M, cin, cout, mode, _stream(x)))
+    KERNEL_TIMER.stop(t, f"mlp_d8_gelu_kernel<{'bwd' if mode else 'fwd'}>", 2 * M * 8 * (cin + 2 * cout) + 16 * cin * cout,
+                      24.0 * M * cin * cout)
+    return (h, y) if mode == 0 else y
