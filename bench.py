@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every step eagerly (default at 1 GPU: the step is captured once with Trainer.capture and "
+                         "replayed as one hipGraph; the kernel-timing steps stay eager.  With DDP the steps are always eager)")
     ap.add_argument("--wgrad-bf16-out", action="store_true", help="developer A/B: library weight gradients in bf16 + cast")
     ap.add_argument("--dense-hip", default=None,
                     help="developer A/B: comma list of standard-half GEMMs on csrc/dense_gemm.hip (default: functional.DENSE_HIP; 'none' = library)")
@@ -132,6 +135,11 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             log("first warm-up step done")
+    graphed = None
+    if world == 1 and not args.no_graph:
+        graphed = trainer.capture(samples, targets, warmup=1)
+        for _ in range(2):
+            graphed.replay()
     sync()
     log("warm-up done, timing")
     if not args.no_kernel_timing:
@@ -145,7 +153,10 @@ def main():
     for i in range(args.steps):
         if timing:
             ops.KERNEL_TIMER.on = i in sampled
-        loss = trainer.step(samples, targets)
+        if graphed is not None and not (timing and i in sampled):
+            loss = graphed.replay()
+        else:
+            loss = trainer.step(samples, targets)
     issued = time.perf_counter() - t0          # host time to enqueue the steps (no sync): launch-bound if ~ elapsed
     sync()
     elapsed = time.perf_counter() - t0
@@ -198,7 +209,8 @@ def main():
                                    f"bf16-autocast fwd + bwd + LAMB + EMA, 224x224, batch {args.batch}/GPU "
                                    f"(BASELINE configs[1]), data parallel over {world} GPU(s)",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
-                       "library_gemm_table": bool(trainer.tuned_gemms)},
+                       "library_gemm_table": bool(trainer.tuned_gemms),
+                       "launch": "hipGraph replay (kernel-timing steps eager)" if graphed is not None else "eager"},
             "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),
             "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4),
         }

@@ -163,15 +163,23 @@ def _unfold_tables(h: int, kind: str):
     return ia.flatten(), sa.flatten().float(), ib.flatten(), sb.flatten().float()
 
 
+@lru_cache(maxsize=None)
+def _unfold_tables_on(h: int, kind: str, device: str, dtype):
+    """The tables resident on `device` (uploaded once: a training step does no host-to-device copies, which also
+    keeps it capturable in a hipGraph)."""
+    ia, sa, ib, sb = _unfold_tables(h, kind)
+    dev = torch.device(device)
+    return (ia.to(dev), sa.to(dev, dtype), None if ib is None else ib.to(dev), None if sb is None else sb.to(dev, dtype))
+
+
 def _gather_unfold(flat, dim, h, kind):
     """flat: tensor whose dimension `dim` enumerates the h*h quarter; returns it with (2h)^2 entries."""
-    ia, sa, ib, sb = _unfold_tables(h, kind)
-    dev = flat.device
+    ia, sa, ib, sb = _unfold_tables_on(h, kind, str(flat.device), flat.dtype)
     shape = [1] * flat.dim()
     shape[dim] = -1
-    out = flat.index_select(dim, ia.to(dev)) * sa.to(dev, flat.dtype).view(shape)
+    out = flat.index_select(dim, ia) * sa.view(shape)
     if ib is not None:
-        out = out + flat.index_select(dim, ib.to(dev)) * sb.to(dev, flat.dtype).view(shape)
+        out = out + flat.index_select(dim, ib) * sb.view(shape)
     return out
 
 

@@ -159,6 +159,7 @@ class FusedLamb:
             self._wt_items = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
             self._wt_blocks = blocks
         self._g_key = None
+        self._g_pinned, self._g_capture_host = [], None
         self.ntensors, self.nchunks = len(self.params), len(ct)
         self.ws = torch.zeros(int(_lib.lib().octic_lamb_workspace_floats(self.ntensors, self.nchunks)),
                               dtype=torch.float32, device=dev)
@@ -182,6 +183,11 @@ class FusedLamb:
         """EMA weights as {param index: tensor view} (same order as the parameters)."""
         return [self.ema[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self._offs)]
 
+    def prepare_capture(self):
+        """Page-locked staging for the gradient address table of a step that is about to be captured (host
+        allocations are not allowed while a stream is capturing)."""
+        self._g_capture_host = torch.empty(len(self.params), dtype=torch.int64).pin_memory()
+
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             if set_to_none:
@@ -200,12 +206,23 @@ class FusedLamb:
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = p.grad = g.float().contiguous()
             grads.append(g)
-        if self.step_count == 0 or (self.step_count & 63) == 0:      # the tables hold raw parameter addresses
+        capturing = torch.cuda.is_current_stream_capturing()
+        if (self.step_count == 0 or (self.step_count & 63) == 0) and not capturing:   # the tables hold raw parameter addresses
             if tuple(p.data_ptr() for p in self.params) != tuple(self.p_ptrs.tolist()):
                 raise RuntimeError("FusedLamb: a parameter was re-allocated after the optimizer was built "
                                    "(move the model to its device before constructing the optimizer)")
         key = tuple(g.data_ptr() for g in grads)
-        if key != self._g_key:
+        if capturing:
+            # the upload becomes a node of the graph: its source must stay valid (and unchanged) for every replay, so
+            # it is a pinned buffer owned by this capture; eager steps afterwards upload their own table again
+            if self._g_capture_host is None:
+                raise RuntimeError("FusedLamb: call prepare_capture() before capturing a step")
+            host, self._g_capture_host = self._g_capture_host, None
+            host.copy_(torch.tensor(key, dtype=torch.int64))
+            self._g_pinned.append(host)
+            self.g_ptrs.copy_(host, non_blocking=True)
+            self._g_key = None
+        elif key != self._g_key:
             self.g_ptrs.copy_(torch.tensor(key, dtype=torch.int64), non_blocking=False)
             self._g_key = key
         self.step_count += 1
@@ -378,6 +395,61 @@ class Trainer:
             self.ema.update(self.raw_model)
         self._pending_loss = loss.detach()
         return loss
+
+    # ---- the whole iteration as one hipGraph -----------------------------------------------------------------------
+    def capture(self, samples, targets, warmup=3):
+        """Record forward + backward + optimizer of ``step`` once (static shapes) and return a ``GraphedStep`` whose
+        ``replay(samples, targets)`` re-launches it with one host call: the ~3000 kernel launches of a ViT-H step
+        cost the host nothing any more.  Everything the step needs is already device-side: the bias-correction step
+        and the non-finite-gradient guard live in the optimizer kernels, the drop-path masks come from the device
+        generator (advanced per replay by torch's graph support), the prepared weights are refreshed by the captured
+        launches themselves.  ``warmup`` eager steps run first (they also build every lazily created cache).
+        Single-process only: with DDP the bucketed all-reduce stays eager."""
+        if self.device_type != "cuda" or not isinstance(self.optimizer, FusedLamb):
+            raise RuntimeError("Trainer.capture needs the GPU and the fused optimizer")
+        if self.model is not self.raw_model:
+            raise RuntimeError("Trainer.capture: distributed steps are not captured")
+        if self.accum_steps != 1:
+            raise RuntimeError("Trainer.capture: accum_steps > 1 is not captured")
+        from . import ops
+        if ops.KERNEL_TIMER.on:
+            raise RuntimeError("Trainer.capture: disable the kernel timer first")
+        sx, sy = samples.clone(), targets.clone()
+        for _ in range(max(1, warmup)):
+            self.step(sx, sy)
+        torch.cuda.synchronize()
+        self.model.train()
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.prepare_capture()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            loss = self._forward_loss(sx, sy)
+            loss.backward()
+            self.optimizer.step()
+        return GraphedStep(self, graph, sx, sy, loss.detach())
+
+
+class GraphedStep:
+    """A captured training iteration (see ``Trainer.capture``).  ``replay`` copies the batch into the graph's input
+    buffers, launches the graph and returns the (device-resident) loss of this iteration."""
+
+    def __init__(self, trainer, graph, samples, targets, loss):
+        self.trainer, self.graph, self.samples, self.targets, self.loss = trainer, graph, samples, targets, loss
+
+    def replay(self, samples=None, targets=None):
+        t = self.trainer
+        t._steps += 1
+        # the same one-step-late check as Trainer.step; self.loss is overwritten by the replay, so look first
+        if t._pending_loss is not None and t._steps % t.check_every == 0 and not math.isfinite(t._pending_loss.item()):
+            raise FloatingPointError("Loss is not finite, stopping training")
+        if samples is not None and samples.data_ptr() != self.samples.data_ptr():
+            self.samples.copy_(samples, non_blocking=True)
+        if targets is not None and targets.data_ptr() != self.targets.data_ptr():
+            self.targets.copy_(targets, non_blocking=True)
+        self.graph.replay()
+        t.optimizer.step_count += 1
+        t._pending_loss = self.loss
+        return self.loss
 
 
 class _null:

@@ -328,3 +328,53 @@ def test_invariant_vit_huge_full_size():
             got = net(R.image_space_group_action(g, x[:2]).contiguous()).float()
             err = float((got - base).abs().max())
             assert err <= 3e-2 * scale, f"invariance under {g}: {err:.3e} vs scale {scale:.3e}"
+
+
+def test_captured_step_replays_like_eager_steps():
+    """Trainer.capture: forward + backward + LAMB/EMA as one hipGraph.  Two identically initialised trainers, one
+    stepping eagerly and one replaying its captured graph on the same batches, must produce the same losses and weights (same kernels,
+    same order); the device-side step counter keeps the bias correction advancing."""
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.train import Trainer, synthetic_batch
+    kw = dict(img_size=32, patch_size=4, in_chans=3, num_classes=10, embed_dim=128, depth=4, num_heads=2,
+              mlp_ratio=4.0, drop_path_rate=0.0, octic_equi_break_layer=2)
+    torch.manual_seed(0)
+    ma = OcticVisionTransformer(**kw).cuda()
+    torch.manual_seed(0)
+    mb = OcticVisionTransformer(**kw).cuda()
+    ta, tb = Trainer(ma, lr=1e-3), Trainer(mb, lr=1e-3)
+    batches = [synthetic_batch(8, 10, "cuda", seed=s, img_size=32) for s in range(5)]
+    warm = batches[0]
+    gs = tb.capture(*warm, warmup=2)
+    for _ in range(2):
+        ta.step(*warm)
+    la, lb = [], []
+    for x, y in batches[1:] + batches[1:]:
+        la.append(float(ta.step(x, y).detach()))
+        lb.append(float(gs.replay(x, y)))
+    assert la == lb, (la, lb)
+    assert len(set(la)) == len(la)                 # the weights did move between the steps
+    # not bitwise: the pos_embed gradient is ATen's index_select backward (atomic adds -> run-to-run rounding
+    # differences), which reaches every tensor through LAMB's global gradient norm
+    for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.allclose(pa, pb, rtol=0, atol=1e-6), n
+    for ea, eb in zip(ta.optimizer.ema_state(), tb.optimizer.ema_state()):
+        assert torch.allclose(ea, eb, rtol=0, atol=1e-6)
+    # an eager step after the replays continues from the same state (the caches were refreshed on the device)
+    x, y = batches[0]
+    assert abs(float(ta.step(x, y).detach()) - float(tb.step(x, y).detach())) < 1e-6
+    assert abs(float(ta.step(x, y).detach()) - float(gs.replay(x, y))) < 1e-6
+
+
+def test_captured_step_draws_fresh_drop_path_masks():
+    """The drop-path masks come from the device generator: replays of one graph must not repeat the captured draw."""
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.train import Trainer, synthetic_batch
+    torch.manual_seed(0)
+    m = OcticVisionTransformer(img_size=32, patch_size=4, in_chans=3, num_classes=10, embed_dim=128, depth=4,
+                               num_heads=2, mlp_ratio=4.0, drop_path_rate=0.5, octic_equi_break_layer=2).cuda()
+    t = Trainer(m, lr=0.0)                      # lr = 0: the weights stay put, the loss varies with the masks only
+    x, y = synthetic_batch(8, 10, "cuda", seed=1, img_size=32)
+    gs = t.capture(x, y, warmup=1)
+    losses = {float(gs.replay(x, y)) for _ in range(6)}
+    assert len(losses) > 1
