@@ -57,7 +57,10 @@ inline int attn_rsv(int dp) { int r = dp * 2; return ((r / 4) % 32 == 0) ? r + 6
 // Stage two row images (zero-filled beyond T rows / kcA, kcB source chunks per row) with all global loads of a batch
 // in flight before the first LDS store.  The s_memtime timeline showed 10-20k cycles (a third of the kernel) in
 // the one-load-one-store loops this replaces: every trip waited out a full HBM round trip.
-constexpr int kStageBatch = 5;
+#ifndef OCTIC_STAGE_BATCH
+#define OCTIC_STAGE_BATCH 5
+#endif
+constexpr int kStageBatch = OCTIC_STAGE_BATCH;
 __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA, int64_t stA, int kcA, int wcA,
                                           char* imgB, int rsB, const bf16* srcB, int64_t stB, int kcB, int wcB,
                                           int T, int Tp, int tid, int nthr) {
@@ -103,7 +106,7 @@ __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA,
 // it against its 1-2 tiles of the other dimension and the partial results are combined through LDS (the K/V images
 // are dead by then).
 #ifdef OCTIC_ATTN_TRACE
-// developer-only timeline (build with -DOCTIC_ATTN_TRACE): [kernel 0 fwd / 1 dq / 2 dkv][256 workgroups][10 waves][16]
+// developer-only timeline (build with -DOCTIC_ATTN_TRACE=<first workgroup>): [kernel 0 fwd / 1 dq / 2 dkv][256 workgroups][10 waves][16]
 __device__ unsigned long long g_attn_trace[3 * 256 * 10 * 16];
 extern "C" void* octic_dbg_attn_trace(void) {
   void* p = nullptr;
@@ -112,8 +115,8 @@ extern "C" void* octic_dbg_attn_trace(void) {
 }
 #define ATRACE(kern, slot)                                                                              \
   do {                                                                                                  \
-    if (blockIdx.x < 256 && (threadIdx.x & 63) == 0 && (slot) < 16)                                     \
-      g_attn_trace[(((kern) * 256 + blockIdx.x) * 10 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); \
+    if (blockIdx.x >= OCTIC_ATTN_TRACE && blockIdx.x < OCTIC_ATTN_TRACE + 256 && (threadIdx.x & 63) == 0 && (slot) < 16)     \
+      g_attn_trace[(((kern) * 256 + blockIdx.x - OCTIC_ATTN_TRACE) * 10 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define ATRACE(kern, slot) do {} while (0)
@@ -336,12 +339,240 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
   combine_store<DT>(parts, W, ml + W * 32, ml + 2 * W * 32, 1.0f, ob, a.oT, W * 32, T, hd, tid, blockDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent forward for nt <= 9 tiles (T <= 258 with at most two rows in the ninth tile: the ViT token counts).
+// The kernel above spends more than a third of a workgroup's life loading the head's rows with idle matrix cores
+// (s_memtime timeline at (64,16,257,80): load 11k cycles, barrier 1.3k, passes 15.5k, store 1.8k) and the 106 KB of
+// images allow no second workgroup on the CU to fill the gap.  Here one workgroup per CU walks over its heads and
+// fetches the NEXT head while it computes the current one:
+//   * K: two images, the next one filled by LDS-DMA (buffer_load ... lds, 16 B per lane; a wave-instruction fills
+//     1 KiB of the padded image, the lanes that fall on the pad chunk or beyond row T read out of the descriptor's
+//     range and get zeros) - no registers, no instructions besides the issue;
+//   * V: one image (its reads need the zero pad columns), the next head's rows wait in registers (<= 6 x 16 B per
+//     lane) from the start of the pass until every wave is done with the current image;
+//   * Q rows of the next head are requested right after the last use of the current ones.
+// Eight waves (two per SIMD, one query tile each); the ninth tile's one or two queries are shared: wave w runs them
+// against key tiles w, w + 8 and wave 0 merges the eight partial rows.  Two barriers per head.
+template <int KS, int DT>
+__global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int rsk, int rsv, int nt, int units) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.T, hd = a.hd;
+  const int W = blockDim.x >> 6;             // min(nt, 8) waves
+  const int nthr = blockDim.x;
+  const int Tp = nt * 32;
+  const int kimg = (Tp * rsk + 1023) & ~1023;          // K image, rounded up to whole DMA instructions
+  char* const Vs = smem + 2 * kimg;
+  constexpr int DC = DT * 32 + kPartPad;
+  const int nrows = T - W * 32;                        // queries of the shared tile (<= 0: none)
+  float* const parts = (float*)(Vs + (size_t)Tp * rsv);          // [W][nrows][DC]
+  float* const ml = parts + (size_t)W * (nrows > 0 ? nrows : 0) * DC;   // m[W][nrows] | l[W][nrows]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, half = lane >> 5;
+  const int G = gridDim.x;
+  constexpr int kc = 2 * KS;                           // 16-byte chunks of a row (hd / 8)
+
+  // ---- K DMA: wave w issues instructions w, w + W, ...; instruction i covers image bytes [1024 i, 1024 i + 1024)
+  constexpr int MAXI = 8;
+  const int ninstr = kimg >> 10;
+  const int cpr = rsk >> 4;                            // chunks per image row (data + pad)
+  unsigned voff[MAXI];
+#pragma unroll
+  for (int j = 0; j < MAXI; ++j) {
+    const int idx = (wid + j * W) * 64 + lane;
+    const int row = idx / cpr, ch = idx - row * cpr;
+    voff[j] = (ch < kc && row < T) ? (unsigned)(row * (int)a.sT * 2 + ch * 16) : 0x7FFFFFF0u;
+  }
+  const int krec = (int)((T - 1) * a.sT * 2 + hd * 2);
+  // The DMA goes out as inline assembly on purpose: the compiler protects every transposing LDS read that follows a
+  // buffer_load ... lds builtin with s_waitcnt vmcnt(0) (it cannot tell the two K images apart), which would put the
+  // arrival of the NEXT head in front of the first P V product of the current one.  The waits that matter are
+  // written out below (vmcnt(0) in front of the barrier that hands the image over).
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  auto issue_k = [&](const bf16* kb, unsigned lds_dst) {
+    const uint64_t p = (uint64_t)kb;
+    const i32x4 rs = {(int)(uint32_t)p, (int)(uint32_t)((p >> 32) & 0xFFFF), krec, 0x27000};
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+      const int i = wid + j * W;
+      if (i < ninstr)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 1\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(lds_dst + i * 1024), "v"(voff[j]), "s"(rs) : "memory");
+    }
+  };
+  const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // ---- V through registers
+  constexpr int NV = 6;
+  const int nv = (T * kc + nthr - 1) / nthr;           // <= NV (checked by the launcher)
+  u32x4 vreg[NV];
+  auto load_v = [&](const bf16* vb) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it)
+      if (it < nv) {
+        int idx = it * nthr + tid;
+        asm volatile("" : "+v"(idx));                    // recomputed per head: hoisted addresses would cost 2 NV registers
+        const int row = idx / kc, c = idx - row * kc;
+        vreg[it] = u32x4{0, 0, 0, 0};
+        if (row < T) vreg[it] = *(const u32x4*)(vb + (int64_t)row * a.sT + c * 8);
+      }
+  };
+  auto write_v = [&]() {
+#pragma unroll
+    for (int it = 0; it < NV; ++it)
+      if (it < nv) {
+        int idx = it * nthr + tid;
+        asm volatile("" : "+v"(idx));
+        const int row = idx / kc, c = idx - row * kc;
+        if (row < T) *(u32x4*)(Vs + (size_t)row * rsv + c * 16) = vreg[it];
+      }
+  };
+  auto head_off = [&](int u, int64_t& in_off, int64_t& o_off, int64_t& st_off) {
+    const int b = u / a.H, h = u - b * a.H;
+    in_off = b * a.sB + h * a.sH;
+    o_off = b * a.oB + h * a.oH;
+    st_off = ((int64_t)b * a.H + h) * T;
+  };
+
+  int u = blockIdx.x;
+  int64_t in_off, o_off, st_off;
+  head_off(u, in_off, o_off, st_off);
+  bf16x8 qf[KS], qfs[KS];
+  issue_k(a.k + in_off, smem_lds);
+  load_v(a.v + in_off);
+  load_rows8<KS>(qf, a.q + in_off, a.sT, wid, T, lane);
+  if (nrows > 0) load_rows8<KS>(qfs, a.q + in_off, a.sT, W, T, lane);
+  // the V image's pad (columns >= hd, rows >= T) is written once: zeros
+  for (int o = tid * 16; o < Tp * rsv; o += nthr * 16) *(u32x4*)(Vs + o) = u32x4{0, 0, 0, 0};
+  __syncthreads();
+  write_v();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (; u < units; u += G) {
+    const int un = u + G;
+    const bool has_next = un < units;
+    const char* Ks = smem + cur * kimg;
+    const bool tr_on = u == (int)blockIdx.x + G;
+    if (tr_on) ATRACE(0, 0);
+    int64_t n_in = 0, n_o = 0, n_st = 0;
+    // The Q rows were requested a pass ago: settle them HERE, before the prefetch goes out.  Left to the compiler,
+    // the wait lands in front of the first MFMA with a count it cannot know (the prefetch instructions are
+    // predicated), i.e. vmcnt(0) - and the pass would start only after the next head has arrived.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("" : "+v"(qf[ks]));
+      asm volatile("" : "+v"(qfs[ks]));
+    }
+    if (has_next) {
+      head_off(un, n_in, n_o, n_st);
+      issue_k(a.k + n_in, smem_lds + (cur ^ 1) * kimg);
+      load_v(a.v + n_in);
+    }
+    if (tr_on) ATRACE(0, 1);
+    bf16* ob = a.o + o_off;
+    float* lseb = a.lse ? a.lse + st_off : nullptr;
+
+    f32x16 ot[DT];
+    zero_acc<DT>(ot);
+    float m = -INFINITY, l = 0.f;
+    fwd_pass<KS, DT>(a, Ks, Vs, rsk, rsv, qf, 0, 1, nt, lane, m, l, ot);
+    if (tr_on) ATRACE(0, 2);
+    l += __shfl_xor(l, 32, 64);
+    {
+      const int qi = wid * 32 + r;
+      if (qi < T) {
+        if (half == 0 && lseb) lseb[qi] = m + log2f(l);
+        store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half);
+      }
+    }
+    if (has_next) load_rows8<KS>(qf, a.q + n_in, a.sT, wid, T, lane);
+    if (tr_on) ATRACE(0, 3);
+    if (nrows > 0) {
+      // the shared tile against this wave's key tiles; the partial rows meet in LDS
+      zero_acc<DT>(ot);
+      m = -INFINITY;
+      l = 0.f;
+      fwd_pass<KS, DT>(a, Ks, Vs, rsk, rsv, qfs, wid, W, nt, lane, m, l, ot);
+      l += __shfl_xor(l, 32, 64);
+      if (has_next) load_rows8<KS>(qfs, a.q + n_in, a.sT, W, T, lane);
+      if (r < nrows) {
+        float* row = parts + ((size_t)wid * nrows + r) * DC;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4)
+            *(f32x4*)(row + d * 32 + 8 * k4 + 4 * half) =
+                f32x4{ot[d][4 * k4], ot[d][4 * k4 + 1], ot[d][4 * k4 + 2], ot[d][4 * k4 + 3]};
+        if (half == 0) {
+          ml[wid * nrows + r] = m;
+          ml[(W + wid) * nrows + r] = l;
+        }
+      }
+    }
+    if (tr_on) ATRACE(0, 4);
+    __syncthreads();                                   // every wave is done with K[cur] and V
+    if (tr_on) ATRACE(0, 5);
+    if (has_next) write_v();
+    if (tr_on) ATRACE(0, 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the K DMA of the next head has landed
+    if (tr_on) ATRACE(0, 7);
+    __syncthreads();
+    if (tr_on) ATRACE(0, 8);
+    if (nrows > 0 && wid == 0) {
+      for (int rr = 0; rr < nrows; ++rr) {
+        float M = -INFINITY;
+        for (int w = 0; w < W; ++w) M = fmaxf(M, ml[w * nrows + rr]);
+        float L = 0.f, o0 = 0.f, o1 = 0.f;
+        for (int w = 0; w < W; ++w) {
+          const float g = __builtin_amdgcn_exp2f(ml[w * nrows + rr] - M);
+          L += ml[(W + w) * nrows + rr] * g;
+          const float* row = parts + ((size_t)w * nrows + rr) * DC;
+          o0 += g * row[lane];
+          if (lane + 64 < DT * 32) o1 += g * row[lane + 64];
+        }
+        const int qi = W * 32 + rr;
+        const float inv = 1.0f / L;
+        bf16* orow = ob + (int64_t)qi * a.oT;
+        if (lane < hd) orow[lane] = (bf16)(o0 * inv);
+        if (lane + 64 < hd) orow[lane + 64] = (bf16)(o1 * inv);
+        if (lane == 0 && lseb) lseb[qi] = M + log2f(L);
+      }
+    }
+    if (tr_on) ATRACE(0, 9);
+    cur ^= 1;
+    in_off = n_in; o_off = n_o; st_off = n_st;
+  }
+}
+
 template <int KS, int DT>
 static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
   // the forward is light on registers: one wave per tile even for nine tiles (three waves on one SIMD hide the
   // softmax latency better than the shared-tile split does: 78 vs 85 us at T = 257); the kernel supports both
-  const int nt = (a.T + 31) / 32, W = nt;
   const int rsk = attn_rsk(a.hd), rsv = attn_rsv(DT * 32);
+  {
+    const int nt = (a.T + 31) / 32, W = nt < 8 ? nt : 8;
+    const int nrows = a.T - W * 32;
+    const int kimg = (nt * 32 * rsk + 1023) & ~1023;
+    const size_t need = 2 * (size_t)kimg + (size_t)nt * 32 * rsv +
+                        (nrows > 0 ? (size_t)W * nrows * (DT * 32 + kPartPad + 2) * sizeof(float) : 0);
+    const bool fits = nt <= 9 && nrows <= 2 && need <= 160 * 1024 && kimg / 1024 <= 8 * W &&
+                      (a.T * 2 * KS + W * 64 - 1) / (W * 64) <= 6 && (a.T - 1) * a.sT * 2 + a.hd * 2 < 0x7FFFFFF0ll;
+    if (fits) {
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        (void)hipFuncSetAttribute((const void*)attn_fwd_persist_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+      }
+      const int units = (int)(B * a.H);
+      attn_fwd_persist_kernel<KS, DT><<<units < cus ? units : cus, W * 64, need, s>>>(a, rsk, rsv, nt, units);
+      return launch_status();
+    }
+  }
+  const int nt = (a.T + 31) / 32, W = nt;
   size_t smem = (size_t)nt * 32 * (rsk + rsv);
   const size_t comb = ((size_t)W * 32 * (DT * 32 + kPartPad) + (2 * W + 1) * 32) * sizeof(float);
   if (nt != W && comb > smem) smem = comb;

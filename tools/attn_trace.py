@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 buf = torch.zeros(n, dtype=torch.int64, device="cuda")
 hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(src), n * 8, 3)
 tr = buf.cpu().numpy().reshape(3, 256, 10, 16)
-names = {0: ["stage issue", "barrier", "main pass", "store"], 1: ["stage issue", "barrier", "main pass", "store", "shared pass", "barrier", "combine"],
+names = {0: ["wait q + issue", "main pass", "O store + q load", "shared pass", "barrier A", "write V", "vmcnt(0)", "barrier B", "merge"], 1: ["stage issue", "barrier", "main pass", "store", "shared pass", "barrier", "combine"],
          2: ["stage issue", "barrier", "main pass", "store", "shared pass", "barrier", "combine"]}
 for kern, label in ((0, "fwd"), (1, "dq"), (2, "dkv")):
     rows = []

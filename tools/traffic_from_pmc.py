@@ -18,7 +18,12 @@ NAMES = [
     (r"linear_d8_ring_kernel(IDF16bDF16bLi0E|<__bf16, __bf16, 0)", "linear_d8_ring_kernel<bf16,bf16,0>"),
     (r"linear_d8_ring_kernel(IDF16bfLi1E|<__bf16, float, 1|<bool _Accum, 1)", "linear_d8_ring_kernel<bf16,f32,1>"),
     (r"wgrad_ring_kernel", "wgrad_ring_kernel<bf16>"),
-    (r"attn_fwd_kernel", "attn_fwd_kernel"),
+    (r"attn_fwd(_persist)?_kernel", "attn_fwd_kernel"),
+    (r"dense_nt_kernel(ILi0E|<0>)", "dense_nt_kernel<0>"),
+    (r"dense_nt_kernel(ILi1E|<1>)", "dense_nt_kernel<1>"),
+    (r"heads_permute_kernel", "heads_permute_kernel<bf16>"),
+    (r"lamb_stage1_kernel", "lamb_stage1_kernel"),
+    (r"lamb_stage2_kernel", "lamb_stage2_kernel"),
     (r"attn_bwd_dq_kernel", "attn_bwd_dq_kernel"),
     (r"attn_bwd_dkv_kernel", "attn_bwd_dkv_kernel"),
     (r"ln_fwd_g8_kernel", "ln_fwd_kernel<bf16>"),
