@@ -167,9 +167,11 @@ def _unfold_tables(h: int, kind: str):
 def _unfold_tables_on(h: int, kind: str, device: str, dtype):
     """The tables resident on `device` (uploaded once: a training step does no host-to-device copies, which also
     keeps it capturable in a hipGraph)."""
-    ia, sa, ib, sb = _unfold_tables(h, kind)
-    dev = torch.device(device)
-    return (ia.to(dev), sa.to(dev, dtype), None if ib is None else ib.to(dev), None if sb is None else sb.to(dev, dtype))
+    with torch.inference_mode(False):      # cached: must be ordinary tensors even if the first caller is in inference mode
+        ia, sa, ib, sb = _unfold_tables(h, kind)
+        dev = torch.device(device)
+        t = lambda x, *a: None if x is None else x.to(dev, *a).clone()
+        return t(ia), t(sa, dtype), t(ib), t(sb, dtype)
 
 
 def _gather_unfold(flat, dim, h, kind):
