@@ -97,7 +97,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly (default at 1 GPU: the step is captured once with Trainer.capture and "
                          "replayed as one hipGraph; the kernel-timing steps stay eager.  With DDP the steps are always eager)")
-    ap.add_argument("--wgrad-bf16-out", action="store_true", help="developer A/B: library weight gradients in bf16 + cast")
+    ap.add_argument("--wgrad-f32-out", action="store_true",
+                    help="developer A/B: library weight gradients straight to f32 (default: bf16 result + cast, as autocast does)")
     ap.add_argument("--dense-hip", default=None,
                     help="developer A/B: comma list of standard-half GEMMs on csrc/dense_gemm.hip (default: functional.DENSE_HIP; 'none' = library)")
     args = ap.parse_args()
@@ -110,9 +111,9 @@ def main():
     if args.dense_hip is not None:
         from octic_vits_amd import functional as _OF
         _OF.DENSE_HIP = set() if args.dense_hip == "none" else set(args.dense_hip.split(","))
-    if args.wgrad_bf16_out:
+    if args.wgrad_f32_out:
         from octic_vits_amd import functional as _OF
-        _OF.WGRAD_F32_OUT = False
+        _OF.WGRAD_F32_OUT = True
     world, rank, local_rank = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
