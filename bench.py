@@ -138,9 +138,15 @@ def main():
             log("first warm-up step done")
     graphed = None
     if world == 1 and not args.no_graph:
-        graphed = trainer.capture(samples, targets, warmup=1)
-        for _ in range(2):
-            graphed.replay()
+        try:
+            graphed = trainer.capture(samples, targets, warmup=1)
+            for _ in range(2):
+                graphed.replay()
+            torch.cuda.synchronize()
+        except Exception as e:      # a failed capture can leave the stream unusable: measure eagerly in a fresh child
+            log(f"graph capture failed ({type(e).__name__}: {e}); re-running eagerly in a child process")
+            import subprocess
+            raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"]).returncode)
     sync()
     log("warm-up done, timing")
     if not args.no_kernel_timing:

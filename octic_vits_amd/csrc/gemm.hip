@@ -563,6 +563,9 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
 // n-tiles; only W tiles [80 x 64k] stream through a 3-stage LDS-DMA ring (30 KiB LDS -> 3 workgroups per CU).
 // L2->CU traffic for fc1: 42 MB (X once) + 316 MB (W per 128-row block) = 358 MB.
 // ================================================================================================
+#ifndef OCTIC_XREG_ABL
+#define OCTIC_XREG_ABL 0   // developer ablation builds (tools/xreg_variants.py): 1 no W DMA, 2 no global stores, 4 no MFMAs
+#endif
 constexpr int kXStage = kRingBN * 128;   // one W tile: 80 rows x 128 B
 constexpr int kXS = 3;                   // ring depth (5 measured no faster)
 
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
     char* st = lds + l_stage * kXStage;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      if (q < w_cnt)
+      if (q < w_cnt && !(OCTIC_XREG_ABL & 1))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + k * 2),
                                          (__attribute__((address_space(3))) void*)(st + (w_first + q) * 1024), 16, 0, 0);
     l_stage = l_stage == kXS - 1 ? 0 : l_stage + 1;
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
             v = __builtin_bit_cast(u32x4, o);
           }
         }
-        *(u32x4*)(ok ? (TOUT*)G.y + yoff + n : sink) = v;
+        *(u32x4*)((ok && !(OCTIC_XREG_ABL & 2)) ? (TOUT*)G.y + yoff + n : sink) = v;
       }
     }
   };
@@ -835,7 +838,8 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
           for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], xf[kt * 2 + ks][j], acc[i][j], 0, 0, 0);
+              if constexpr (OCTIC_XREG_ABL & 4) acc[i][j][0] += (float)af[i][0] * (float)xf[kt * 2 + ks][j][0];
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], xf[kt * 2 + ks][j], acc[i][j], 0, 0, 0);
         }
       }
       XTRACE(4 + 3 * s);
