@@ -37,12 +37,28 @@ def as_packed(xs):
     return torch.cat([xs[0], xs[1], xs[2], xs[3], xs[4].flatten(-2)], dim=-1), c
 
 
+_FP16_NOTE = [False]
+
+
 def compute_dtype(t: torch.Tensor):
+    """Operand dtype of the octic kernels for `t` under the ambient autocast state.  bf16 autocast -> bf16 (the fast
+    path, BASELINE dtype).  fp16 autocast (the reference's DeiT default, deit/engine.py:56) -> float32: the engine has no
+    fp16 kernels, so the octic half runs on its exact-f32 MFMA path - a superset of fp16's precision, slower than bf16;
+    the standard blocks run the reference's own eager fp16 ops.  Said once on stderr, never silently."""
     if torch.is_autocast_enabled("cuda"):
         dt = torch.get_autocast_dtype("cuda")
-        if dt != torch.bfloat16:
-            raise NotImplementedError("octic engine: autocast is supported with dtype=torch.bfloat16 only")
-        return dt
+        if dt == torch.bfloat16:
+            return dt
+        if dt == torch.float16:
+            if not _FP16_NOTE[0]:
+                _FP16_NOTE[0] = True
+                import sys
+                print("octic engine: fp16 autocast -> the octic blocks compute in float32 (no fp16 kernels; use "
+                      "dtype=torch.bfloat16 for the fast path)", file=sys.stderr)
+            if t.dtype not in (torch.float32, torch.float16):
+                raise TypeError(f"octic engine under fp16 autocast expects float32 / float16 inputs, got {t.dtype}")
+            return torch.float32
+        raise NotImplementedError(f"octic engine: autocast dtype {dt} is not supported (bfloat16 or float16)")
     if t.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f"octic engine supports float32 / bfloat16, got {t.dtype}")
     return t.dtype
@@ -366,7 +382,8 @@ def attention_core(q, k, v, dropout_p=0.0):
     B, H, T, hd = q.shape
     if dropout_p == 0.0 and q.is_cuda and ops.attn_supported(T, hd, q.dtype):
         return AttnFn.apply(q, k, v, hd ** -0.5)
-    return torch.nn.functional.scaled_dot_product_attention(q, k, v, dropout_p=dropout_p)
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v, dropout_p=dropout_p)
+    return o if o.dtype == q.dtype else o.to(q.dtype)       # fp16 autocast hands back fp16: the octic rows stay in q's dtype
 
 
 # -------------------------------------------------------------------------------------- standard half

@@ -81,6 +81,29 @@ class _Autocast(torch.nn.Module):
             return self.mod(x)
 
 
+class _AutocastFp16(_Autocast):
+    def forward(self, x):
+        with torch.autocast("cuda", dtype=torch.float16):
+            return self.mod(x)
+
+
+@pytest.mark.parametrize("name", ["mlp", "attention", "block_deit", "block_dino", "model_hybrid"])
+def test_fp16_autocast_runs_the_octic_half_in_f32(name):
+    """fp16 autocast is the reference's DeiT default (deit/engine.py:56).  The engine has no fp16 kernels: the octic
+    blocks then compute in float32 (functional.compute_dtype), the standard blocks run the reference's eager fp16 ops.
+    Outputs and gradients must stay within fp16-autocast distance of the f32 goldens: 1e-4 where everything is octic,
+    2e-2 relative L2 for the hybrid model (its standard half really is fp16)."""
+    got = cases.run_module_case(product_ns(), name, device="cuda", to_module=_AutocastFp16)
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    lim = 2e-2 if name.startswith("model") else 2e-3
+    for k in want.files:
+        if k not in got:
+            continue
+        a, b = got[k].astype(np.float64).ravel(), want[k].astype(np.float64).ravel()
+        rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+        assert rel <= lim, f"{name}:{k} rel L2 err {rel:.5f} > {lim}"
+
+
 BF16_CASES = ["linear_bias", "layernorm", "gelu", "mlp", "attention", "block_deit", "block_deit_droppath", "block_dino",
               "patch_embed", "model_hybrid", "model_invariant"]
 
