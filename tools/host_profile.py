@@ -23,7 +23,22 @@ for _ in range(5):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"batch {batch}: issue {1e3 * (t1 - t0) / 5:.1f} ms/step, wall {1e3 * (t2 - t0) / 5:.1f} ms/step")
+print(f"batch {batch}: eager issue {1e3 * (t1 - t0) / 5:.1f} ms/step, wall {1e3 * (t2 - t0) / 5:.1f} ms/step")
+# the same step captured once and replayed as one hipGraph (Trainer.capture)
+tr.check_every = 1 << 30            # no host read of the loss: pure launch cost
+gs = tr.capture(x, y, warmup=1)
+for _ in range(3):
+    gs.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    gs.replay()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"batch {batch}: graph replay issue {1e3 * (t1 - t0) / 10:.2f} ms/step, wall {1e3 * (t2 - t0) / 10:.1f} ms/step")
+if "--profile" not in sys.argv:
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
