@@ -142,6 +142,10 @@ def main():
             graphed = trainer.capture(samples, targets, warmup=1)
             for _ in range(2):
                 graphed.replay()
+            # torch.cuda.graph() empties the caching allocator before it captures: one more eager step here lets the
+            # eager kernel-timing steps of the timed region reuse cached blocks instead of calling hipMalloc
+            if not args.no_kernel_timing:
+                trainer.step(samples, targets)
             torch.cuda.synchronize()
         except Exception as e:      # a failed capture can leave the stream unusable: measure eagerly in a fresh child
             log(f"graph capture failed ({type(e).__name__}: {e}); re-running eagerly in a child process")
