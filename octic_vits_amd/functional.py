@@ -415,9 +415,12 @@ class DenseWeightCache:
         if wt_copy is not None:
             self.wt, self.wt_key = wt_copy, self.key
 
-    def get_nt(self, w, b):
-        """(bf16 W [N,K], bf16 W^T [K,N]) for the hand-written dense GEMMs (forward / input-gradient operands)."""
+    def get_nt(self, w, b, need_wt=True):
+        """(bf16 W [N,K], bf16 W^T [K,N] or None) for the hand-written dense GEMMs (forward / input-gradient operands);
+        the transposed copy only exists for layers whose input gradient runs on csrc/dense_gemm.hip."""
         wb, _ = self.get(w, b, torch.bfloat16)
+        if not need_wt:
+            return wb, None
         if getattr(self, "wt_key", None) != self.key:
             with torch.no_grad():
                 self.wt = wb.t().contiguous()
@@ -621,13 +624,13 @@ class DenseLinearNTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, cache, tag):
         xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
-        wb, wt = cache.get_nt(w, b)
+        wb, wt = cache.get_nt(w, b, ("d" + tag) in DENSE_HIP)
         x2 = xb.reshape(-1, wb.shape[1])
         if tag in DENSE_HIP:
             y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b), name="dense_nt_kernel<plain>")
         else:
             y = _linear_lib(x2, wb, None if b is None else cache.b)
-        ctx.save_for_backward(x2, wb, wt)
+        ctx.save_for_backward(x2, wb, wt)          # wt is None unless the input gradient is routed to the HIP kernel
         ctx.meta = (b is not None, x.dtype, x.shape, tag)
         return y.view(*x.shape[:-1], wb.shape[0])
 
@@ -635,10 +638,10 @@ class DenseLinearNTFn(torch.autograd.Function):
     def backward(ctx, gy):
         x2, wb, wt = ctx.saved_tensors
         has_b, x_dtype, x_shape, tag = ctx.meta
-        g2 = _c(gy).reshape(-1, wt.shape[1])
+        g2 = _c(gy).reshape(-1, wb.shape[0])
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (ops.dense_gemm_nt(g2, wt, 0, name="dense_nt_kernel<dgrad>") if ("d" + tag) in DENSE_HIP
+            gx = (ops.dense_gemm_nt(g2, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
                   else _mm_lib(g2, wb)).view(x_shape).to(x_dtype)
         gb = g2.sum(0, dtype=torch.float32) if has_b else None
         return gx, _wgrad_lib(g2, x2), gb, None, None
@@ -652,7 +655,7 @@ class DenseProjResidFn(torch.autograd.Function):
     def forward(ctx, x, a, w, b, gamma, rs, rps, cache):
         x = _c(x)
         ab = _c(a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16))
-        wb, wt = cache.get_nt(w, b)
+        wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP)
         a2 = ab.reshape(-1, wb.shape[1])
         g32, rs32 = _f32(gamma), _f32(rs)
         y, out = ops.dense_gemm_nt(a2, wb, 2, bias=_f32(b), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, wb.shape[0]),
@@ -670,7 +673,7 @@ class DenseProjResidFn(torch.autograd.Function):
                                                     want_colsum=has_b)
         ga = None
         if ctx.needs_input_grad[1]:
-            ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if "dproj" in DENSE_HIP
+            ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
                   else _mm_lib(gy, wb)).view(a_shape).to(a_dtype)
         return gout, ga, _wgrad_lib(gy, a2), colsum, dgamma, None, None, None
 
@@ -686,8 +689,8 @@ class DenseMlpFn(torch.autograd.Function):
     def forward(ctx, y, x, w1, b1, w2, b2, gamma, rs, rps, c1, c2):
         x = _c(x)
         yb = _c(y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16))
-        w1b, w1t = c1.get_nt(w1, b1)
-        w2b, w2t = c2.get_nt(w2, b2)
+        w1b, w1t = c1.get_nt(w1, b1, "dfc1" in DENSE_HIP)
+        w2b, w2t = c2.get_nt(w2, b2, "dfc2" in DENSE_HIP)
         y2 = yb.reshape(-1, w1b.shape[1])
         g32, rs32 = _f32(gamma), _f32(rs)
         if "fc1" in DENSE_HIP:
@@ -712,7 +715,7 @@ class DenseMlpFn(torch.autograd.Function):
         gout = _c(gout.float())
         gbr, dgamma, db2 = ops.scale_residual_bwd(gout.view(br.shape), br, g32, rs32, rps, want_gamma=has_gamma,
                                                   want_colsum=has_b2)
-        if "dfc2" in DENSE_HIP:
+        if w2t is not None:
             dh = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>")     # gelu'(h) * (gbr W2)
             db1 = dh.sum(0, dtype=torch.float32) if has_b1 else None
         else:
@@ -721,7 +724,7 @@ class DenseMlpFn(torch.autograd.Function):
         gw1 = _wgrad_lib(dh, y2)
         gy = None
         if ctx.needs_input_grad[0]:
-            gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>") if "dfc1" in DENSE_HIP
+            gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>") if w1t is not None
                   else _mm_lib(dh, w1b)).view(y_shape).to(y_dtype)
         return gy, gout, gw1, db1, gw2, db2, dgamma, None, None, None, None
 

@@ -130,7 +130,11 @@ class FusedLamb:
         self.g_ptrs = torch.zeros(len(self.params), dtype=i64, device=dev)
         index = {id(p): i for i, p in enumerate(self.params)}
         sh_ptrs, self._shadows = [0] * len(self.params), []
-        for lin, cache in shadow_layers:
+        from . import functional as _OF
+        for item in shadow_layers:
+            lin, cache = item[0], item[1]
+            # a transposed copy only where the input gradient runs on csrc/dense_gemm.hip (role "qkv" -> "dqkv" routed)
+            need_wt = len(item) < 3 or ("d" + item[2]) in _OF.DENSE_HIP
             w, b = lin.weight, lin.bias
             if id(w) not in index or (b is not None and id(b) not in index):
                 continue
@@ -139,25 +143,30 @@ class FusedLamb:
             sh_ptrs[index[id(w)]] = wb.data_ptr()
             if b is not None:
                 sh_ptrs[index[id(b)]] = bb.data_ptr()
-            self._shadows.append((lin, cache, wb, bb))
+            self._shadows.append((lin, cache, wb, bb, need_wt))
         self.s_ptrs = torch.tensor(sh_ptrs, dtype=i64, device=dev) if self._shadows else None
         # transposed bf16 copies (operand of the hand-written input-gradient GEMMs): one batched launch per step
         self._wt, self._wt_items, self._wt_blocks = [], None, 0
-        if self._shadows:
+        wt_layers = [sh for sh in self._shadows if sh[4]]
+        self._wt = [None] * len(self._shadows)
+        if wt_layers:
             import numpy as np
             dt = np.dtype([("src", "<u8"), ("wb", "<u8"), ("wt", "<u8"), ("N", "<i4"), ("K", "<i4"),
                            ("block_begin", "<i4"), ("pad", "<i4")])
-            tab = np.zeros(len(self._shadows), dtype=dt)
-            blocks = 0
-            for i, (lin, cache, wb, bb) in enumerate(self._shadows):
+            tab = np.zeros(len(wt_layers), dtype=dt)
+            blocks, j = 0, 0
+            for i, (lin, cache, wb, bb, need_wt) in enumerate(self._shadows):
+                if not need_wt:
+                    continue
                 N, K = wb.shape
                 wt = torch.empty((K, N), dtype=torch.bfloat16, device=dev)
-                self._wt.append(wt)
-                tab[i]["src"], tab[i]["wb"], tab[i]["wt"] = wb.data_ptr(), 0, wt.data_ptr()
-                tab[i]["N"], tab[i]["K"], tab[i]["block_begin"] = N, K, blocks
+                self._wt[i] = wt
+                tab[j]["src"], tab[j]["wb"], tab[j]["wt"] = wb.data_ptr(), 0, wt.data_ptr()
+                tab[j]["N"], tab[j]["K"], tab[j]["block_begin"] = N, K, blocks
                 blocks += int(_lib.lib().octic_dense_prep_batch_blocks(N, K))
+                j += 1
             self._wt_items = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
-            self._wt_blocks = blocks
+            self._wt_blocks, self._wt_count = blocks, len(wt_layers)
         self._g_key = None
         self._g_pinned, self._g_capture_host = [], None
         self.ntensors, self.nchunks = len(self.params), len(ct)
@@ -240,9 +249,9 @@ class FusedLamb:
         torch._C._autograd._unsafe_set_version_counter(
             tuple(self.params), tuple(p._version + 1 for p in self.params))
         if self._wt_items is not None:
-            self._lib.check(self._lib.lib().octic_dense_prep_batch(vp(self._wt_items), len(self._shadows), self._wt_blocks,
+            self._lib.check(self._lib.lib().octic_dense_prep_batch(vp(self._wt_items), self._wt_count, self._wt_blocks,
                                                                    self._lib.BF16, stream))
-        for (lin, cache, wb, bb), wt in zip(self._shadows, self._wt):   # the bf16 copies are current for the new versions
+        for (lin, cache, wb, bb, _), wt in zip(self._shadows, self._wt):   # the bf16 copies are current for the new versions
             cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16, wt_copy=wt)
         if self._prep_source is not None:
             if self._prep_batch is None or self._prep_batch.stale():
@@ -303,14 +312,14 @@ def use_tuned_gemms(table=None):
 
 
 def library_gemm_layers(model):
-    """(nn.Linear, DenseWeightCache) of every projection of the standard half (vit.Attention / vit.Mlp)."""
+    """(nn.Linear, DenseWeightCache, role) of every projection of the standard half (vit.Attention / vit.Mlp)."""
     from . import vit
     out = []
     for m in model.modules():
         if isinstance(m, vit.Attention):
-            out += [(m.qkv, m._c1), (m.proj, m._c2)]
+            out += [(m.qkv, m._c1, "qkv"), (m.proj, m._c2, "proj")]
         elif isinstance(m, vit.Mlp):
-            out += [(m.fc1, m._c1), (m.fc2, m._c2)]
+            out += [(m.fc1, m._c1, "fc1"), (m.fc2, m._c2, "fc2")]
     return out
 
 
