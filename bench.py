@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly (default at 1 GPU: the step is captured once with Trainer.capture and "
                          "replayed as one hipGraph; the kernel-timing steps stay eager.  With DDP the steps are always eager)")
+    ap.add_argument("--no-packed-attn", action="store_true",
+                    help="developer A/B: AttentionD8 through the pack / unpack kernels instead of the packed-row attention")
     ap.add_argument("--wgrad-f32-out", action="store_true",
                     help="developer A/B: library weight gradients straight to f32 (default: bf16 result + cast, as autocast does)")
     ap.add_argument("--dense-hip", default=None,
@@ -111,6 +113,9 @@ def main():
     if args.dense_hip is not None:
         from octic_vits_amd import functional as _OF
         _OF.DENSE_HIP = set() if args.dense_hip == "none" else set(args.dense_hip.split(","))
+    if args.no_packed_attn:
+        from octic_vits_amd import functional as _OF
+        _OF.ATTN_PACKED = False
     if args.wgrad_f32_out:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_F32_OUT = True

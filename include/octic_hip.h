@@ -189,6 +189,18 @@ int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    int64_t sT, int64_t oB, int64_t oH, int64_t oT, int64_t gB, int64_t gH, int64_t gT, float scale,
                    int phase, void* stream);
 
+/* AttentionD8 straight on packed rows - reference octic_vits/d8_layers.py:631-656 (head split of the five-irrep
+ * projection output, F.scaled_dot_product_attention, re-assembly of the irreps) WITHOUT the pack / unpack copies:
+ * qkv = LinearD8 output [B, T, 3*8c] (row stride ld_qkv elements), o = packed [B, T, 8c] input of the output
+ * projection.  c / H must be 10 (head_dim 80), bf16.  lse [B,H,T] as in octic_attn_fwd. */
+int octic_attn_fwd_packed(const void* qkv, void* o, float* lse, int64_t B, int H, int T, int c, int64_t ld_qkv,
+                          int64_t ld_o, float scale, void* stream);
+/* Backward of octic_attn_fwd_packed (autograd of d8_layers.py:631-656): dqkv packed like qkv (row stride ld_g)
+ * receives dq | dk | dv, dout packed like o; phase as in octic_attn_bwd. */
+int octic_attn_bwd_packed(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                          int64_t B, int H, int T, int c, int64_t ld_qkv, int64_t ld_o, int64_t ld_g, float scale,
+                          int phase, void* stream);
+
 /* ---- octic -> standard hand-off (model.py:196-200) ---------------------------------------------
  * hybrid:    dense[m, :] = cat(A1,A2,B1,B2, E[0,:c], E[1,:c], E[0,c:], E[1,c:])   (8-tuple order,
  *            d8_utils.py:370-385; the following standard blocks' weights depend on it)

@@ -66,6 +66,8 @@ _PROTOS = {
     "octic_linear_d8_prep_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "octic_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int,
                                c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_float, c_void_p]),
+    "octic_attn_fwd_packed": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_float, c_void_p]),
+    "octic_attn_bwd_packed": (c_int, [c_void_p] * 6 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_float, c_int, c_void_p]),
     "octic_attn_bwd": (c_int, [c_void_p] * 10 + [c_i64, c_int, c_int, c_int] + [c_i64] * 9 + [c_float, c_int, c_void_p]),
     "octic_attn_pack_heads": (c_int, [VP, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "octic_attn_unpack_heads": (c_int, [c_void_p, VP, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),

@@ -27,7 +27,91 @@ struct AttnArgs {
   float* lse;            // [B,H,T] log2-domain log-sum-exp of the scaled scores
   int H, T, hd;
   float scale_log2;      // softmax scale * log2(e)
+  // packed mode (cv_in > 0): q == k == v is the packed LinearD8 output [B,T,3*8c] (row stride sT, sH = 0), o the packed
+  // [B,T,8c] input of the output projection; cv = irrep block width of a row (3c / c), c = channels per irrep.
+  int cv_in, cv_out, c;
 };
+
+// ---- head-vector addressing ------------------------------------------------------------------------------------------
+// Plain (cv == 0): the hd elements of (b,h,t) are contiguous.  Packed: the head vector of tensor s, head h is six pieces
+// of the token row - w = c/H channels of each one-dimensional irrep and 2w of each row of E (reference
+// d8_layers.py:631-643, 650-656) - so AttentionD8 needs no pack / unpack passes.  The dot products do not care about the
+// order of the hd elements as long as q, k (and v, o) agree, so the pieces are visited in an order that keeps 16-byte
+// groups inside a piece where possible (w = 10, hd = 80 = ten groups of 8): groups 0-3 = first 8 channels of A1, A2, B1,
+// B2; groups 4-7 = E0[0:8], E0[8:16], E1[0:8], E1[8:16]; group 8 = the four 2-channel remainders of the 1-D pieces;
+// group 9 = the two 4-channel remainders of the E pieces.  Pieces start on 4-byte boundaries (20 h bytes).
+struct HeadMap { int cv, bs; };        // bs = s*c + h*w
+typedef unsigned u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int hm_off8(const HeadMap m, int g) {
+  return g < 4 ? g * m.cv + m.bs : (4 + 2 * ((g - 4) >> 1)) * m.cv + 2 * m.bs + ((g - 4) & 1) * 8;
+}
+__device__ __forceinline__ u32x4 hm_load16(const bf16* row, int c, const HeadMap m) {
+  if (m.cv == 0) return *(const u32x4*)(row + c * 8);
+  if (c < 8) return *(const u32x4_u*)(row + hm_off8(m, c));
+  if (c == 8) {
+    const bf16* p = row + m.bs + 8;
+    return u32x4{*(const unsigned*)p, *(const unsigned*)(p + m.cv), *(const unsigned*)(p + 2 * m.cv),
+                 *(const unsigned*)(p + 3 * m.cv)};
+  }
+  const bf16* p = row + 4 * m.cv + 2 * m.bs + 16;
+  const u32x2_u e0 = *(const u32x2_u*)p, e1 = *(const u32x2_u*)(p + 2 * m.cv);
+  return u32x4{e0[0], e0[1], e1[0], e1[1]};
+}
+__device__ __forceinline__ void hm_store16(bf16* row, int c, const u32x4 v, const HeadMap m) {
+  if (m.cv == 0) { *(u32x4*)(row + c * 8) = v; return; }
+  if (c < 8) { *(u32x4_u*)(row + hm_off8(m, c)) = v; return; }
+  if (c == 8) {
+    bf16* p = row + m.bs + 8;
+    *(unsigned*)p = v[0]; *(unsigned*)(p + m.cv) = v[1]; *(unsigned*)(p + 2 * m.cv) = v[2]; *(unsigned*)(p + 3 * m.cv) = v[3];
+    return;
+  }
+  bf16* p = row + 4 * m.cv + 2 * m.bs + 16;
+  *(u32x2_u*)p = u32x2_u{v[0], v[1]};
+  *(u32x2_u*)(p + 2 * m.cv) = u32x2_u{v[2], v[3]};
+}
+// four consecutive elements: half `sub` of group g
+__device__ __forceinline__ void hm_store8(bf16* row, int g, int sub, const u32x2 v, const HeadMap m) {
+  if (m.cv == 0) { *(u32x2*)(row + g * 8 + sub * 4) = v; return; }
+  if (g < 8) { *(u32x2_u*)(row + hm_off8(m, g) + sub * 4) = u32x2_u{v[0], v[1]}; return; }
+  if (g == 8) {
+    bf16* p = row + 2 * sub * m.cv + m.bs + 8;
+    *(unsigned*)p = v[0]; *(unsigned*)(p + m.cv) = v[1];
+    return;
+  }
+  *(u32x2_u*)(row + (4 + 2 * sub) * m.cv + 2 * m.bs + 16) = u32x2_u{v[0], v[1]};
+}
+// the head maps of one (b, h): tensor s of the packed projection output / the packed single-tensor rows
+struct HeadMaps { HeadMap q, k, v, o; };
+template <typename A>
+__device__ __forceinline__ HeadMaps head_maps(const A& a, int h) {
+  HeadMaps m;
+  const int w = a.cv_in > 0 ? a.c / a.H : 0;
+  m.q = HeadMap{a.cv_in, h * w};
+  m.k = HeadMap{a.cv_in, a.c + h * w};
+  m.v = HeadMap{a.cv_in, 2 * a.c + h * w};
+  m.o = HeadMap{a.cv_out, h * w};
+  return m;
+}
+// Workgroup / work-item index -> (b, h) unit.  When the heads of a token share cache lines (packed rows: 20-byte pieces;
+// the standard block's fused [B,T,3,H,hd] projection: 160-byte pieces) the units are dealt so that each XCD works on
+// whole batches: the lines a head leaves partly used are consumed by its neighbours out of the same L2 instead of
+// being fetched once per XCD.  Bijective for any unit count.
+__device__ __forceinline__ int unit_of(int idx, int units, bool shared_rows) {
+  if (!shared_rows) return idx;
+  const int xcd = idx & 7, local = idx >> 3, q8 = units >> 3, r8 = units & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+}
+
+// element e of the head vector -> element offset in the row (scalar accesses of the merge paths)
+__device__ __forceinline__ int hm_elem(int e, const HeadMap m) {
+  if (m.cv == 0) return e;
+  const int g = e >> 3, j = e & 7;
+  if (g < 8) return hm_off8(m, g) + j;
+  if (g == 8) return (j >> 1) * m.cv + m.bs + 8 + (j & 1);
+  return (4 + 2 * (j >> 2)) * m.cv + 2 * m.bs + 16 + (j & 3);
+}
 
 __device__ inline int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -63,7 +147,8 @@ inline int attn_rsv(int dp) { int r = dp * 2; return ((r / 4) % 32 == 0) ? r + 6
 constexpr int kStageBatch = OCTIC_STAGE_BATCH;
 __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA, int64_t stA, int kcA, int wcA,
                                           char* imgB, int rsB, const bf16* srcB, int64_t stB, int kcB, int wcB,
-                                          int T, int Tp, int tid, int nthr) {
+                                          int T, int Tp, int tid, int nthr, const HeadMap mA = HeadMap{0, 0},
+                                          const HeadMap mB = HeadMap{0, 0}) {
   // wc = chunks written per row (>= kc: the extra ones are zeros), kc = chunks that exist in the source row
   const int totA = Tp * wcA, totB = Tp * wcB;
   const int tot = totA > totB ? totA : totB;
@@ -76,11 +161,11 @@ __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA,
       vb[it] = u32x4{0, 0, 0, 0};
       if (q < totA) {
         const int t = q / wcA, c = q - t * wcA;
-        if (t < T && c < kcA) va[it] = *(const u32x4*)(srcA + (int64_t)t * stA + c * 8);
+        if (t < T && c < kcA) va[it] = hm_load16(srcA + (int64_t)t * stA, c, mA);
       }
       if (q < totB) {
         const int t = q / wcB, c = q - t * wcB;
-        if (t < T && c < kcB) vb[it] = *(const u32x4*)(srcB + (int64_t)t * stB + c * 8);
+        if (t < T && c < kcB) vb[it] = hm_load16(srcB + (int64_t)t * stB, c, mB);
       }
     }
 #pragma unroll
@@ -129,12 +214,14 @@ constexpr int kPartPad = 4;    // f32 row pad of the partial-result images (conf
 // (m, l: per lane = per query, l still split between the half-waves) and O^T accumulators are updated in place.
 // lane (r, half) holds Q[query][16 ks + 8 half .. +7] = B operand of K Q^T
 template <int KS>
-__device__ __forceinline__ void load_rows8(bf16x8 (&f)[KS], const bf16* base, int64_t st, int tile, int T, int lane) {
+__device__ __forceinline__ void load_rows8(bf16x8 (&f)[KS], const bf16* base, int64_t st, int tile, int T, int lane,
+                                           const HeadMap m = HeadMap{0, 0}) {
   const int r = lane & 31, half = lane >> 5;
   const int i = tile * 32 + r;
   const int ic = i < T ? i : T - 1;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) f[ks] = *(const bf16x8*)(base + (int64_t)ic * st + ks * 16 + half * 8);
+  for (int ks = 0; ks < KS; ++ks)
+    f[ks] = __builtin_bit_cast(bf16x8, hm_load16(base + (int64_t)ic * st, 2 * ks + half, m));
 }
 
 template <int KS, int DT>
@@ -213,7 +300,7 @@ __device__ __forceinline__ void store_partial(float* part, const f32x16 (&acc)[D
 template <int DT>
 __device__ __forceinline__ void combine_store(const float* parts, int waves, const float* wgt, const float* rowscale,
                                               float scale, bf16* out, int64_t st, int row0, int T, int hd, int tid,
-                                              int nthr) {
+                                              int nthr, const HeadMap m = HeadMap{0, 0}) {
   const int DC = DT * 32 + kPartPad;
   const int c8 = hd / 8;
   const int nrows = T - row0 < 32 ? T - row0 : 32;
@@ -233,22 +320,23 @@ __device__ __forceinline__ void combine_store(const float* parts, int waves, con
       o[j] = (bf16)(s0[j] * f);
       o[4 + j] = (bf16)(s1[j] * f);
     }
-    *(bf16x8*)(out + (int64_t)(row0 + r) * st + c * 8) = o;
+    hm_store16(out + (int64_t)(row0 + r) * st, c, __builtin_bit_cast(u32x4, o), m);
   }
 }
 
 // accumulator tile set -> bf16 rows of the output (lane r = row `row`, 4 consecutive columns per store)
 template <int DT>
-__device__ __forceinline__ void store_rows(bf16* row, const f32x16 (&acc)[DT], float f, int hd, int half) {
+__device__ __forceinline__ void store_rows(bf16* row, const f32x16 (&acc)[DT], float f, int hd, int half,
+                                           const HeadMap m = HeadMap{0, 0}) {
 #pragma unroll
   for (int d = 0; d < DT; ++d)
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
-      const int d0 = d * 32 + 8 * k4 + 4 * half;
-      if (d0 < hd) {
+      const int g = d * 4 + k4;                  // elements 8 g + 4 half .. + 3
+      if (g * 8 < hd) {
         bf16x4 ov = {(bf16)(acc[d][4 * k4] * f), (bf16)(acc[d][4 * k4 + 1] * f), (bf16)(acc[d][4 * k4 + 2] * f),
                      (bf16)(acc[d][4 * k4 + 3] * f)};
-        *(bf16x4*)(row + d0) = ov;
+        hm_store8(row, g, half, __builtin_bit_cast(u32x2, ov), m);
       }
     }
 }
@@ -270,7 +358,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
   const int Tp = nt * 32;
   char* Ks = smem;
   char* Vs = smem + (size_t)Tp * rsk;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int bh = unit_of(blockIdx.x, gridDim.x, a.sH < a.sT), b = bh / a.H, h = bh - b * a.H;
   const bf16* qb = a.q + b * a.sB + h * a.sH;
   const bf16* kb = a.k + b * a.sB + h * a.sH;
   const bf16* vb = a.v + b * a.sB + h * a.sH;
@@ -283,9 +371,11 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
   // ---- this wave's query rows first (their loads overlap the staging), then K and V of this head (zero-filled
   // pads: padded keys are masked, padded V rows meet P = 0)
   bf16x8 qf[KS], qfs[KS];                       // own query tile; the shared tile's rows are fetched up front too
-  load_rows8<KS>(qf, qb, a.sT, wid, T, lane);
-  if (nt != W) load_rows8<KS>(qfs, qb, a.sT, W, T, lane);
-  stage_two(Ks, rsk, kb, a.sT, hd / 8, hd / 8, Vs, rsv, vb, a.sT, hd / 8, (DT * 32) / 8, T, Tp, tid, blockDim.x);
+  const HeadMaps hm = head_maps(a, h);
+  load_rows8<KS>(qf, qb, a.sT, wid, T, lane, hm.q);
+  if (nt != W) load_rows8<KS>(qfs, qb, a.sT, W, T, lane, hm.q);
+  stage_two(Ks, rsk, kb, a.sT, hd / 8, hd / 8, Vs, rsv, vb, a.sT, hd / 8, (DT * 32) / 8, T, Tp, tid, blockDim.x, hm.k,
+            hm.v);
   ATRACE(0, 1);
   __syncthreads();
   ATRACE(0, 2);
@@ -300,7 +390,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
     const int qi = wid * 32 + r;
     if (qi < T) {
       if (half == 0 && lseb) lseb[qi] = m + log2f(l);
-      store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half);
+      store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half, hm.o);
     }
   }
   ATRACE(0, 4);
@@ -336,7 +426,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
     if (qi < T && lseb) lseb[qi] = M + log2f(L);
   }
   __syncthreads();
-  combine_store<DT>(parts, W, ml + W * 32, ml + 2 * W * 32, 1.0f, ob, a.oT, W * 32, T, hd, tid, blockDim.x);
+  combine_store<DT>(parts, W, ml + W * 32, ml + 2 * W * 32, 1.0f, ob, a.oT, W * 32, T, hd, tid, blockDim.x, hm.o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -375,28 +465,61 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
   constexpr int MAXI = 8;
   const int ninstr = kimg >> 10;
   const int cpr = rsk >> 4;                            // chunks per image row (data + pad)
+  const bool packed = a.cv_in > 0;                     // head vectors gathered from packed LinearD8 rows (HeadMap)
   unsigned voff[MAXI];
+  unsigned emask = 0;                                  // packed mode: bit j = instruction j of this lane reads an E piece
 #pragma unroll
   for (int j = 0; j < MAXI; ++j) {
     const int idx = (wid + j * W) * 64 + lane;
     const int row = idx / cpr, ch = idx - row * cpr;
-    voff[j] = (ch < kc && row < T) ? (unsigned)(row * (int)a.sT * 2 + ch * 16) : 0x7FFFFFF0u;
+    if (!packed) {
+      voff[j] = (ch < kc && row < T) ? (unsigned)(row * (int)a.sT * 2 + ch * 16) : 0x7FFFFFF0u;
+    } else {
+      // groups 0-7 are one 16-byte piece each (start + bs or 2 bs elements, added per head); groups 8, 9 are gathered
+      // through registers (below), the DMA leaves zeros there
+      const int g0 = hm_off8(HeadMap{a.cv_in, 0}, ch < 8 ? ch : 0);
+      voff[j] = (ch < 8 && row < T) ? (unsigned)((row * (int)a.sT + g0) * 2) : 0x7FFFFFF0u;
+      if (ch >= 4 && ch < 8) emask |= 1u << j;
+    }
   }
-  const int krec = (int)((T - 1) * a.sT * 2 + hd * 2);
+  const int krec = packed ? (int)((T - 1) * a.sT * 2 + 16 * a.cv_in) : (int)((T - 1) * a.sT * 2 + hd * 2);
   // The DMA goes out as inline assembly on purpose: the compiler protects every transposing LDS read that follows a
   // buffer_load ... lds builtin with s_waitcnt vmcnt(0) (it cannot tell the two K images apart), which would put the
   // arrival of the NEXT head in front of the first P V product of the current one.  The waits that matter are
   // written out below (vmcnt(0) in front of the barrier that hands the image over).
   typedef __attribute__((ext_vector_type(4))) int i32x4;
-  auto issue_k = [&](const bf16* kb, unsigned lds_dst) {
+  auto issue_k = [&](const bf16* kb, unsigned lds_dst, int bs) {
     const uint64_t p = (uint64_t)kb;
     const i32x4 rs = {(int)(uint32_t)p, (int)(uint32_t)((p >> 32) & 0xFFFF), krec, 0x27000};
 #pragma unroll
     for (int j = 0; j < MAXI; ++j) {
       const int i = wid + j * W;
-      if (i < ninstr)
+      if (i < ninstr) {
+        const unsigned vo = voff[j] == 0x7FFFFFF0u ? voff[j] : voff[j] + (unsigned)(bs * (((emask >> j) & 1) ? 4 : 2));
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 1\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                     :: "s"(lds_dst + i * 1024), "v"(voff[j]), "s"(rs) : "memory");
+                     :: "s"(lds_dst + i * 1024), "v"(vo), "s"(rs) : "memory");
+      }
+    }
+  };
+  // packed mode: the gathered groups 8 and 9 of the K rows (two 16-byte chunks per row) travel through registers
+  u32x4 ktail[2];
+  auto load_ktail = [&](const bf16* kb, const HeadMap mk) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int idx = it * nthr + tid;
+      asm volatile("" : "+v"(idx));
+      const int row = idx >> 1;
+      ktail[it] = u32x4{0, 0, 0, 0};
+      if (row < T) ktail[it] = hm_load16(kb + (int64_t)row * a.sT, 8 + (idx & 1), mk);
+    }
+  };
+  auto write_ktail = [&](char* Kimg) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int idx = it * nthr + tid;
+      asm volatile("" : "+v"(idx));
+      const int row = idx >> 1;
+      if (row < T) *(u32x4*)(Kimg + (size_t)row * rsk + (8 + (idx & 1)) * 16) = ktail[it];
     }
   };
   const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -404,7 +527,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
   constexpr int NV = 6;
   const int nv = (T * kc + nthr - 1) / nthr;           // <= NV (checked by the launcher)
   u32x4 vreg[NV];
-  auto load_v = [&](const bf16* vb) {
+  auto load_v = [&](const bf16* vb, const HeadMap mv) {
 #pragma unroll
     for (int it = 0; it < NV; ++it)
       if (it < nv) {
@@ -412,7 +535,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
         asm volatile("" : "+v"(idx));                    // recomputed per head: hoisted addresses would cost 2 NV registers
         const int row = idx / kc, c = idx - row * kc;
         vreg[it] = u32x4{0, 0, 0, 0};
-        if (row < T) vreg[it] = *(const u32x4*)(vb + (int64_t)row * a.sT + c * 8);
+        if (row < T) vreg[it] = hm_load16(vb + (int64_t)row * a.sT, c, mv);
       }
   };
   auto write_v = [&]() {
@@ -425,8 +548,12 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
         if (row < T) *(u32x4*)(Vs + (size_t)row * rsv + c * 16) = vreg[it];
       }
   };
-  auto head_off = [&](int u, int64_t& in_off, int64_t& o_off, int64_t& st_off) {
-    const int b = u / a.H, h = u - b * a.H;
+  const bool shared_rows = a.sH < a.sT;
+  auto head_off = [&](int idx, int64_t& in_off, int64_t& o_off, int64_t& st_off, int& h) {
+    // work item idx of this launch -> unit; the padded index space keeps `idx + G` on the same XCD
+    const int u = unit_of(idx, units, shared_rows);
+    const int b = u / a.H;
+    h = u - b * a.H;
     in_off = b * a.sB + h * a.sH;
     o_off = b * a.oB + h * a.oH;
     st_off = ((int64_t)b * a.H + h) * T;
@@ -434,17 +561,21 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
 
   int u = blockIdx.x;
   int64_t in_off, o_off, st_off;
-  head_off(u, in_off, o_off, st_off);
+  int hh;
+  head_off(u, in_off, o_off, st_off, hh);
+  HeadMaps hm = head_maps(a, hh);
   bf16x8 qf[KS], qfs[KS];
-  issue_k(a.k + in_off, smem_lds);
-  load_v(a.v + in_off);
-  load_rows8<KS>(qf, a.q + in_off, a.sT, wid, T, lane);
-  if (nrows > 0) load_rows8<KS>(qfs, a.q + in_off, a.sT, W, T, lane);
+  issue_k(a.k + in_off, smem_lds, hm.k.bs);
+  if (packed) load_ktail(a.k + in_off, hm.k);
+  load_v(a.v + in_off, hm.v);
+  load_rows8<KS>(qf, a.q + in_off, a.sT, wid, T, lane, hm.q);
+  if (nrows > 0) load_rows8<KS>(qfs, a.q + in_off, a.sT, W, T, lane, hm.q);
   // the V image's pad (columns >= hd, rows >= T) is written once: zeros
   for (int o = tid * 16; o < Tp * rsv; o += nthr * 16) *(u32x4*)(Vs + o) = u32x4{0, 0, 0, 0};
   __syncthreads();
   write_v();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (packed) write_ktail(smem);
   __syncthreads();
 
   int cur = 0;
@@ -464,10 +595,14 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
       asm volatile("" : "+v"(qf[ks]));
       asm volatile("" : "+v"(qfs[ks]));
     }
+    int nh = 0;
+    HeadMaps nhm = hm;
     if (has_next) {
-      head_off(un, n_in, n_o, n_st);
-      issue_k(a.k + n_in, smem_lds + (cur ^ 1) * kimg);
-      load_v(a.v + n_in);
+      head_off(un, n_in, n_o, n_st, nh);
+      nhm = head_maps(a, nh);
+      issue_k(a.k + n_in, smem_lds + (cur ^ 1) * kimg, nhm.k.bs);
+      if (packed) load_ktail(a.k + n_in, nhm.k);
+      load_v(a.v + n_in, nhm.v);
     }
     if (tr_on) ATRACE(0, 1);
     bf16* ob = a.o + o_off;
@@ -483,10 +618,10 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
       const int qi = wid * 32 + r;
       if (qi < T) {
         if (half == 0 && lseb) lseb[qi] = m + log2f(l);
-        store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half);
+        store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half, hm.o);
       }
     }
-    if (has_next) load_rows8<KS>(qf, a.q + n_in, a.sT, wid, T, lane);
+    if (has_next) load_rows8<KS>(qf, a.q + n_in, a.sT, wid, T, lane, nhm.q);
     if (tr_on) ATRACE(0, 3);
     if (nrows > 0) {
       // the shared tile against this wave's key tiles; the partial rows meet in LDS
@@ -495,7 +630,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
       l = 0.f;
       fwd_pass<KS, DT>(a, Ks, Vs, rsk, rsv, qfs, wid, W, nt, lane, m, l, ot);
       l += __shfl_xor(l, 32, 64);
-      if (has_next) load_rows8<KS>(qfs, a.q + n_in, a.sT, W, T, lane);
+      if (has_next) load_rows8<KS>(qfs, a.q + n_in, a.sT, W, T, lane, nhm.q);
       if (r < nrows) {
         float* row = parts + ((size_t)wid * nrows + r) * DC;
 #pragma unroll
@@ -516,6 +651,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
     if (has_next) write_v();
     if (tr_on) ATRACE(0, 6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the K DMA of the next head has landed
+    if (packed && has_next) write_ktail(smem + (cur ^ 1) * kimg);
     if (tr_on) ATRACE(0, 7);
     __syncthreads();
     if (tr_on) ATRACE(0, 8);
@@ -534,14 +670,15 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
         const int qi = W * 32 + rr;
         const float inv = 1.0f / L;
         bf16* orow = ob + (int64_t)qi * a.oT;
-        if (lane < hd) orow[lane] = (bf16)(o0 * inv);
-        if (lane + 64 < hd) orow[lane + 64] = (bf16)(o1 * inv);
+        if (lane < hd) orow[hm_elem(lane, hm.o)] = (bf16)(o0 * inv);
+        if (lane + 64 < hd) orow[hm_elem(lane + 64, hm.o)] = (bf16)(o1 * inv);
         if (lane == 0 && lseb) lseb[qi] = M + log2f(L);
       }
     }
     if (tr_on) ATRACE(0, 9);
     cur ^= 1;
     in_off = n_in; o_off = n_o; st_off = n_st;
+    hm = nhm;
   }
 }
 
@@ -605,7 +742,9 @@ struct AttnBwdArgs {
   bf16* dq; bf16* dk; bf16* dv; int64_t gB, gH, gT;                     // gradients
   int H, T, hd;
   float scale, scale_log2;
+  int cv_in, cv_out, c;                                                   // packed mode, see AttnArgs
 };
+
 
 // per-query operands of the dq kernel for one query tile: Q and dO fragments, log-sum-exp, delta = <dO, O>
 template <int KS>
@@ -616,16 +755,16 @@ struct DqRows {
 // issue the loads only: the staging loads follow right behind, so the two memory round trips overlap ...
 template <int KS>
 __device__ __forceinline__ void load_dq_rows(DqRows<KS>& R, const AttnBwdArgs& a, int64_t in_off, int64_t o_off,
-                                             int64_t stat_off, int qtile, int lane) {
+                                             int64_t stat_off, int qtile, int lane, const HeadMaps& hm) {
   const int T = a.T;
   const int r = lane & 31, half = lane >> 5;
   const int qi = qtile * 32 + r;
   const int qc = qi < T ? qi : T - 1;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    R.qf[ks] = *(const bf16x8*)(a.q + in_off + (int64_t)qc * a.sT + ks * 16 + half * 8);
-    R.dof[ks] = *(const bf16x8*)(a.dout + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
-    R.of[ks] = *(const bf16x8*)(a.o + o_off + (int64_t)qc * a.oT + ks * 16 + half * 8);
+    R.qf[ks] = __builtin_bit_cast(bf16x8, hm_load16(a.q + in_off + (int64_t)qc * a.sT, 2 * ks + half, hm.q));
+    R.dof[ks] = __builtin_bit_cast(bf16x8, hm_load16(a.dout + o_off + (int64_t)qc * a.oT, 2 * ks + half, hm.o));
+    R.of[ks] = __builtin_bit_cast(bf16x8, hm_load16(a.o + o_off + (int64_t)qc * a.oT, 2 * ks + half, hm.o));
   }
   R.lse = a.lse[stat_off + qc];
 }
@@ -688,7 +827,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   const int W = blockDim.x >> 6, Tp = nt * 32;
   char* Ks = smem;
   char* Vs = smem + (size_t)Tp * rs;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int bh = unit_of(blockIdx.x, gridDim.x, a.sH < a.sT), b = bh / a.H, h = bh - b * a.H;
   const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH;
   const int64_t stat_off = ((int64_t)b * a.H + h) * T;
   bf16* dqb = a.dq + b * a.gB + h * a.gH;
@@ -696,10 +835,11 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   const int r = lane & 31, half = lane >> 5;
   ATRACE(1, 0);
   DqRows<KS> mine, shared;                          // the shared tile's rows are fetched up front too
-  load_dq_rows<KS>(mine, a, in_off, o_off, stat_off, wid, lane);
-  if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane);
+  const HeadMaps hm = head_maps(a, h);
+  load_dq_rows<KS>(mine, a, in_off, o_off, stat_off, wid, lane, hm);
+  if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane, hm);
   stage_two(Ks, rs, a.k + in_off, a.sT, hd / 8, hd / 8, Vs, rs, a.v + in_off, a.sT, hd / 8, hd / 8, T, Tp, tid,
-            blockDim.x);
+            blockDim.x, hm.k, hm.v);
   finish_dq_rows<KS>(mine, a, stat_off, wid, lane, true);
   if (nt != W) finish_dq_rows<KS>(shared, a, stat_off, W, lane, wid == 0);
   ATRACE(1, 1);
@@ -710,7 +850,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   zero_acc<DT>(dqt);
   dq_pass<KS, DT>(a, Ks, Vs, rs, mine, 0, 1, nt, lane, dqt);
   ATRACE(1, 3);
-  if (wid * 32 + r < T) store_rows<DT>(dqb + (int64_t)(wid * 32 + r) * a.gT, dqt, a.scale, hd, half);
+  if (wid * 32 + r < T) store_rows<DT>(dqb + (int64_t)(wid * 32 + r) * a.gT, dqt, a.scale, hd, half, hm.q);
   ATRACE(1, 4);
   if (nt == W) return;
 
@@ -722,7 +862,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   float* parts = (float*)smem;
   store_partial<DT>(parts + (size_t)wid * 32 * (DT * 32 + kPartPad), dqt, lane, T - W * 32);
   __syncthreads();
-  combine_store<DT>(parts, W, nullptr, nullptr, a.scale, dqb, a.gT, W * 32, T, hd, tid, blockDim.x);
+  combine_store<DT>(parts, W, nullptr, nullptr, a.scale, dqb, a.gT, W * 32, T, hd, tid, blockDim.x, hm.q);
   ATRACE(1, 7);
 }
 
@@ -733,14 +873,15 @@ struct KvRows {
   bf16x8 kf[KS], vf[KS];
 };
 template <int KS>
-__device__ __forceinline__ void load_kv_rows(KvRows<KS>& R, const AttnBwdArgs& a, int64_t in_off, int ktile, int lane) {
+__device__ __forceinline__ void load_kv_rows(KvRows<KS>& R, const AttnBwdArgs& a, int64_t in_off, int ktile, int lane,
+                                             const HeadMaps& hm) {
   const int r = lane & 31, half = lane >> 5;
   const int ki = ktile * 32 + r;
   const int kcl = ki < a.T ? ki : a.T - 1;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    R.kf[ks] = *(const bf16x8*)(a.k + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
-    R.vf[ks] = *(const bf16x8*)(a.v + in_off + (int64_t)kcl * a.sT + ks * 16 + half * 8);
+    R.kf[ks] = __builtin_bit_cast(bf16x8, hm_load16(a.k + in_off + (int64_t)kcl * a.sT, 2 * ks + half, hm.k));
+    R.vf[ks] = __builtin_bit_cast(bf16x8, hm_load16(a.v + in_off + (int64_t)kcl * a.sT, 2 * ks + half, hm.v));
   }
 }
 
@@ -795,7 +936,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   char* Ds = smem + (size_t)Tp * rs;
   float* lse_s = (float*)(smem + (size_t)2 * Tp * rs);
   float* del_s = lse_s + Tp;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int bh = unit_of(blockIdx.x, gridDim.x, a.sH < a.sT), b = bh / a.H, h = bh - b * a.H;
   const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH;
   bf16* dkb = a.dk + b * a.gB + h * a.gH;
   bf16* dvb = a.dv + b * a.gB + h * a.gH;
@@ -803,9 +944,10 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   const int r = lane & 31, half = lane >> 5;
   ATRACE(2, 0);
   KvRows<KS> kv;                                     // own key rows first: their round trip overlaps the staging
-  load_kv_rows<KS>(kv, a, in_off, wid, lane);
+  const HeadMaps hm = head_maps(a, h);
+  load_kv_rows<KS>(kv, a, in_off, wid, lane, hm);
   stage_two(Qs, rs, a.q + in_off, a.sT, hd / 8, hd / 8, Ds, rs, a.dout + o_off, a.oT, hd / 8, hd / 8, T, Tp, tid,
-            blockDim.x);
+            blockDim.x, hm.q, hm.o);
   for (int t = tid; t < Tp; t += blockDim.x) {
     const int64_t stat = ((int64_t)b * a.H + h) * T + t;
     lse_s[t] = t < T ? a.lse[stat] : INFINITY;    // padded queries: P = exp2(x - inf) = 0
@@ -821,15 +963,15 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, kv, 0, 1, nt, lane, dkt, dvt);
   ATRACE(2, 3);
   if (wid * 32 + r < T) {
-    store_rows<DT>(dkb + (int64_t)(wid * 32 + r) * a.gT, dkt, a.scale, hd, half);
-    store_rows<DT>(dvb + (int64_t)(wid * 32 + r) * a.gT, dvt, 1.0f, hd, half);
+    store_rows<DT>(dkb + (int64_t)(wid * 32 + r) * a.gT, dkt, a.scale, hd, half, hm.k);
+    store_rows<DT>(dvb + (int64_t)(wid * 32 + r) * a.gT, dvt, 1.0f, hd, half, hm.v);
   }
   ATRACE(2, 4);
   if (nt == W) return;
 
   zero_acc<DT>(dkt);
   zero_acc<DT>(dvt);
-  load_kv_rows<KS>(kv, a, in_off, W, lane);
+  load_kv_rows<KS>(kv, a, in_off, W, lane, hm);
   dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, kv, wid, W, nt, lane, dkt, dvt);
   ATRACE(2, 5);
   __syncthreads();
@@ -838,11 +980,11 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   float* mine = parts + (size_t)wid * 32 * (DT * 32 + kPartPad);
   store_partial<DT>(mine, dkt, lane, T - W * 32);
   __syncthreads();
-  combine_store<DT>(parts, W, nullptr, nullptr, a.scale, dkb, a.gT, W * 32, T, hd, tid, blockDim.x);
+  combine_store<DT>(parts, W, nullptr, nullptr, a.scale, dkb, a.gT, W * 32, T, hd, tid, blockDim.x, hm.k);
   __syncthreads();
   store_partial<DT>(mine, dvt, lane, T - W * 32);
   __syncthreads();
-  combine_store<DT>(parts, W, nullptr, nullptr, 1.0f, dvb, a.gT, W * 32, T, hd, tid, blockDim.x);
+  combine_store<DT>(parts, W, nullptr, nullptr, 1.0f, dvb, a.gT, W * 32, T, hd, tid, blockDim.x, hm.v);
   ATRACE(2, 7);
 }
 
@@ -901,6 +1043,7 @@ int octic_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
   a.lse = lse;
   a.H = H; a.T = T; a.hd = hd;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.cv_in = a.cv_out = a.c = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (hd / 16) {
     case 1: return attn_fwd_launch<1, 1>(a, B, s);
@@ -933,6 +1076,7 @@ int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
   a.H = H; a.T = T; a.hd = hd;
   a.scale = scale;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.cv_in = a.cv_out = a.c = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (hd / 16) {
     case 1: return attn_bwd_launch<1, 1>(a, B, phase, s);
@@ -944,6 +1088,48 @@ int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     case 7: return attn_bwd_launch<7, 4>(a, B, phase, s);
     default: return attn_bwd_launch<8, 4>(a, B, phase, s);
   }
+}
+
+// AttentionD8 on PACKED rows (reference d8_layers.py:631-656 without the pack / unpack copies): qkv is the LinearD8
+// output [B, T, 3*8c] (row stride ld_qkv elements), o the packed [B, T, 8c] input of the output projection (row stride
+// ld_o); head h of tensor s takes c/H channels of every one-dimensional irrep and 2c/H of each E row.  c/H must be 10
+// (head_dim 80: the piece schedule of HeadMap), bf16.
+int octic_attn_fwd_packed(const void* qkv, void* o, float* lse, int64_t B, int H, int T, int c, int64_t ld_qkv,
+                          int64_t ld_o, float scale, void* stream) {
+  if (!qkv || !o) return OCTIC_ENULL;
+  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || c <= 0 || c != 10 * H) return OCTIC_ESHAPE;
+  if (((((uintptr_t)qkv) | ((uintptr_t)o)) & 15) || ((ld_qkv | ld_o) & 7) || ld_qkv < 24 * c || ld_o < 8 * c) return OCTIC_EALIGN;
+  AttnArgs a;
+  a.q = a.k = a.v = (const bf16*)qkv;
+  a.sB = (int64_t)T * ld_qkv; a.sH = 0; a.sT = ld_qkv;
+  a.o = (bf16*)o; a.oB = (int64_t)T * ld_o; a.oH = 0; a.oT = ld_o;
+  a.lse = lse;
+  a.H = H; a.T = T; a.hd = 80;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  a.cv_in = 3 * c; a.cv_out = c; a.c = c;
+  return attn_fwd_launch<5, 3>(a, B, (hipStream_t)stream);
+}
+
+// Backward of the above: dqkv (packed like qkv, row stride ld_g) receives dq | dk | dv; dout packed like o.
+int octic_attn_bwd_packed(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                          int64_t B, int H, int T, int c, int64_t ld_qkv, int64_t ld_o, int64_t ld_g, float scale,
+                          int phase, void* stream) {
+  if (!qkv || !o || !dout || !lse || !delta || !dqkv) return OCTIC_ENULL;
+  if (phase < 1 || phase > 3) return OCTIC_ESHAPE;
+  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || c <= 0 || c != 10 * H) return OCTIC_ESHAPE;
+  if (((((uintptr_t)qkv) | ((uintptr_t)o) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) || ((ld_qkv | ld_o | ld_g) & 7) ||
+      ld_qkv < 24 * c || ld_g < 24 * c || ld_o < 8 * c)
+    return OCTIC_EALIGN;
+  AttnBwdArgs a;
+  a.q = a.k = a.v = (const bf16*)qkv; a.sB = (int64_t)T * ld_qkv; a.sH = 0; a.sT = ld_qkv;
+  a.o = (const bf16*)o; a.dout = (const bf16*)dout; a.oB = (int64_t)T * ld_o; a.oH = 0; a.oT = ld_o;
+  a.lse = lse; a.delta = delta;
+  a.dq = a.dk = a.dv = (bf16*)dqkv; a.gB = (int64_t)T * ld_g; a.gH = 0; a.gT = ld_g;
+  a.H = H; a.T = T; a.hd = 80;
+  a.scale = scale;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  a.cv_in = 3 * c; a.cv_out = c; a.c = c;
+  return attn_bwd_launch<5, 3>(a, B, phase, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -465,10 +465,16 @@ class AttentionD8(nn.Module):
         if xp.dim() != 3:
             raise ValueError("AttentionD8 expects [B, N, C] irreps")
         qkv = self.qkv(xs if isinstance(xs, Octic) else Octic(xp, c))
-        q, k, v = OF.PackHeadsFn.apply(qkv.packed, self.num_heads, c)
-        # HIP attention core for the shapes it covers (bf16, T <= 320, no dropout); torch SDPA (== self.att) otherwise
-        o = OF.attention_core(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.)
-        on = Octic(OF.UnpackHeadsFn.apply(o, c), c)
+        drop = self.attn_drop.p if self.training else 0.
+        if (OF.ATTN_PACKED and drop == 0. and qkv.packed.is_cuda
+                and OF.ops.attn_packed_ok(qkv.packed.shape[1], c, self.num_heads, qkv.packed.dtype)):
+            # head split, softmax core and irrep re-assembly in the attention kernels themselves (head_dim 80)
+            on = Octic(OF.AttnPackedFn.apply(qkv.packed, self.num_heads, c, (8 * c // self.num_heads) ** -0.5), c)
+        else:
+            q, k, v = OF.PackHeadsFn.apply(qkv.packed, self.num_heads, c)
+            # HIP attention core for the shapes it covers (bf16, T <= 320, no dropout); torch SDPA (== self.att) otherwise
+            o = OF.attention_core(q, k, v, dropout_p=drop)
+            on = Octic(OF.UnpackHeadsFn.apply(o, c), c)
         if self.proj_drop.active or resid is None:
             return _tail(self.proj_drop(self.proj(on)), resid, rs, cs)
         return self.proj(on, resid=resid, rs=rs, cs=cs)

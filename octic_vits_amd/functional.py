@@ -40,6 +40,9 @@ def as_packed(xs):
 _FP16_NOTE = [False]
 
 
+ATTN_PACKED = True     # AttentionD8: attention kernels read / write the packed irrep rows (no pack / unpack passes)
+
+
 def compute_dtype(t: torch.Tensor):
     """Operand dtype of the octic kernels for `t` under the ambient autocast state.  bf16 autocast -> bf16 (the fast
     path, BASELINE dtype).  fp16 autocast (the reference's DeiT default, deit/engine.py:56) -> float32: the engine has no
@@ -340,6 +343,26 @@ class AttnFn(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ops.attn_bwd(q, k, v, o, do, lse, ctx.scale, dq, dk, dv)
         return dq, dk, dv, None
+
+
+class AttnPackedFn(torch.autograd.Function):
+    """AttentionD8's core on packed rows (reference d8_layers.py:631-656): qkv [B,T,3*8c] -> o [B,T,8c].  The head
+    vectors are gathered from / scattered to the irrep pieces inside the attention kernels, so the four pack / unpack
+    passes of a training step (and their 0.5 GB of traffic per block) do not exist."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, c, scale):
+        qkv = _c(qkv)
+        o, lse = ops.attn_fwd_packed(qkv, H, c, scale)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.meta = (H, c, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        H, c, scale = ctx.meta
+        return ops.attn_bwd_packed(qkv, o, _c(do), lse, H, c, scale), None, None, None
 
 
 class AttnFusedQKVFn(torch.autograd.Function):

@@ -384,6 +384,36 @@ def attn_bwd(q, k, v, o, dout, lse, scale, dq, dk, dv):
         KERNEL_TIMER.stop(t, name, nbytes * q.numel() * 2, flops * B * H * T * T * hd)
 
 
+def attn_packed_ok(T, c, H, dtype):
+    """Shapes of octic_attn_{fwd,bwd}_packed: bf16, head_dim 80 (c = 10 H), T <= 320."""
+    return dtype == torch.bfloat16 and c == 10 * H and 0 < T <= 320 and attn_supported(T, 80, dtype)
+
+
+def attn_fwd_packed(qkv, H, c, scale):
+    """qkv packed [B,T,3*8c] bf16 -> (o packed [B,T,8c], lse [B,H,T]); no head pack / unpack copies."""
+    B, T = qkv.shape[0], qkv.shape[1]
+    o = torch.empty((B, T, 8 * c), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_attn_fwd_packed(_p(qkv), _p(o), _p(lse), B, H, T, c, qkv.stride(1), o.stride(1), float(scale),
+                                      _stream(qkv)))
+    KERNEL_TIMER.stop(t, "attn_fwd_kernel", 4 * B * T * 8 * c * 2, 4.0 * B * T * T * 8 * c)
+    return o, lse
+
+
+def attn_bwd_packed(qkv, o, dout, lse, H, c, scale):
+    """-> dqkv packed [B,T,3*8c] (dq | dk | dv in the layout of qkv)."""
+    B, T = qkv.shape[0], qkv.shape[1]
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+    for phase, name, nbytes, flops in ((1, "attn_bwd_dq_kernel", 6, 6.0), (2, "attn_bwd_dkv_kernel", 6, 8.0)):
+        t = KERNEL_TIMER.start()
+        check(lib().octic_attn_bwd_packed(_p(qkv), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, H, T, c, qkv.stride(1),
+                                          o.stride(1), dqkv.stride(1), float(scale), phase, _stream(qkv)))
+        KERNEL_TIMER.stop(t, name, nbytes * B * T * 8 * c * 2, flops * B * T * T * 8 * c)
+    return dqkv
+
+
 def handoff_cat_fwd(x, c, out_dtype):
     M = x.numel() // (8 * c)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)

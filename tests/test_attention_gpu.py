@@ -90,3 +90,59 @@ def test_attn_fused_qkv_function_matches_reference():
     assert torch.allclose(out.float(), ro, atol=2e-2, rtol=2e-2)
     scale = max(1.0, float(ref.grad.abs().max()))
     assert float((qkv.grad.float() - ref.grad).abs().max()) <= 3e-2 * scale
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 257, 16), (3, 197, 16), (1, 64, 4), (2, 33, 8)])
+def test_packed_attention_matches_pack_attention_unpack(B, T, H):
+    """octic_attn_{fwd,bwd}_packed (AttentionD8 between its two linears, reference d8_layers.py:631-656, on the packed rows)
+    against the three-step path it replaces: pack kernels (bit-exact vs the oracle's pack_heads, test_kernels_gpu) ->
+    attention kernels on [B,H,T,80] -> unpack.  Same arithmetic per head in a different element order inside the dot
+    products: outputs and gradients agree to bf16 rounding (2e-2 of scale)."""
+    from octic_vits_amd import functional as OF, ops
+    c = 10 * H
+    torch.manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16().requires_grad_(True)
+    do = torch.randn(B, T, 8 * c, device="cuda").bfloat16()
+    assert ops.attn_packed_ok(T, c, H, qkv.dtype)
+    o1 = OF.AttnPackedFn.apply(qkv, H, c, 80 ** -0.5)
+    (g1,) = torch.autograd.grad(o1, qkv, do)
+    q, k, v = OF.PackHeadsFn.apply(qkv, H, c)
+    o2 = OF.UnpackHeadsFn.apply(OF.AttnFn.apply(q, k, v, 80 ** -0.5), c)
+    (g2,) = torch.autograd.grad(o2, qkv, do)
+    for a, b, name in ((o1, o2, "o"), (g1, g2, "dqkv")):
+        a, b = a.float(), b.float()
+        err = (a - b).abs().max().item()
+        assert err <= 2e-2 * b.abs().max().item() + 1e-3, (name, err, b.abs().max().item())
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < 1e-2, (name, rel)
+
+
+def test_packed_attention_matches_fp64_reference():
+    """Packed attention against float64 softmax attention on the oracle's head split (no HIP kernel in the reference leg)."""
+    import sys, os
+    from octic_vits_amd import functional as OF
+    B, T, H = 2, 257, 16
+    c = 10 * H
+    torch.manual_seed(7)
+    qkv = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16()
+    o = OF.AttnPackedFn.apply(qkv, H, c, 80 ** -0.5).float().cpu()
+    # oracle head split: head h = [w channels of A1, A2, B1, B2 | 2w of E0 | 2w of E1] of tensor s (d8_layers.py:631-643)
+    x = qkv.float().cpu().double()
+    w, cv = c // H, 3 * c
+    def head(s, h):
+        b0 = s * c + h * w
+        pieces = [x[:, :, g * cv + b0: g * cv + b0 + w] for g in range(4)]
+        pieces += [x[:, :, 4 * cv + r * 2 * cv + 2 * b0: 4 * cv + r * 2 * cv + 2 * b0 + 2 * w] for r in range(2)]
+        return torch.cat(pieces, -1)
+    ref = torch.zeros(B, T, 8 * c, dtype=torch.float64)
+    for h in range(H):
+        q, k, v = head(0, h), head(1, h), head(2, h)
+        p = torch.softmax(q @ k.transpose(1, 2) * 80 ** -0.5, -1)
+        oh = p @ v
+        b0 = h * w
+        for g in range(4):
+            ref[:, :, g * c + b0: g * c + b0 + w] = oh[:, :, g * w:(g + 1) * w]
+        for r in range(2):
+            ref[:, :, 4 * c + r * 2 * c + 2 * b0: 4 * c + r * 2 * c + 2 * b0 + 2 * w] = oh[:, :, 4 * w + r * 2 * w: 4 * w + (r + 1) * 2 * w]
+    err = (o.double() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), err

@@ -14,18 +14,30 @@ _lib.LIB_PATH = os.environ.get("OCTIC_LIB", os.path.join(os.path.dirname(os.path
 L = _lib.lib()
 L.octic_dbg_attn_trace.restype = ctypes.c_void_p
 B, H, T, hd = 64, 16, 257, 80
-q, k, v = (torch.randn(B, H, T, hd, device="cuda").bfloat16().requires_grad_(True) for _ in range(3))
-do = torch.randn(B, H, T, hd, device="cuda").bfloat16()
+PACKED = os.environ.get("PACKED", "0") == "1"       # AttentionD8 core on packed rows (octic_attn_*_packed)
+if PACKED:
+    c = 10 * H
+    qkv = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16().requires_grad_(True)
+    dop = torch.randn(B, T, 8 * c, device="cuda").bfloat16()
+
+    def run():
+        o = OF.AttnPackedFn.apply(qkv, H, c, hd ** -0.5)
+        torch.autograd.grad(o, qkv, dop)
+else:
+    q, k, v = (torch.randn(B, H, T, hd, device="cuda").bfloat16().requires_grad_(True) for _ in range(3))
+    do = torch.randn(B, H, T, hd, device="cuda").bfloat16()
+
+    def run():
+        o = OF.AttnFn.apply(q, k, v, hd ** -0.5)
+        torch.autograd.grad(o, (q, k, v), do)
 for _ in range(2):
-    o = OF.AttnFn.apply(q, k, v, hd ** -0.5)
-    torch.autograd.grad(o, (q, k, v), do)
+    run()
 torch.cuda.synchronize()
 n = 3 * 256 * 10 * 16
 hip = ctypes.CDLL("libamdhip64.so")
 src = L.octic_dbg_attn_trace()
 hip.hipMemset(ctypes.c_void_p(src), 0, n * 8)
-o = OF.AttnFn.apply(q, k, v, hd ** -0.5)
-torch.autograd.grad(o, (q, k, v), do)
+run()
 torch.cuda.synchronize()
 buf = torch.zeros(n, dtype=torch.int64, device="cuda")
 hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(src), n * 8, 3)
