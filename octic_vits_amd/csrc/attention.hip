@@ -149,6 +149,76 @@ __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA,
                                           char* imgB, int rsB, const bf16* srcB, int64_t stB, int kcB, int wcB,
                                           int T, int Tp, int tid, int nthr, const HeadMap mA = HeadMap{0, 0},
                                           const HeadMap mB = HeadMap{0, 0}) {
+  if (mA.cv != 0) {
+    // Packed rows: stage by PIECES - a thread fetches one whole piece (20 bytes of a one-dimensional irrep: 16 + 4, or
+    // 40 bytes of an E row: 16 + 16 + 8) and spreads it over the row image's groups.  One cache-line request per
+    // piece instead of one per 16-byte group (6 instead of 16 per row: with one request per group the staging phases
+    // of the backward kernels doubled).  Work items are ordered [piece][row], so a wave never mixes the two piece kinds.
+    // pads first: rows >= T, and groups >= hd / 8 of every row
+    for (int q = tid; q < Tp * (wcA > wcB ? wcA : wcB); q += nthr) {
+      const int tA = q / wcA, cA = q - tA * wcA, tB = q / wcB, cB = q - tB * wcB;
+      if (tA < Tp && (tA >= T || cA >= kcA)) *(u32x4*)(imgA + (size_t)tA * rsA + cA * 16) = u32x4{0, 0, 0, 0};
+      if (tB < Tp && (tB >= T || cB >= kcB)) *(u32x4*)(imgB + (size_t)tB * rsB + cB * 16) = u32x4{0, 0, 0, 0};
+    }
+    constexpr int PB = 3;                         // pieces in flight per thread and image
+    for (int base = 0; base < 4 * T; base += PB * nthr) {          // one-dimensional pieces: p = item / T
+      u32x4 a4[PB], b4[PB];
+      unsigned a1[PB], b1[PB];
+#pragma unroll
+      for (int it = 0; it < PB; ++it) {
+        const int q = base + it * nthr + tid;
+        if (q < 4 * T) {
+          const int pz = q / T, t = q - pz * T;
+          const bf16* ra = srcA + (int64_t)t * stA + pz * mA.cv + mA.bs;
+          const bf16* rb = srcB + (int64_t)t * stB + pz * mB.cv + mB.bs;
+          a4[it] = *(const u32x4_u*)ra; a1[it] = *(const unsigned*)(ra + 8);
+          b4[it] = *(const u32x4_u*)rb; b1[it] = *(const unsigned*)(rb + 8);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < PB; ++it) {
+        const int q = base + it * nthr + tid;
+        if (q < 4 * T) {
+          const int pz = q / T, t = q - pz * T;
+          char* la = imgA + (size_t)t * rsA;
+          char* lb = imgB + (size_t)t * rsB;
+          *(u32x4*)(la + pz * 16) = a4[it]; *(unsigned*)(la + 8 * 16 + pz * 4) = a1[it];
+          *(u32x4*)(lb + pz * 16) = b4[it]; *(unsigned*)(lb + 8 * 16 + pz * 4) = b1[it];
+        }
+      }
+    }
+    for (int base = 0; base < 2 * T; base += 2 * nthr) {             // E pieces: 16 + 16 + 8 bytes
+      u32x4 a4[2][2], b4[2][2];
+      u32x2 a2[2], b2[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int q = base + it * nthr + tid;
+        if (q < 2 * T) {
+          const int pz = q / T, t = q - pz * T;
+          const bf16* ra = srcA + (int64_t)t * stA + (4 + 2 * pz) * mA.cv + 2 * mA.bs;
+          const bf16* rb = srcB + (int64_t)t * stB + (4 + 2 * pz) * mB.cv + 2 * mB.bs;
+          a4[it][0] = *(const u32x4_u*)ra; a4[it][1] = *(const u32x4_u*)(ra + 8);
+          b4[it][0] = *(const u32x4_u*)rb; b4[it][1] = *(const u32x4_u*)(rb + 8);
+          const u32x2_u ta = *(const u32x2_u*)(ra + 16), tb = *(const u32x2_u*)(rb + 16);
+          a2[it] = u32x2{ta[0], ta[1]}; b2[it] = u32x2{tb[0], tb[1]};
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int q = base + it * nthr + tid;
+        if (q < 2 * T) {
+          const int pz = q / T, t = q - pz * T;
+          char* la = imgA + (size_t)t * rsA;
+          char* lb = imgB + (size_t)t * rsB;
+          *(u32x4*)(la + (4 + 2 * pz) * 16) = a4[it][0]; *(u32x4*)(la + (5 + 2 * pz) * 16) = a4[it][1];
+          *(u32x2*)(la + 9 * 16 + pz * 8) = a2[it];
+          *(u32x4*)(lb + (4 + 2 * pz) * 16) = b4[it][0]; *(u32x4*)(lb + (5 + 2 * pz) * 16) = b4[it][1];
+          *(u32x2*)(lb + 9 * 16 + pz * 8) = b2[it];
+        }
+      }
+    }
+    return;
+  }
   // wc = chunks written per row (>= kc: the extra ones are zeros), kc = chunks that exist in the source row
   const int totA = Tp * wcA, totB = Tp * wcB;
   const int tot = totA > totB ? totA : totB;
