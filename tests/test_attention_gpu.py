@@ -118,31 +118,33 @@ def test_packed_attention_matches_pack_attention_unpack(B, T, H):
 
 
 def test_packed_attention_matches_fp64_reference():
-    """Packed attention against float64 softmax attention on the oracle's head split (no HIP kernel in the reference leg)."""
-    import sys, os
+    """Packed-row attention against the ORACLE's AttentionD8 core in float64: oracle.pack_heads (reference
+    d8_layers.py:631-643) -> softmax attention -> oracle.unpack_heads (d8_layers.py:650-656).  No HIP kernel and no
+    product code in the reference leg; checks the head-piece schedule of the kernels (HeadMap) against the reference's
+    head split, forward and backward."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import octic_ref as R
     from octic_vits_amd import functional as OF
     B, T, H = 2, 257, 16
     c = 10 * H
+    cv = 3 * c
     torch.manual_seed(7)
-    qkv = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16()
-    o = OF.AttnPackedFn.apply(qkv, H, c, 80 ** -0.5).float().cpu()
-    # oracle head split: head h = [w channels of A1, A2, B1, B2 | 2w of E0 | 2w of E1] of tensor s (d8_layers.py:631-643)
-    x = qkv.float().cpu().double()
-    w, cv = c // H, 3 * c
-    def head(s, h):
-        b0 = s * c + h * w
-        pieces = [x[:, :, g * cv + b0: g * cv + b0 + w] for g in range(4)]
-        pieces += [x[:, :, 4 * cv + r * 2 * cv + 2 * b0: 4 * cv + r * 2 * cv + 2 * b0 + 2 * w] for r in range(2)]
-        return torch.cat(pieces, -1)
-    ref = torch.zeros(B, T, 8 * c, dtype=torch.float64)
-    for h in range(H):
-        q, k, v = head(0, h), head(1, h), head(2, h)
-        p = torch.softmax(q @ k.transpose(1, 2) * 80 ** -0.5, -1)
-        oh = p @ v
-        b0 = h * w
-        for g in range(4):
-            ref[:, :, g * c + b0: g * c + b0 + w] = oh[:, :, g * w:(g + 1) * w]
-        for r in range(2):
-            ref[:, :, 4 * c + r * 2 * c + 2 * b0: 4 * c + r * 2 * c + 2 * b0 + 2 * w] = oh[:, :, 4 * w + r * 2 * w: 4 * w + (r + 1) * 2 * w]
-    err = (o.double() - ref).abs().max().item()
-    assert err <= 2e-2 * ref.abs().max().item(), err
+    qkv = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16().requires_grad_(True)
+    do = torch.randn(B, T, 8 * c, device="cuda").bfloat16()
+    o = OF.AttnPackedFn.apply(qkv, H, c, 80 ** -0.5)
+    (g,) = torch.autograd.grad(o, qkv, do)
+
+    x = qkv.detach().float().cpu().double().requires_grad_(True)
+    tup = tuple(x[..., i * cv:(i + 1) * cv] for i in range(4)) + (x[..., 4 * cv:].reshape(B, T, 2, 2 * cv),)
+    q, k, v = R.pack_heads(tup, H)
+    p = torch.softmax(q @ k.transpose(-1, -2) * 80 ** -0.5, -1)
+    out5 = R.unpack_heads(p @ v)
+    ref = torch.cat(list(out5[:4]) + [out5[4].flatten(-2)], dim=-1)
+    (gref,) = torch.autograd.grad(ref, x, do.float().cpu().double())
+    for got, want, name in ((o, ref, "o"), (g, gref, "dqkv")):
+        got, want = got.detach().float().cpu().double(), want.detach()
+        err = (got - want).abs().max().item()
+        assert err <= 2e-2 * want.abs().max().item(), (name, err)
+        assert ((got - want).norm() / want.norm()).item() < 1e-2, name
