@@ -352,7 +352,8 @@ def test_captured_step_replays_like_eager_steps():
     for x, y in batches[1:] + batches[1:]:
         la.append(float(ta.step(x, y).detach()))
         lb.append(float(gs.replay(x, y)))
-    assert la == lb, (la, lb)
+    # equal to rounding: the pos_embed gradient's atomic adds make the two runs differ in the last bits (see below)
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 1e-6, (la, lb)
     assert len(set(la)) == len(la)                 # the weights did move between the steps
     # not bitwise: the pos_embed gradient is ATen's index_select backward (atomic adds -> run-to-run rounding
     # differences), which reaches every tensor through LAMB's global gradient norm
