@@ -817,6 +817,16 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
 #pragma unroll
         for (int pz = 0; pz < kXS - 1; ++pz) stores += sth[pz];
         // tail of the workgroup: a smaller count than strictly needed is always safe (it only waits longer)
+#ifndef OCTIC_XREG_SLOWWAIT
+        // steady state first (two or three scalar compares instead of the 17-way ladder of wait_vmcnt)
+        if (kXS == 3 && left >= 1 && stores == 0) {
+          if (w_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if (kXS == 3 && left >= 1 && stores == NSTORE && NSTORE == 6) {
+          if (w_cnt == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else
+#endif
         wait_vmcnt(left >= kXS - 2 ? (kXS - 2) * w_cnt + (stores > 20 ? 20 : stores) : left * w_cnt);
       } else {
         wait_vmcnt(0);
