@@ -20,4 +20,6 @@ for r in range(rounds):
     for name, so in libs:
         env = dict(os.environ, OCTIC_LIB=so)
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_xreg.py")], env=env, capture_output=True, text=True)
+        res2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_ring.py")], env=env, capture_output=True, text=True)
+        res.stdout = res.stdout.strip() + "   " + res2.stdout.strip()
         print(f"round {r} {name}:\n{res.stdout.strip()} {res.stderr.strip()[-200:] if res.returncode else ''}", flush=True)
