@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly (default at 1 GPU: the step is captured once with Trainer.capture and "
                          "replayed as one hipGraph; the kernel-timing steps stay eager.  With DDP the steps are always eager)")
+    ap.add_argument("--no-wgrad-slabs", action="store_true",
+                    help="developer A/B: library weight gradients as one GEMM instead of a batched GEMM over row slabs")
     ap.add_argument("--no-packed-attn", action="store_true",
                     help="developer A/B: AttentionD8 through the pack / unpack kernels instead of the packed-row attention")
     ap.add_argument("--wgrad-f32-out", action="store_true",
@@ -113,6 +115,9 @@ def main():
     if args.dense_hip is not None:
         from octic_vits_amd import functional as _OF
         _OF.DENSE_HIP = set() if args.dense_hip == "none" else set(args.dense_hip.split(","))
+    if args.no_wgrad_slabs:
+        from octic_vits_amd import functional as _OF
+        _OF.WGRAD_SLABS = {}
     if args.no_packed_attn:
         from octic_vits_amd import functional as _OF
         _OF.ATTN_PACKED = False
