@@ -105,7 +105,27 @@ def main():
                     help="developer A/B: library weight gradients straight to f32 (default: bf16 result + cast, as autocast does)")
     ap.add_argument("--dense-hip", default=None,
                     help="developer A/B: comma list of standard-half GEMMs on csrc/dense_gemm.hip (default: functional.DENSE_HIP; 'none' = library)")
+    ap.add_argument("--accum", type=int, default=1,
+                    help="micro-batches of --batch images per optimizer step (gradient accumulation; BASELINE configs[2] "
+                         "= --gpus 8 --batch 64 --accum 4: global batch 2048)")
+    ap.add_argument("--bucket-mb", type=int, default=None, help="DDP gradient bucket size (default: train.DDP_BUCKET_MB)")
+    ap.add_argument("--bf16-buckets", action="store_true", help="all-reduce the gradient buckets in bf16")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as FRESH child processes, before
+        # this process has touched the GPU (nothing above initialises HIP), relay rank 0's JSON line and the exit code.
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("no WORLD_SIZE in the environment: launching " + " ".join(cmd[1:]))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     from octic_vits_amd import ops
     from octic_vits_amd.deit_models import create_model
@@ -133,8 +153,11 @@ def main():
     log(f"rank {rank}/{world}: building {args.model}")
     model = create_model(args.model, num_classes=1000, drop_path_rate=0.5, img_size=224).to(dev)
     log("model on device")
-    trainer = Trainer(model, distributed=world > 1, local_rank=local_rank)
-    samples, targets = synthetic_batch(args.batch, 1000, dev, 4242 + rank)
+    tkw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
+    trainer = Trainer(model, distributed=world > 1, local_rank=local_rank, accum_steps=args.accum,
+                      bf16_buckets=args.bf16_buckets, **tkw)
+    samples, targets = synthetic_batch(args.batch * args.accum, 1000, dev, 4242 + rank)
+    n_ranks_seen = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
 
     def sync():
         if world > 1:
@@ -147,7 +170,7 @@ def main():
             torch.cuda.synchronize()
             log("first warm-up step done")
     graphed = None
-    if world == 1 and not args.no_graph:
+    if world == 1 and not args.no_graph and args.accum == 1:
         try:
             graphed = trainer.capture(samples, targets, warmup=1)
             for _ in range(2):
@@ -188,7 +211,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms = elapsed / args.steps * 1e3
-    ips = world * args.batch * args.steps / elapsed
+    ips = world * args.batch * args.accum * args.steps / elapsed
 
     # ---- forward-only throughput in the reference's own protocol (experiments/complexity.py:13-15,40-56,60-95): eval,
     # no_grad, batch 64, 10 warm-up + 100 timed forwards each followed by a synchronize, mean time -> images/s.  The
@@ -221,36 +244,61 @@ def main():
     if rank == 0:
         line = {
             "metric": METRIC, "value": round(ips, 2),
-            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "images/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (randn images, multi-hot targets; random-init weights)",
             "config": {"workload": f"{args.model} ({n_oct} octic + {n_std} standard blocks"
                                    f"{', invariant hand-off' if getattr(model, 'invariant', False) else ''}, drop_path 0.5) "
                                    "DeiT-III train step: "
                                    f"bf16-autocast fwd + bwd + LAMB + EMA, 224x224, batch {args.batch}/GPU "
-                                   f"(BASELINE configs[1]), data parallel over {world} GPU(s)",
-                       "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
+                                   + (f"x {args.accum} accumulated micro-batches (BASELINE configs[2] shape), "
+                                      if args.accum > 1 else "(BASELINE configs[1]), ")
+                                   + f"data parallel over {world} GPU(s)",
+                       "global_batch": world * args.batch * args.accum, "per_gpu_batch": args.batch,
+                       "accum_steps": args.accum, "parallelism": f"dp{world}",
                        "library_gemm_table": bool(trainer.tuned_gemms),
                        "launch": "hipGraph replay (kernel-timing steps eager)" if graphed is not None else "eager"},
             "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),
             "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4),
         }
-        k = ops.KERNEL_TIMER.dominant()
-        if k is not None:
+        kern = ops.KERNEL_TIMER.summary()
+        if kern:
             traffic_db = {}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic_db = json.load(f)
-
             sampled_steps = len(sampled)
+            agg = ops.KERNEL_TIMER._agg()
 
-            def roof(k):
+            def family_of(name):
+                if name.startswith("library_gemm"):
+                    return "library GEMM (hipBLASLt, standard half)"
+                if name.startswith(("dense_nt_kernel", "dense_tn_kernel")):
+                    return "hand-written dense GEMM (standard half)"
+                if name.startswith(("linear_d8", "wgrad_", "mlp_d8")):
+                    return "octic irrep GEMM (LinearD8 fwd/dgrad/wgrad)"
+                if name.startswith("attn_"):
+                    return "attention"
+                return "row kernels (LayerNorm, GELU, residual tails, casts)"
+
+            def merged(names, label):
+                """One record for a set of timer entries (e.g. all library weight-gradient shapes = one rocprof family)."""
+                rs = [agg[n] for n in names]
+                tot = sum(r["total_us"] for r in rs)
+                launches = sum(r["launches"] for r in rs)
+                return {"name": label, "launches": launches, "total_us": tot, "avg_us": tot / launches,
+                        "alg_bytes_per_launch": sum(r["bytes"] for r in rs) / launches,
+                        "flops_per_launch": sum(r["flops"] for r in rs) / launches}
+
+            def roof(k, bound=None):
                 sec = k["avg_us"] * 1e-6
+                tr = traffic_db.get(k["name"], {}).get("hbm_bytes_per_launch")
                 common = {"kernel": k["name"], "launches": k["launches"], "avg_us": round(k["avg_us"], 2),
-                          "share_of_step": round(k["total_us"] / (ms * 1e3 * sampled_steps), 4),
-                          "traffic": traffic_db.get(k["name"], {}).get("hbm_bytes_per_launch")}
-                if ops.KERNEL_TIMER.bound_of(k["name"]) == "mfma":
+                          "share_of_step": round(k["total_us"] / (ms * 1e3 * sampled_steps), 4), "traffic": tr}
+                if tr is not None:
+                    common["traffic_source"] = "profiles/traffic.json (PMC FETCH_SIZE x2 + WRITE_SIZE, builder's rocprofv3 run)"
+                if (bound or ops.KERNEL_TIMER.bound_of(k["name"])) == "mfma":
                     ach = k["flops_per_launch"] / sec
                     return {"bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
                             "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16, 4),
@@ -260,16 +308,52 @@ def main():
                         "frac": round(ach / HBM_PEAK, 4), "alg_bytes_per_launch": int(k["alg_bytes_per_launch"]),
                         "mfma_tflops": round(k["flops_per_launch"] / sec / 1e12, 1), **common}
 
-            # dominant = the hand-written kernel with the largest total time in the timed steps; the largest
-            # HBM-bound one is reported next to it when the dominant one is MFMA-bound (attention)
-            line["roofline"] = roof(k)
-            kh = ops.KERNEL_TIMER.dominant("hbm")
-            if kh is not None and kh["name"] != k["name"]:
-                line["roofline_hbm_kernel"] = roof(kh)
-            line["kernels"] = ops.KERNEL_TIMER.summary()
+            # `roofline` = the kernel with the largest total time in the timed steps.  Library GEMMs are ranked the way a
+            # profiler sees them - per operation kind (all weight-gradient shapes run the same hipBLASLt kernel family),
+            # not split by shape - so a 10 % library family is not hidden behind a 6 % hand-written kernel.
+            cands = {n: a for n, a in agg.items() if not n.startswith("library_gemm")}
+            for kind in ("fwd", "dgrad", "wgrad"):
+                names = [n for n in agg if n.startswith(f"library_gemm<{kind} ")]
+                if names:
+                    cands[f"library_gemm<{kind}, all shapes>"] = merged(names, f"library_gemm<{kind}, all shapes>")
+            top = max(cands.values(), key=lambda a: a["total_us"])
+            line["roofline"] = roof(top)
+            hand = [a for n, a in agg.items() if not n.startswith("library_gemm")]
+            if hand:
+                kh = max(hand, key=lambda a: a["total_us"])
+                if kh["name"] != top["name"]:
+                    line["roofline_top_handwritten"] = roof(kh)
+                hb = [a for a in hand if ops.KERNEL_TIMER.bound_of(a["name"]) == "hbm"]
+                if hb:
+                    kb = max(hb, key=lambda a: a["total_us"])
+                    if kb["name"] not in (top["name"], kh["name"]):
+                        line["roofline_hbm_kernel"] = roof(kb)
+            line["kernels"] = kern
+            # families: where the step goes, each against its own roofline
+            fams = {}
+            for n, a in agg.items():
+                f = fams.setdefault(family_of(n), {"ms_per_step": 0.0, "bytes": 0.0, "flops": 0.0, "us": 0.0,
+                                                   "mfma": ops.KERNEL_TIMER.bound_of(n) == "mfma"})
+                f["ms_per_step"] += a["total_us"] / sampled_steps / 1e3
+                f["us"] += a["total_us"]
+                f["bytes"] += a["bytes"]
+                f["flops"] += a["flops"]
+            timed_us = sum(v["total_us"] for v in kern.values()) / sampled_steps
+            out_f = {}
+            for name, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+                sec = f["us"] * 1e-6
+                rec = {"ms_per_step": round(f["ms_per_step"], 2), "share_of_step": round(f["ms_per_step"] / ms, 4)}
+                if f["flops"]:
+                    rec["TFLOPs"] = round(f["flops"] / sec / 1e12, 1)
+                    rec["frac_mfma_peak"] = round(f["flops"] / sec / MFMA_PEAK_BF16, 4)
+                rec["GBps"] = round(f["bytes"] / sec / 1e9, 1)
+                rec["frac_hbm_peak"] = round(f["bytes"] / sec / HBM_PEAK, 4)
+                out_f[name] = rec
+            out_f["optimizer + ATen glue (untimed)"] = {"ms_per_step": round(ms - timed_us / 1e3, 2),
+                                                        "share_of_step": round(1 - timed_us / 1e3 / ms, 4)}
+            line["families"] = out_f
             # how much of a step the per-kernel table explains: engine kernels + the BLAS-library GEMMs are timed
             # individually; the rest is ATen glue (casts, reductions, RNG, copies) and the fused optimizer
-            timed_us = sum(v["total_us"] for v in line["kernels"].values()) / sampled_steps
             line["step_breakdown"] = {"timed_kernels_ms": round(timed_us / 1e3, 2),
                                       "other_ms": round(ms - timed_us / 1e3, 2),
                                       "note": "timed = engine kernels + BLAS-library GEMMs of the standard half, HIP events in "

@@ -469,8 +469,9 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     const int last = flag[0];
     __syncthreads();                       // flag word is part of the staging area below
     if (last == 0) return;
+    // fixed summation order slab 0 + slab 1 + ... whichever part arrived last (its own partial is re-read from its
+    // slab): the result does not depend on the arrival order, so identical launches give identical bits
     for (int p = 0; p < a.split; ++p) {
-      if (p == part) continue;
       const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)rem_idx * a.split + p) * (DG_BM * DG_BN)) +
                         (int64_t)wid * 32 * 64 + lane;
 #pragma unroll
@@ -480,7 +481,10 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mh][nh][mi][ni] += o4[(((mh * 2 + nh) * 4 + mi) * 2 + ni) * 64];
+            for (int ni = 0; ni < 2; ++ni) {
+              const f32x4 o = o4[(((mh * 2 + nh) * 4 + mi) * 2 + ni) * 64];
+              acc[mh][nh][mi][ni] = p == 0 ? o : acc[mh][nh][mi][ni] + o;
+            }
     }
   }
 

@@ -174,15 +174,57 @@ def _unfold_tables_on(h: int, kind: str, device: str, dtype):
         return t(ia), t(sa, dtype), t(ib), t(sb, dtype)
 
 
+@lru_cache(maxsize=None)
+def _fold_tables_on(h: int, kind: str, device: str, dtype):
+    """Inverse of the unfold tables: for every quarter entry the (2h)^2-grid positions that read it, as a dense
+    [h*h, n] index table per gather (every quarter entry is read the same number of times: 4 quadrants), with the
+    signs.  The backward of the unfold is then a GATHER over these tables - a fixed-order sum, bitwise reproducible -
+    instead of ATen's index_select backward (index_add_ with float atomics, whose summation order changes from run
+    to run and leaks into every tensor of a LAMB step through the global gradient norm)."""
+    with torch.inference_mode(False):
+        ia, sa, ib, sb = _unfold_tables(h, kind)
+        dev = torch.device(device)
+        out = []
+        for idx, sg in ((ia, sa), (ib, sb)):
+            if idx is None:
+                out += [None, None]
+                continue
+            order = torch.argsort(idx, stable=True)
+            counts = torch.bincount(idx, minlength=h * h)
+            n = int(counts[0])
+            assert bool((counts == n).all()), "unfold table is not uniform"
+            out += [order.view(h * h, n).to(dev).clone(), sg[order].view(h * h, n).to(dev, dtype).clone()]
+        return tuple(out)
+
+
+class _GatherUnfoldFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, dim, h, kind):
+        ia, sa, ib, sb = _unfold_tables_on(h, kind, str(flat.device), flat.dtype)
+        shape = [1] * flat.dim()
+        shape[dim] = -1
+        out = flat.index_select(dim, ia) * sa.view(shape)
+        if ib is not None:
+            out = out + flat.index_select(dim, ib) * sb.view(shape)
+        ctx.meta = (dim, h, kind)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dim, h, kind = ctx.meta
+        pa, ga, pb, gb = _fold_tables_on(h, kind, str(g.device), g.dtype)
+        n = pa.shape[1]
+        shape = [1] * (g.dim() + 1)
+        shape[dim], shape[dim + 1] = h * h, n
+        gf = (g.index_select(dim, pa.flatten()).unflatten(dim, (h * h, n)) * ga.view(shape)).sum(dim + 1)
+        if pb is not None:
+            gf = gf + (g.index_select(dim, pb.flatten()).unflatten(dim, (h * h, n)) * gb.view(shape)).sum(dim + 1)
+        return gf, None, None, None
+
+
 def _gather_unfold(flat, dim, h, kind):
     """flat: tensor whose dimension `dim` enumerates the h*h quarter; returns it with (2h)^2 entries."""
-    ia, sa, ib, sb = _unfold_tables_on(h, kind, str(flat.device), flat.dtype)
-    shape = [1] * flat.dim()
-    shape[dim] = -1
-    out = flat.index_select(dim, ia) * sa.view(shape)
-    if ib is not None:
-        out = out + flat.index_select(dim, ib) * sb.view(shape)
-    return out
+    return _GatherUnfoldFn.apply(flat, dim, h, kind)
 
 
 def unfold_quarter(q, kind, d0, d1):

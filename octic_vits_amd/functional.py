@@ -416,6 +416,7 @@ class DenseWeightCache:
     def __init__(self):
         self.key = None
         self.w = self.b = None
+        self.wt = self.wt_key = None
 
     @staticmethod
     def _key(w, b, dtype):
@@ -428,6 +429,7 @@ class DenseWeightCache:
                 self.w = _c(w.detach().to(dtype))
                 self.b = None if b is None else _c(b.detach().to(dtype))
             self.key = key
+            self.wt, self.wt_key = None, None     # a transposed copy of the old cast is stale with it
         return self.w, self.b
 
     def adopt(self, w, b, w_copy, b_copy, dtype, wt_copy=None):
@@ -444,7 +446,7 @@ class DenseWeightCache:
         wb, _ = self.get(w, b, torch.bfloat16)
         if not need_wt:
             return wb, None
-        if getattr(self, "wt_key", None) != self.key:
+        if self.wt is None or self.wt_key != self.key:
             with torch.no_grad():
                 self.wt = wb.t().contiguous()
             self.wt_key = self.key
@@ -577,6 +579,10 @@ def invalidate_weight_caches(model):
             c = getattr(m, attr, None)
             if isinstance(c, (WeightPrep, DenseWeightCache)):
                 c.key = None
+                if isinstance(c, DenseWeightCache):
+                    # the transposed copy (operand of the hand-written input-gradient GEMM) keys on `key`; a re-cast
+                    # restores the same key (data_ptr and _version are unchanged by a raw write), so drop it explicitly
+                    c.wt, c.wt_key = None, None
                 n += 1
     return n
 
@@ -599,9 +605,10 @@ DENSE_HIP = {"qkv", "dqkv", "fc1"}          # subset of {"qkv", "dqkv", "proj", 
 
 
 def dense_hip_ok(x, w, which=None):
-    """bf16 autocast on the GPU, a shape csrc/dense_gemm.hip covers (K % 64 == 0, K >= 128, N % 8 == 0) and routed."""
+    """bf16 autocast on the GPU, a shape csrc/dense_gemm.hip covers in BOTH directions (forward: K = in_features,
+    input gradient: K = out_features; the kernel needs K % 64 == 0, K >= 128, N % 8 == 0) and routed."""
     return ((which is None or which in DENSE_HIP) and x.is_cuda and w.shape[1] % 64 == 0 and w.shape[1] >= 128
-            and w.shape[0] % 8 == 0 and w.shape[0] % 64 == 0)
+            and w.shape[0] % 64 == 0 and w.shape[0] >= 128)
 
 
 def _f32(t):

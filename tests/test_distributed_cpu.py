@@ -85,3 +85,89 @@ def test_synthetic_batches_differ_per_rank_and_are_reproducible():
     a2, _ = synthetic_batch(2, 10, "cpu", 4242 + 0, img_size=16)
     assert not torch.equal(a, b) and torch.equal(a, a2)
     assert ta.shape == (2, 10) and set(ta.unique().tolist()) <= {0.0, 1.0} and (ta.sum(1) >= 1).all()
+
+
+class _Net(torch.nn.Module):
+    """standard block + head with the model surface Trainer needs (no_weight_decay)."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = _make_model()
+
+    def no_weight_decay(self):
+        return set()
+
+    def forward(self, x):
+        return self.body(x).mean(1)
+
+
+def _accum_batch():
+    g = torch.Generator().manual_seed(321)
+    x = torch.randn(8, 6, 32, generator=g)
+    y = (torch.rand(8, 5, generator=g) > 0.6).float()
+    return x, y
+
+
+def _accum_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from octic_vits_amd.train import Trainer, init_distributed
+    init_distributed()
+    x, y = _accum_batch()
+    per = 8 // world
+    tr = Trainer(_Net(), distributed=True, fused_optimizer=False, tuned_gemms=False, autocast=False, accum_steps=2,
+                 ema_decay=None, device_type="cpu", bucket_cap_mb=1)
+    for _ in range(3):
+        tr.step(x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per])
+    flat = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g) for g in gathered)
+    if rank == 0:
+        torch.save(flat, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trainer_accumulation_under_ddp_matches_single_process(tmp_path):
+    """configs[2]'s shape in miniature: 2 ranks x 2 accumulated micro-batches x 2 samples == one process on all 8
+    samples.  The first micro-batch runs under DDP.no_sync (no all-reduce), the second one all-reduces the SUM of both
+    micro-batch gradients; Trainer divides each micro-batch loss by the number of micro-batches."""
+    out = str(tmp_path / "accum.pt")
+    mp.spawn(_accum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ddp = torch.load(out)
+    from octic_vits_amd.train import Trainer
+    x, y = _accum_batch()
+    for accum in (1, 4):
+        tr = Trainer(_Net(), distributed=False, fused_optimizer=False, tuned_gemms=False, autocast=False,
+                     accum_steps=accum, ema_decay=None, device_type="cpu")
+        for _ in range(3):
+            tr.step(x, y)
+        single = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
+        assert torch.allclose(ddp, single, rtol=1e-4, atol=1e-5), (accum, float((ddp - single).abs().max()))
+
+
+def test_bench_spawns_its_own_ranks_when_launched_bare(monkeypatch, capsys):
+    """`python bench.py --gpus N` with no WORLD_SIZE must start N ranks itself (fresh children, before any GPU call) and
+    pass the exit code through; here the child launcher is intercepted."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--accum", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-8:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--accum", "4"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

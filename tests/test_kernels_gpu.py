@@ -313,7 +313,8 @@ def test_handoff_and_power_spectrum(out_dtype):
     close(o.power_spectrum_bwd(d6.to(DEV), x, c), pack([t.grad for t in xr]), 2e-5, 2e-5, "power spectrum bwd")
 
 
-@pytest.mark.parametrize("p,G,D", [(4, 4, 64), (14, 2, 64), (16, 14, 384)])
+# (14, 16, 1280) is the bench shape: ViT-H/14 at 224x224 (K = 588 padded to 592)
+@pytest.mark.parametrize("p,G,D", [(4, 4, 64), (14, 2, 64), (16, 14, 384), (14, 16, 1280)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_lift_gemm_matches_patch_embed(p, G, D, dtype):
     """im2col + one GEMM against the symmetry-expanded kernels == the 8 strided convs of PatchEmbedD8."""

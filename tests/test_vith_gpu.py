@@ -1,0 +1,81 @@
+"""The headline model itself: `hybrid_deit_huge_patch14` (BASELINE configs[1], 16 octic + 16 standard blocks, D = 1280,
+patch 14, 224x224) on the GPU against the CPU oracle (oracle/octic_ref.py, pinned to the reference by tests/golden).
+
+  * f32 forward on 2 images: max |logit error| <= 1e-3 of the logit scale - the north-star sentence ("forward matching
+    reference to 1e-3 rel"), literally, on the 32-block ViT-H (reference octic_vits/model.py:170-213);
+  * bf16-autocast forward + backward (the bench's compute mode, deit/engine.py:43-87): logits within 5e-2 of scale and
+    parameter gradients per tensor, on a strided sample of the 982 tensors, within max(3e-2, 2 x the oracle's own
+    distance under CPU bf16 autocast) in relative L2 - the rule of test_modules_gpu.py::test_bf16_autocast_*.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _models():
+    from oracle import octic_ref as R
+    from octic_vits_amd.deit_models import create_model
+    ref = R.create_model("hybrid_deit_huge_patch14", num_classes=1000, drop_path_rate=0.0, img_size=224)
+    cases.fill_parameters(ref, salt="vith.")
+    net = create_model("hybrid_deit_huge_patch14", num_classes=1000, drop_path_rate=0.0, img_size=224)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    return ref, net.cuda()
+
+
+@pytest.mark.timeout(1800)
+def test_hybrid_vit_huge_forward_f32_and_bf16_gradients_match_the_oracle():
+    ref, net = _models()
+    img = cases.randn("vith.img", 2, 3, 224, 224)
+    cot = cases.randn("vith.cot", 2, 1000)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+
+    # ---- f32 forward: the north-star tolerance on the headline model
+    ref.eval()
+    net.eval()
+    with torch.no_grad():
+        want = ref(img)
+        got = net(img.cuda()).float().cpu()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= 1e-3 * scale, f"ViT-H f32 forward: max err {err:.3e} vs scale {scale:.3g}"
+
+    # ---- f32 reference gradients (train mode, drop_path 0) and the oracle's own bf16-autocast distance
+    ref.train()
+    names = [n for n, p in ref.named_parameters() if p.requires_grad]
+    sample = names[::17] + [n for n in names if n.startswith(("pos_embed", "cls_token.0", "head.", "norm."))]
+    sample = sorted(set(sample))
+
+    def grads_of(model, x, c, autocast_device=None):
+        for p in model.parameters():
+            p.grad = None
+        if autocast_device is None:
+            out = model(x)
+        else:
+            with torch.autocast(autocast_device, dtype=torch.bfloat16):
+                out = model(x)
+        (out.float() * c).sum().backward()
+        params = dict(model.named_parameters())
+        return out.detach().float().cpu(), {n: params[n].grad.detach().float().cpu().double().numpy() for n in sample}
+
+    out_ref, g_ref = grads_of(ref, img, cot)
+    _, g_yard = grads_of(ref, img, cot, "cpu")
+    net.train()
+    out_got, g_got = grads_of(net, img.cuda(), cot.cuda(), "cuda")
+    assert torch.allclose(out_got, out_ref, rtol=5e-2, atol=5e-2 * scale), \
+        f"ViT-H bf16 forward: max err {float((out_got - out_ref).abs().max()):.3e}"
+    worst = []
+    for n in sample:
+        w = g_ref[n]
+        den = max(float(np.linalg.norm(w)), 1e-6)
+        rel = float(np.linalg.norm(g_got[n] - w)) / den
+        rel_oracle = float(np.linalg.norm(g_yard[n] - w)) / den
+        lim = max(3e-2, 2.0 * rel_oracle)
+        worst.append((rel / lim, n, rel, rel_oracle))
+    worst.sort(reverse=True)
+    bad = [w for w in worst if w[0] > 1.0]
+    assert not bad, "ViT-H bf16 gradients beyond max(3e-2, 2 x oracle-under-bf16): " + \
+        "; ".join(f"{n}: {r:.4f} (oracle {ro:.4f})" for _, n, r, ro in bad[:8])
