@@ -14,9 +14,13 @@
 //     16-lane group).  32-byte slots are XOR-swizzled with ((row & 3) | ((row >> 3) & 1) << 2) on the DMA source side and
 //     in the read address, so the 8 (row, slot) pieces a half-wave touches land in 8 different bank groups;
 //   * the output is small (N x K) and the reduction long (M = 16 448 rows = 257 steps): there are only 25-100 tiles for
-//     256 CUs, so the work is cut stream-K style — the tiles x steps units are dealt to `grid` workgroups in equal
-//     contiguous ranges; a range that covers only part of a tile leaves an f32 partial slab, and the LAST workgroup to
-//     finish a tile (agent-scope ticket) adds the other slabs in a fixed order and writes dW (bitwise reproducible);
+//     256 CUs, so the reduction is cut into S ROW SLABS and a workgroup owns one (slab, tile) item.  All tiles of a slab
+//     are dealt to consecutive workgroups and walk the same token rows in lockstep, tiles that share a dY column panel
+//     sit on one XCD: an operand row is fetched from HBM once per slab and then served out of L2 / the Infinity Cache.
+//     (Round 2's stream-K split - equal contiguous ranges of tiles x steps - gave concurrent workgroups disjoint token
+//     rows: every workgroup streamed its own operands, 1.7 GB of HBM traffic per launch instead of 0.2 GB, and the
+//     kernel ran at the HBM rate, 0.53 PFLOP/s.)  Every item leaves an f32 partial slab; the LAST workgroup to finish
+//     a tile (agent-scope ticket) adds the S slabs in slab order and writes dW (bitwise reproducible).
 //     (Bias gradients come from the row kernels that already stream dY: csrc/dense.hip.)
 #include <type_traits>
 #include "octic_common.hpp"
@@ -26,8 +30,20 @@ namespace octic {
 constexpr int DW_T = 256;                     // output tile side
 constexpr int DW_BR = 64;                     // token rows per reduction step
 constexpr int DW_UNIT = 64 * 256;             // bytes per unit: 64 rows x 128 bf16 columns
-constexpr int DW_SLOTS = 8;
-constexpr int DW_D = 6;
+#ifndef DW_NSLOT
+#define DW_NSLOT 8
+#endif
+#ifndef DW_DIST
+#define DW_DIST 6
+#endif
+#ifndef DW_MAP
+#define DW_MAP 1        // 1: an XCD works on 32 consecutive (slab, tile) items per round; 0: one slab spread over all XCDs
+#endif
+#ifndef DW_AUX
+#define DW_AUX 0        // cache policy bits of the LDS-DMA loads (2 = nt)
+#endif
+constexpr int DW_SLOTS = DW_NSLOT;
+constexpr int DW_D = DW_DIST;
 
 struct DwArgs {
   const bf16* Y;      // dY [M, N]
@@ -37,8 +53,10 @@ struct DwArgs {
   float* W;           // dW [N, K]
   int tiles_k;        // K / 256
   int tiles;          // (N / 256) * (K / 256), tile = tn * tiles_k + tk
+  int tiles8;         // tiles rounded up to a multiple of 8: items per slab (the padding items exit at once)
   int steps;          // ceil(M / 64) reduction steps per tile
-  float* slabs;       // [2 * grid] x 256 x 256 f32 partial tiles
+  int S;              // row slabs: slab s covers steps [steps s / S, steps (s + 1) / S)
+  float* slabs;       // [tiles][S] x 256 x 256 f32 partial tiles
   int* tickets;       // [tiles], zero when the workspace is created; the last arriver of a tile re-arms its ticket
 };
 
@@ -48,8 +66,17 @@ __device__ inline void dw_wait_vmcnt(int n) {
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
+}
+
+__device__ inline void dw_wait_steady() {          // steady state: all but the 2 (D - 2) youngest DMA instructions landed
+  static_assert(DW_D == 4 || DW_D == 6 || DW_D == 8, "add the immediate");
+  if constexpr (DW_D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (DW_D == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
 __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
@@ -93,19 +120,38 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) offX[i] = frow * 256 + (((wc * 2 + i) ^ ff) << 5) + (fr & 3) * 8;
 
-  // ---- this workgroup's share of the tiles x steps units (stream-K)
-  const int64_t U = (int64_t)a.tiles * a.steps;
-  int64_t u0 = U * blockIdx.x / gridDim.x;
-  const int64_t u1 = U * (blockIdx.x + 1) / gridDim.x;
-  int seg = 0;
-  while (u0 < u1) {
-    const int tile = (int)(u0 / a.steps);
-    const int s0 = (int)(u0 - (int64_t)tile * a.steps);
-    const int s1 = (int)((u1 - u0) < (a.steps - s0) ? s0 + (u1 - u0) : a.steps);
-    u0 += s1 - s0;
+  // ---- this workgroup's (slab, tile) item.  Items of a slab are consecutive; item j of a slab runs on XCD j % 8
+  // (workgroups are dealt round-robin over the XCDs), which owns a contiguous chunk of the tn-major tile list: the
+  // tiles of one dY column panel (same tn) share an L2, and a tile's S partial slabs are written and reduced there.
+#if DW_MAP == 1
+  // Items are numbered slab-major, tiles tn-major inside a slab.  Workgroups are dealt round-robin over the 8 XCDs and
+  // 32 of them are resident per XCD: XCD x takes items [32 (8 r + x), + 32) in round r - a compact patch of ~6 dY
+  // column panels x all X panels of ONE slab, so an XCD fetches ~11 operand panels per step for 32 tiles (0.36 panel
+  // fetches per tile-step; spreading a slab over all XCDs costs 0.6 and made the kernel wait on the fabric).
+  int slab_i, tile;
+  {
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int item = ((slot >> 5) * 8 + x) * 32 + (slot & 31);
+    if (item >= a.tiles * a.S) return;                       // padding item
+    slab_i = item / a.tiles;
+    tile = item - slab_i * a.tiles;
+  }
+#else
+  const int slab_i = blockIdx.x / a.tiles8;
+  int tile;
+  {
+    const int j = blockIdx.x - slab_i * a.tiles8;
+    const int x = j & 7, l = j >> 3, q8 = a.tiles >> 3, r8 = a.tiles & 7;
+    if (l >= q8 + (x < r8 ? 1 : 0)) return;                  // padding item
+    tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + l;
+  }
+#endif
+  {
+    const int s0 = (int)((int64_t)a.steps * slab_i / a.S);
+    const int s1 = (int)((int64_t)a.steps * (slab_i + 1) / a.S);
     const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
     const int n0 = tn * DW_T, k0 = tk * DW_T;
-    const int nkt = s1 - s0;
+    const int nkt = s1 - s0;                                 // >= 1 (the launcher keeps S <= max(1, steps / 2))
     const int nunits = 4 * nkt;
 
     f32x4 acc[2][2][4][2];               // [n-half][k-half][n-tile][k-tile]
@@ -129,16 +175,16 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
       constexpr int KIND = decltype(kind_c)::value;
       constexpr bool isY = KIND == 0 || KIND == 3;
       constexpr bool second = KIND >= 2;
-      char* dst = lds + (u_issue & (DW_SLOTS - 1)) * DW_UNIT + wid * 2048;
+      char* dst = lds + (u_issue % DW_SLOTS) * DW_UNIT + wid * 2048;
       const int t = u_issue >> 2;
       if constexpr (isY) {
         const int so = sbY + t * stepY + (second ? 128 : 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)dst, 16, voY[0], so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voY[1], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)dst, 16, voY[0], so, 0, DW_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voY[1], so, 0, DW_AUX);
       } else {
         const int so = sbX + t * stepX + (second ? 64 : 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, voX[0], so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voX[1], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, voX[0], so, 0, DW_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voX[1], so, 0, DW_AUX);
       }
       ++u_issue;
     };
@@ -153,14 +199,14 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
       return __builtin_bit_cast(bf16x8, v);
     };
     auto readY = [&](int unit) {
-      const char* base = lds + (unit & (DW_SLOTS - 1)) * DW_UNIT;
+      const char* base = lds + (unit % DW_SLOTS) * DW_UNIT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j) Yf[ks][j] = tr8(base + ks * (32 * 256) + offY[j]);
     };
     auto readX = [&](int kh, int unit) {
-      const char* base = lds + (unit & (DW_SLOTS - 1)) * DW_UNIT;
+      const char* base = lds + (unit % DW_SLOTS) * DW_UNIT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -185,14 +231,15 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
       int need = g + 2;
       need = need < nunits - 1 ? need : nunits - 1;
       const int ok = (u_issue - 1) - need;
-      if (ok == DW_D - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (ok == DW_D - 2) dw_wait_steady();
       else dw_wait_vmcnt(ok > 0 ? 2 * ok : 0);
     };
-    static_assert(DW_D == 6, "steady-state vmcnt immediate is 2 * (D - 2) = 8");
 
     // ---- prologue (see csrc/dense_gemm.hip for the protocol)
 #define DW_PRO(i) if (u_issue < nunits) issue_unit(DW_IC((i) & 3));
-    DW_PRO(0) DW_PRO(1) DW_PRO(2) DW_PRO(3) DW_PRO(4) DW_PRO(5)
+    DW_PRO(0) DW_PRO(1) DW_PRO(2) DW_PRO(3)
+    if constexpr (DW_D > 4) { DW_PRO(4) DW_PRO(5) }
+    if constexpr (DW_D > 6) { DW_PRO(6) DW_PRO(7) }
 #undef DW_PRO
     {
       const int ok = (u_issue - 1) - 1;
@@ -207,7 +254,7 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
         if (STEADY || u_issue < nunits) issue_unit(kind_c);
       };
       auto landed = [&]() {
-        if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (STEADY) dw_wait_steady();
         else wait_landed();
       };
       // phase 0: first n half x first k half
@@ -265,11 +312,10 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
     __builtin_amdgcn_s_barrier();            // the ring is idle
 
     // ---- partial tile: publish, last arriver of the tile reduces (plain stores -> drain -> barrier -> agent release ->
-    // ticket; reducer: agent acquire -> barrier).  The number of ranges touching a tile follows from the partition.
-    const bool whole = (s0 == 0 && s1 == a.steps);
-    bool reducer = whole;
-    if (!whole) {
-      float* slab = a.slabs + ((int64_t)blockIdx.x * 2 + seg) * (DW_T * DW_T);
+    // ticket; reducer: agent acquire -> barrier).
+    bool reducer = a.S == 1;
+    if (a.S > 1) {
+      float* slab = a.slabs + ((int64_t)tile * a.S + slab_i) * (DW_T * DW_T);
       f32x4* sw4 = (f32x4*)slab + (int64_t)wid * 32 * 64 + lane;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
@@ -282,22 +328,12 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       int* flag = (int*)lds;
-      // ranges covering this tile: workgroups w with [U w / G, U (w+1) / G) intersecting [tile * steps, (tile+1) * steps)
-      const int64_t tb = (int64_t)tile * a.steps, te = tb + a.steps;
-      const int G = gridDim.x;
-      int w_first = (int)((tb * G) / U);
-      while (U * (w_first + 1) / G <= tb) ++w_first;
-      while (w_first > 0 && U * w_first / G > tb) --w_first;
-      int w_last = (int)(((te - 1) * G) / U);
-      while (U * w_last / G >= te) --w_last;
-      while (w_last + 1 < G && U * (w_last + 1) / G < te) ++w_last;
-      const int count = w_last - w_first + 1;
       if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int old = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = (old == count - 1) ? 1 : 0;
-        if (old == count - 1) {
+        flag[0] = (old == a.S - 1) ? 1 : 0;
+        if (old == a.S - 1) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
@@ -307,21 +343,9 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
       reducer = flag[0] != 0;
       __syncthreads();
       if (reducer) {
-        // fixed order: zero, then every contributing range from the first workgroup to the last (own slab re-read too)
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-              for (int i = 0; i < 2; ++i) acc[nh][kh][j][i] = f32x4{0, 0, 0, 0};
-        for (int w = w_first; w <= w_last; ++w) {
-          // segment index of workgroup w on this tile: 0 if its range starts inside (or at the start of) the tile's part it
-          // processes first, i.e. if the tile contains the range start; else 1
-          const int64_t wu0 = U * w / G;
-          const int sidx = (wu0 >= tb) ? 0 : ((wu0 / a.steps == tile) ? 0 : 1);
-          const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)w * 2 + sidx) * (DW_T * DW_T)) + (int64_t)wid * 32 * 64 + lane;
+        // fixed order: slab 0 + slab 1 + ... (the reducer's own partial is re-read from its slab)
+        for (int w = 0; w < a.S; ++w) {
+          const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)tile * a.S + w) * (DW_T * DW_T)) + (int64_t)wid * 32 * 64 + lane;
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -329,7 +353,10 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
 #pragma unroll
               for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[nh][kh][j][i] += o4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64];
+                for (int i = 0; i < 2; ++i) {
+                  const f32x4 o = o4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64];
+                  acc[nh][kh][j][i] = w == 0 ? o : acc[nh][kh][j][i] + o;
+                }
         }
       }
     }
@@ -352,8 +379,6 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
           }
         }
     }
-    ++seg;
-    __syncthreads();                         // LDS (flag word, ring) is re-used by the next segment
   }
 }
 
@@ -363,30 +388,57 @@ using namespace octic;
 
 extern "C" {
 
-static int dw_grid(int64_t units) {
-  return units < 256 ? (int)units : 256;     // one workgroup per CU (every range non-empty); equal ranges: equally long
+// Row slabs: the items (tiles8 x S) run in ceil(items / CUs) rounds of ceil(steps / S) reduction steps each; every item
+// also pays a fixed prologue + slab epilogue (about 8 steps' worth).  Pick the S with the shortest estimate.
+static int g_tn_slabs_override = 0;
+static int dw_slabs(int tiles, int steps) {
+  if (g_tn_slabs_override > 0) return g_tn_slabs_override <= steps / 2 ? g_tn_slabs_override : (steps / 2 > 0 ? steps / 2 : 1);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    (void)hipGetLastError();
+  }
+  const int tiles8 = (tiles + 7) / 8 * 8;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int S = 1; S <= 16 && S <= steps / 2; ++S) {
+    const int rounds = ((DW_MAP == 1 ? tiles : tiles8) * S + cus - 1) / cus;
+    const double cost = rounds * ((steps + S - 1) / S + (S > 1 ? 8.0 : 2.0));
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+  }
+  return best;
+}
+
+int octic_dbg_dense_wgrad_slabs(int S) {      // developer knob: force the number of row slabs (0 = automatic)
+  const int old = g_tn_slabs_override;
+  g_tn_slabs_override = S;
+  return old;
 }
 
 int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K) {
   const int tiles = (N / DW_T) * (K / DW_T);
-  const int G = dw_grid((int64_t)tiles * ((M + DW_BR - 1) / DW_BR));
-  (void)tiles;
-  return (int64_t)2 * G * (DW_T * DW_T) * 4 + 4096;      // [4 KiB tickets (<= 256 tiles) | slabs]
+  const int steps = (M + DW_BR - 1) / DW_BR;
+  const int S = g_tn_slabs_override > 0 ? 16 : dw_slabs(tiles, steps);      // room for any forced value
+  return (int64_t)tiles * S * (DW_T * DW_T) * 4 + 4096;      // [4 KiB tickets (<= 1024 tiles) | slabs]
 }
 
 int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
                          void* workspace, void* stream) {
   if (!dY || !X || !dW || !workspace) return OCTIC_ENULL;
   if (M <= 0 || N <= 0 || K <= 0 || (N % DW_T) || (K % DW_T) || (ldy % 8) || (ldx % 8)) return OCTIC_ESHAPE;
-  if ((N / DW_T) * (K / DW_T) > 256) return OCTIC_ESHAPE;     // a workgroup's range must touch at most two tiles
+  if ((N / DW_T) * (K / DW_T) > 1024) return OCTIC_ESHAPE;    // ticket region
+  if ((int64_t)M * ldy * 2 >= (1ll << 31) || (int64_t)M * ldx * 2 >= (1ll << 31)) return OCTIC_ESHAPE;   // 32-bit buffer offsets
   if ((((uintptr_t)dY) | ((uintptr_t)X) | ((uintptr_t)dW)) & 15) return OCTIC_EALIGN;
   DwArgs a = {};
   a.Y = (const bf16*)dY; a.X = (const bf16*)X; a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
   a.W = dW;
   a.tiles_k = K / DW_T;
   a.tiles = (N / DW_T) * a.tiles_k;
+  a.tiles8 = (a.tiles + 7) / 8 * 8;
   a.steps = (M + DW_BR - 1) / DW_BR;
-  const int G = dw_grid((int64_t)a.tiles * a.steps);
+  a.S = dw_slabs(a.tiles, a.steps);
   a.tickets = (int*)workspace;
   char* p = (char*)workspace + 4096;         // fixed ticket region: a workspace shared by several shapes keeps its zeros
   a.slabs = (float*)p;
@@ -398,7 +450,11 @@ int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int
     (void)hipGetLastError();
     attr_done = true;
   }
-  dense_tn_kernel<<<G, 512, smem, s>>>(a);
+#if DW_MAP == 1
+  dense_tn_kernel<<<(a.tiles * a.S + 255) / 256 * 256, 512, smem, s>>>(a);
+#else
+  dense_tn_kernel<<<a.tiles8 * a.S, 512, smem, s>>>(a);
+#endif
   return launch_status();
 }
 

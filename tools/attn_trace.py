@@ -54,6 +54,9 @@ for kern, label in ((0, "fwd"), (1, "dq"), (2, "dkv")):
             nz = np.nonzero(t)[0].max()
             rows.append([t[i + 1] - t[i] if i + 1 <= nz else 0 for i in range(len(names[kern]))] + [t[nz] - t[0]])
     rows = np.array(rows)
+    if rows.ndim != 2:
+        print(f"{label}: no waves traced")
+        continue
     print(f"{label}: {len(rows)} waves; mean cycles per phase:")
     for i, nm in enumerate(names[kern]):
         print(f"   {nm:14s} {rows[:, i].mean():9.0f}")
