@@ -1,8 +1,9 @@
-// Persistent softmax-attention kernels for head_dim 80 and T <= 288 tokens (ViT-H/14 at 224x224: T = 257), bf16.
-// Forward and backward of AttentionD8's core on packed LinearD8 rows (reference octic_vits/d8_layers.py:631-656) and of
-// the standard block's fused [B,T,3,H,hd] projection (deit/vit.py:38-45).  Same math and MFMA formulation as
-// csrc/attention.hip (swapped score product, P / dS straight from accumulator registers, transposing LDS reads); what
-// is new is how the operands reach the CU.
+// Persistent softmax-attention FORWARD for head_dim 80 and T <= 288 tokens (ViT-H/14 at 224x224: T = 257), bf16:
+// AttentionD8's core on packed LinearD8 rows (reference octic_vits/d8_layers.py:631-656) and the standard block's fused
+// [B,T,3,H,hd] projection (deit/vit.py:38-45).  Same MFMA formulation as csrc/attention.hip (swapped score product, P
+// straight from accumulator registers, transposing LDS reads); new: how the operands reach the CU, and the softmax.
+// (The backward stays on csrc/attention.hip: persistent dq / dkv kernels on the same tile rings were built and only
+// tied the round-2 kernels - DESIGN.md section 3.3 has the measurements and the reason.)
 //
 // The s_memtime timelines of the round-2 kernels (tools/attn_trace.py, cycles per head and wave at (64,16,257,80)):
 // dq 48k of which 24k staging (71k / 43k on packed rows), dkv 57k / 21k (76k / 31k), forward 34k / 5.5k + 3k + 5k of
@@ -195,14 +196,15 @@ struct LeanStager {
       }
     }
   }
-  // rows of `tile` of one image -> the tile slot of the same index in the image buffer at LDS address `img`
-  __device__ __forceinline__ void issue(int tile, unsigned img, const i32x4 rs, int bs) const {
+  // rows of `tile` of one image -> tile slot `slot` (default: the same index) of the image buffer at LDS address `img`
+  __device__ __forceinline__ void issue(int tile, unsigned img, const i32x4 rs, int bs, int slot = -1) const {
+    if (slot < 0) slot = tile;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (!on[s]) continue;
       unsigned v = vo[s] + (unsigned)(hmul[s] * bs) + (unsigned)(tile * tstride);
       if (tile == nt - 1 && vrow[s] >= rows_last) v = OOR;
-      const unsigned dst = img + tile * TILE_B + ldsoff[s];
+      const unsigned dst = img + slot * TILE_B + ldsoff[s];
       if (kind[s] == 2) dma4(dst, v, rs); else dma16(dst, v, rs);
     }
   }
@@ -269,6 +271,7 @@ __device__ __forceinline__ void xrow_frags(bf16x8 (&f)[KS], const char* xr, int 
 // 8 g + 4 half .. + 3 of group g; exchanging halves between the two half-waves (v_permlane32_swap) gives lanes 0-31
 // the whole even group and lanes 32-63 the whole odd group of a pair: one 16-byte store per lane and pair.
 __device__ __forceinline__ void store_rows16(bf16* row, const f32x16 (&acc)[DT], float f, int half, const HeadMap m) {
+  asm volatile("" : "+v"(half));                    // keep the piece offsets out of the persistent loop's preheader
 #pragma unroll
   for (int pr = 0; pr < 5; ++pr) {                  // groups (2 pr, 2 pr + 1)
     u32x2 a, b;
