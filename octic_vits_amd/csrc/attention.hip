@@ -317,7 +317,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(AttnArgs a, int rsk, int
     const int qi = wid * 32 + r;
     if (qi < T) {
       if (half == 0 && lseb) lseb[qi] = m + log2f(l);
-      store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half, hm.o);
+      store_rows_wide<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half, hm.o);
     }
   }
   ATRACE(0, 4);
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
       const int qi = wid * 32 + r;
       if (qi < T) {
         if (half == 0 && lseb) lseb[qi] = m + log2f(l);
-        store_rows<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half, hm.o);
+        store_rows_wide<DT>(ob + (int64_t)qi * a.oT, ot, 1.0f / l, hd, half, hm.o);
       }
     }
     if (has_next) load_rows8<KS>(qf, a.q + n_in, a.sT, wid, T, lane, nhm.q);
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   zero_acc<DT>(dqt);
   dq_pass<KS, DT>(a, Ks, Vs, rs, mine, 0, 1, nt, lane, dqt);
   ATRACE(1, 3);
-  if (wid * 32 + r < T) store_rows<DT>(dqb + (int64_t)(wid * 32 + r) * a.gT, dqt, a.scale, hd, half, hm.q);
+  if (wid * 32 + r < T) store_rows_wide<DT>(dqb + (int64_t)(wid * 32 + r) * a.gT, dqt, a.scale, hd, half, hm.q);
   ATRACE(1, 4);
   if (nt == W) return;
 
@@ -882,8 +882,8 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   dkv_pass<KS, DT>(a, Qs, Ds, lse_s, del_s, rs, kv, 0, 1, nt, lane, dkt, dvt);
   ATRACE(2, 3);
   if (wid * 32 + r < T) {
-    store_rows<DT>(dkb + (int64_t)(wid * 32 + r) * a.gT, dkt, a.scale, hd, half, hm.k);
-    store_rows<DT>(dvb + (int64_t)(wid * 32 + r) * a.gT, dvt, 1.0f, hd, half, hm.v);
+    store_rows_wide<DT>(dkb + (int64_t)(wid * 32 + r) * a.gT, dkt, a.scale, hd, half, hm.k);
+    store_rows_wide<DT>(dvb + (int64_t)(wid * 32 + r) * a.gT, dvt, 1.0f, hd, half, hm.v);
   }
   ATRACE(2, 4);
   if (nt == W) return;

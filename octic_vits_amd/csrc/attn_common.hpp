@@ -153,6 +153,34 @@ __device__ __forceinline__ void store_rows(bf16* row, const f32x16 (&acc)[DT], f
     }
 }
 
+// 16-byte row stores (head_dim % 16 == 0): a lane holds elements 8 g + 4 half .. + 3 of group g; exchanging halves
+// between the two half-waves (v_permlane32_swap) gives lanes 0-31 the whole even group and lanes 32-63 the whole odd
+// group of a pair - one 16-byte store per lane and pair instead of two 8-byte ones (the store tail of these kernels is
+// bound by the number of store instructions, not by bytes: MI355X guide, T21).
+template <int DT>
+__device__ __forceinline__ void store_rows_wide(bf16* row, const f32x16 (&acc)[DT], float f, int hd, int half,
+                                                const HeadMap m = HeadMap{0, 0}) {
+#pragma unroll
+  for (int pr = 0; pr < DT * 2; ++pr) {                // groups (2 pr, 2 pr + 1)
+    if (pr * 16 < hd) {
+      u32x2 a, b;
+      {
+        const int g = 2 * pr, d = g >> 2, k4 = g & 3;
+        const bf16x4 v = {(bf16)(acc[d][4 * k4] * f), (bf16)(acc[d][4 * k4 + 1] * f), (bf16)(acc[d][4 * k4 + 2] * f), (bf16)(acc[d][4 * k4 + 3] * f)};
+        a = __builtin_bit_cast(u32x2, v);
+      }
+      {
+        const int g = 2 * pr + 1, d = g >> 2, k4 = g & 3;
+        const bf16x4 v = {(bf16)(acc[d][4 * k4] * f), (bf16)(acc[d][4 * k4 + 1] * f), (bf16)(acc[d][4 * k4 + 2] * f), (bf16)(acc[d][4 * k4 + 3] * f)};
+        b = __builtin_bit_cast(u32x2, v);
+      }
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);   // lanes 32-63 of a <-> lanes 0-31 of b
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+      hm_store16(row, 2 * pr + half, u32x4{r0[0], r1[0], r0[1], r1[1]}, m);
+    }
+  }
+}
+
 template <int DT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[DT]) {
 #pragma unroll
