@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 2
+#define OCTIC_ABI_VERSION 3
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -288,19 +288,6 @@ int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const f
 int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, void* stream);
 
-/* ---- LinearD8 fused with the D8 GELU (MlpD8: fc1 -> act, octic_vits/d8_layers.py:215-247; act = TritonGeluD8,
- * octic_vits/d8_gelu.py:104-331,456-482) -------------------------------------------------------------------------
- * mode 0 (forward) : h = x W^T (+ bias on A1), y = F(gelu(F^-1 h)) per hidden channel; writes h (the pre-activation the
- *                    backward needs, d8_gelu.py:469) and y.
- * mode 1 (backward): g = x W^T with x the cotangent of fc2's output and W fc2's transposed (layer-scale-folded) weights
- *                    (octic_linear_d8_prep's wt) = the input gradient of fc2; y := F(gelu'(F^-1 h) * F^-1 g), the
- *                    gradient w.r.t. h (d8_gelu.py:283-321).  h is read.
- * x packed [M, 8 cin], h / y packed [M, 8 cout], all bf16 and contiguous; w_flat = the five matrices in the prepared
- * layout [4 x (cout x cin) | (2 cout x 2 cin)]; bias f32 [cout] or NULL.  cin in {128, 160} (ViT-L / ViT-H), cout % 16 == 0.
- * GELU is evaluated on the bf16-rounded h (as the separate kernels do) with erf by Abramowitz-Stegun 7.1.26 (1.5e-7). */
-int octic_mlp_d8_gelu(const void* x, const void* w_flat, const float* bias, void* h, void* y, int64_t M, int cin,
-                      int cout, int mode, void* stream);
-
 /* bf16 operand copies of nn.Linear weights [N,K] for octic_dense_gemm_nt, all layers in one launch (what autocast's
  * per-use weight casts amount to, deit/engine.py:56): wb = bf16(src) [N,K] (may be NULL) and wt = bf16(src)^T [K,N]
  * (the input-gradient GEMM dX = dY W is then an NT problem too).  src is the f32 master or an existing bf16 copy
@@ -333,17 +320,6 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs,
                         int64_t rows_per_sample, const float* X, float* OUT, const void* H, void* workspace,
                         void* stream);
-
-/* Weight gradient of an nn.Linear of the standard half (the autograd of deit/vit.py:33,46 and of timm Mlp.fc1 / fc2):
- *     dW[N,K] = dY[M,N]^T . X[M,K]     f32, nn.Linear layout
- * dY, X bf16 row-major (ldy, ldx row strides in elements), N % 256 == 0, K % 256 == 0, (N/256)(K/256) <= 1024,
- * M * ld * 2 < 2^31.  The reduction over the M token rows is cut into row slabs (one workgroup per slab and 256 x 256
- * tile, all tiles of a slab walking the same rows in lockstep); the f32 partial tiles are summed in slab order by the
- * last workgroup of a tile (bitwise reproducible).  workspace: octic_dense_wgrad_workspace_bytes(M,N,K) bytes, zeroed
- * once at allocation.                                                                                                 */
-int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K);
-int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
-                         void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

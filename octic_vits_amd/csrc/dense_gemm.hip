@@ -622,6 +622,9 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
                         const float* X, float* OUT, const void* H, void* workspace, void* stream) {
   if (!A || !B || !C) return OCTIC_ENULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % DG_BK) || K < 2 * DG_BK || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 4)) return OCTIC_ESHAPE;
+  // buffer descriptors and per-lane offsets are 32-bit: operands of 2 GiB or more are refused (callers fall back to
+  // the BLAS library) instead of wrapping
+  if ((int64_t)M * lda * 2 >= (1ll << 31) || (int64_t)N * ldb * 2 >= (1ll << 31)) return OCTIC_ESHAPE;
   if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return OCTIC_EALIGN;
   if (mode == DG_GELU && !C2) return OCTIC_ENULL;
   if (mode == DG_RESID && (!X || !OUT || (rs && rps <= 0))) return OCTIC_ENULL;

@@ -607,8 +607,10 @@ DENSE_HIP = {"qkv", "dqkv", "fc1"}          # subset of {"qkv", "dqkv", "proj", 
 def dense_hip_ok(x, w, which=None):
     """bf16 autocast on the GPU, a shape csrc/dense_gemm.hip covers in BOTH directions (forward: K = in_features,
     input gradient: K = out_features; the kernel needs K % 64 == 0, K >= 128, N % 8 == 0) and routed."""
+    rows = x.numel() // max(1, x.shape[-1])
     return ((which is None or which in DENSE_HIP) and x.is_cuda and w.shape[1] % 64 == 0 and w.shape[1] >= 128
-            and w.shape[0] % 64 == 0 and w.shape[0] >= 128)
+            and w.shape[0] % 64 == 0 and w.shape[0] >= 128
+            and rows * max(w.shape) * 2 < 2 ** 31)          # 32-bit buffer offsets in the kernel (it refuses larger operands)
 
 
 def _f32(t):

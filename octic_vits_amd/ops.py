@@ -574,10 +574,6 @@ def _dense_ws(M, N, K, dev):
     return ws
 
 
-def dense_gemm_ok(M, N, K):
-    return K % 128 == 0 and N % 4 == 0 and M > 0
-
-
 def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None):
     """C[M,N] = a[M,K] @ b[N,K]^T on the hand-written MFMA kernel (csrc/dense_gemm.hip) with a fused tail:
     mode 0 -> c ; 1 -> (c, gelu(c)) ; 2 -> (c, x + rs*gamma*c) ; 3 -> gelu'(h) * c.  a, b bf16 2-D, K contiguous."""
@@ -601,49 +597,3 @@ def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h
     if mode == 2:
         return c, out
     return c
-
-
-_DW_WS = {}
-
-
-def dense_wgrad_ok(M, N, K):
-    return N % 256 == 0 and K % 256 == 0 and (N // 256) * (K // 256) <= 256 and M > 0
-
-
-def dense_wgrad_tn(dy, x, name=None):
-    """dW[N,K] = dy[M,N]^T @ x[M,K] in f32 on csrc/dense_wgrad.hip."""
-    _require_cuda(dy)
-    M, N = dy.shape
-    K = x.shape[1]
-    if dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != M:
-        raise ValueError("dense_wgrad_tn: operands must be [M,N] / [M,K] row-major")
-    need = int(lib().octic_dense_wgrad_workspace_bytes(M, N, K))
-    ws = _DW_WS.get(dy.device)
-    if ws is None or ws.numel() < need:          # one workspace per device: launches on a stream are serial
-        ws = _DW_WS[dy.device] = torch.zeros(need, dtype=torch.uint8, device=dy.device)
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-    t = KERNEL_TIMER.start()
-    check(lib().octic_dense_wgrad_tn(_p(dy), _p(x), M, N, K, dy.stride(0), x.stride(0), _p(dw), _p(ws), _stream(dy)))
-    KERNEL_TIMER.stop(t, name or f"dense_tn_kernel<{N}x{K}>", 2 * (M * N + M * K) + 4 * N * K, 2.0 * M * N * K)
-    return dw
-
-
-# ------------------------------------------------------------------------------------------ fused MlpD8 front half
-def mlp_d8_gelu_ok(cin, cout, dtype):
-    return dtype == torch.bfloat16 and cin in (128, 160) and cout % 16 == 0
-
-
-def mlp_d8_gelu(x, w_flat, bias, cin, cout, mode, h=None):
-    """mode 0: (h, y) = (fc1(x), gelu_D8(h)); mode 1: dh = gelu_D8'(h; x W^T).  x packed [.., 8 cin] bf16, w_flat the flat
-    prepared weight buffer (wb of fc1 / wt of fc2), see octic_mlp_d8_gelu."""
-    _require_cuda(x)
-    M = x.numel() // (8 * cin)
-    out_shape = x.shape[:-1] + (8 * cout,)
-    y = torch.empty(out_shape, dtype=torch.bfloat16, device=x.device)
-    if mode == 0:
-        h = torch.empty(out_shape, dtype=torch.bfloat16, device=x.device)
-    t = KERNEL_TIMER.start()
-    check(lib().octic_mlp_d8_gelu(_p(x), _p(w_flat), _p(bias), _p(h), _p(y), M, cin, cout, mode, _stream(x)))
-    KERNEL_TIMER.stop(t, f"mlp_d8_gelu_kernel<{'bwd' if mode else 'fwd'}>", 2 * M * 8 * (cin + 2 * cout) + 16 * cin * cout,
-                      24.0 * M * cin * cout)
-    return (h, y) if mode == 0 else y

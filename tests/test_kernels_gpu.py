@@ -347,50 +347,3 @@ def test_lift_gemm_matches_patch_embed(p, G, D, dtype):
     dw = o.lift_wgrad(patches, dout.to(DEV), Kpad, D)
     ref = dout.double().t() @ patches.double().cpu()
     close(dw, ref, 1e-4, 1e-4, "lift wgrad")
-
-
-# ------------------------------------------------------------------------------- fused fc1 + D8-GELU (and its backward)
-@pytest.mark.parametrize("B,T,cin,cout", [(2, 17, 128, 64), (3, 50, 160, 640), (2, 257, 160, 640), (1, 70, 128, 512)])
-def test_mlp_d8_gelu_fused_matches_separate_kernels_and_oracle(B, T, cin, cout):
-    """octic_mlp_d8_gelu (channel-sliced GEMM with the 8-component butterflies + GELU in registers) against (a) the
-    separate HIP kernels it replaces (irrep GEMM, then D8-GELU forward / backward): h identical up to accumulation order,
-    y / dh within 1 bf16 ulp-ish (erf approximation 1.5e-7); (b) the fp64 oracle on the same bf16 operands, 2e-2."""
-    o = ops()
-    dt = torch.bfloat16
-    xs = rand5("gg.x", B, T, cin, dt)
-    lin = cases.fill_parameters(R.LinearD8(8 * cin, 8 * cout, bias=True), salt="gg")
-    names = ("A1", "A2", "B1", "B2", "E")
-    W32 = [getattr(lin, "lin_" + n).weight.detach().to(DEV).contiguous() for n in names]
-    bias = lin.lin_A1.bias.detach().float().to(DEV)
-    wb, wt = o.linear_prep(W32, None, cin, cout, dt)
-    x = pack(xs).to(DEV)
-    M = B * T
-    # (a) forward vs separate kernels
-    h_ref = torch.empty((B, T, 8 * cout), dtype=dt, device=DEV)
-    o.linear_fwd(o.pview(x, cin), wb, bias, o.pview(h_ref, cout), M, cin, cout, dt, dt, x)
-    y_ref = torch.empty_like(h_ref)
-    o.gelu_fwd(o.pview(h_ref, cout), o.pview(y_ref, cout), M, cout, dt, h_ref)
-    h, y = o.mlp_d8_gelu(x, wb[0], bias, cin, cout, 0)
-    close(h, h_ref, 1e-2, 1e-2, "fused h vs separate GEMM")
-    # GELU of the SAME h: evaluate the separate kernel on the fused h for an apples-to-apples comparison
-    y_same = torch.empty_like(h)
-    o.gelu_fwd(o.pview(h, cout), o.pview(y_same, cout), M, cout, dt, h)
-    close(y, y_same, 1e-2, 1e-2, "fused y vs D8-GELU kernel on the same h")
-    # (b) forward vs oracle (fp64 on the bf16 operands)
-    xr = [t.double() for t in xs]
-    hr = _linear_ref(xr, [w.to(dt).double().cpu() for w in W32], bias.double().cpu())
-    yr = R.TritonGeluD8()(tuple(hr))
-    close(h, pack(hr), 2e-2, 2e-2, "fused h vs oracle")
-    close(y, pack(yr), 2e-2, 2e-2, "fused y vs oracle")
-    # backward: g = dy @ W2 with W2 : LinearD8(8 cout -> 8 cin'), here cin' = cin; dh = gelu'(h) (.) g
-    lin2 = cases.fill_parameters(R.LinearD8(8 * cout, 8 * cin, bias=False), salt="gg2")
-    W2 = [getattr(lin2, "lin_" + n).weight.detach().to(DEV).contiguous() for n in names]
-    _, w2t = o.linear_prep(W2, None, cout, cin, dt)            # transposed: five [cout, cin]-shaped blocks
-    dys = rand5("gg.dy", B, T, cin, dt)
-    dy = pack(dys).to(DEV)
-    g_ref = torch.empty((B, T, 8 * cout), dtype=dt, device=DEV)
-    o.linear_fwd(o.pview(dy, cin), w2t, None, o.pview(g_ref, cout), M, cin, cout, dt, dt, dy)
-    dh_ref = torch.empty_like(g_ref)
-    o.gelu_bwd(o.pview(g_ref, cout), o.pview(h, cout), o.pview(dh_ref, cout), M, cout, dt, h)
-    dh = o.mlp_d8_gelu(dy, w2t[0], None, cin, cout, 1, h=h)
-    close(dh, dh_ref, 1e-2, 1e-2, "fused dh vs separate dgrad + D8-GELU backward")

@@ -29,11 +29,3 @@ print("fc2 resid mode", timeit(lambda: ops.dense_gemm_nt(a, b, 2, bias=g, gamma=
 a = torch.randn(M, 1280, device="cuda").to(torch.bfloat16); b = (torch.randn(5120, 1280, device="cuda") / 36).to(torch.bfloat16)
 g5 = torch.rand(5120, device="cuda")
 print("fc1 gelu mode", timeit(lambda: ops.dense_gemm_nt(a, b, 1, bias=g5)))
-print("--- wgrad (TN) ---")
-for (N, K) in [(5120, 1280), (1280, 5120), (3840, 1280), (1280, 1280)]:
-    dy = torch.randn(M, N, device="cuda").to(torch.bfloat16)
-    xx = torch.randn(M, K, device="cuda").to(torch.bfloat16)
-    t_mine = timeit(lambda: ops.dense_wgrad_tn(dy, xx))
-    t_lib = timeit(lambda: (dy.t() @ xx).float())
-    fl = 2.0 * M * N * K
-    print(f"dW {N:5d}x{K:5d}: mine {t_mine:7.1f} us {fl / t_mine / 1e6:7.1f} TF | lib(+cast) {t_lib:7.1f} us {fl / t_lib / 1e6:7.1f} TF", flush=True)
