@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
 // L2->CU traffic for fc1: 42 MB (X once) + 316 MB (W per 128-row block) = 358 MB.
 // ================================================================================================
 #ifndef OCTIC_XREG_ABL
-#define OCTIC_XREG_ABL 0   // developer ablation builds (tools/xreg_variants.py): 1 no W DMA, 2 no global stores, 4 no MFMAs
+#define OCTIC_XREG_ABL 0   // developer ablation builds (tools/xreg_variants.py): 1 no W DMA, 2 no global stores, 4 no MFMAs, 8 no X loads
 #endif
 constexpr int kXStage = kRingBN * 128;   // one W tile: 80 rows x 128 B
 constexpr int kXS = 3;                   // ring depth (5 measured no faster)
@@ -669,8 +669,13 @@ __global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
     const int64_t off = G.pair ? (mm >> 1) * G.a_ld + (mm & 1) * (int64_t)K : mm * G.a_ld;
     const bf16* xr = (const bf16*)G.a + off + kg * 8;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)          // unconditional: k-steps a group does not have re-read its step 0
-      xf[ks][j] = *(const bf16x8*)(xr + (ks < ksteps ? ks : 0) * 32);
+    for (int ks = 0; ks < KSTEPS; ++ks) {        // unconditional: k-steps a group does not have re-read its step 0
+      if constexpr (OCTIC_XREG_ABL & 8) {        // ablation: no X loads (operands = lane pattern)
+        xf[ks][j] = bf16x8{(bf16)1.f, (bf16)0.5f, (bf16)0.25f, (bf16)0.f, (bf16)1.f, (bf16)0.5f, (bf16)0.25f, (bf16)0.f};
+        asm volatile("" :: "v"(xr));
+      } else
+        xf[ks][j] = *(const bf16x8*)(xr + (ks < ksteps ? ks : 0) * 32);
+    }
   }
   // The X registers are re-defined by an empty asm once their loads have landed.  hipcc's waitcnt pass tracks
   // pending VMEM results per register and cannot see that loads issued before a loop are complete after its first

@@ -18,7 +18,7 @@ NAMES = [
     (r"linear_d8_ring_kernel(IDF16bDF16bLi0E|<__bf16, __bf16, 0)", "linear_d8_ring_kernel<bf16,bf16,0>"),
     (r"linear_d8_ring_kernel(IDF16bfLi1E|<__bf16, float, 1|<bool _Accum, 1)", "linear_d8_ring_kernel<bf16,f32,1>"),
     (r"wgrad_ring_kernel", "wgrad_ring_kernel<bf16>"),
-    (r"attn_fwd(_persist)?_kernel", "attn_fwd_kernel"),
+    (r"attn_fwd(_persist)?_kernel|a80.{0,4}fwd(_os)?_kernel|fwd_os_kernel", "attn_fwd_kernel"),
     (r"dense_nt_kernel(ILi0E|<0>)", "dense_nt_kernel<0>"),
     (r"dense_nt_kernel(ILi1E|<1>)", "dense_nt_kernel<1>"),
     (r"heads_permute_kernel", "heads_permute_kernel<bf16>"),
@@ -33,8 +33,9 @@ NAMES = [
     (r"scale_residual_fwd_kernel", "scale_residual_fwd_kernel<bf16>"),
     (r"scale_residual_bwd_kernel", "scale_residual_bwd_kernel<bf16>"),
     (r"dense_gelu_bwd_kernel", "dense_gelu_bwd_kernel"),
-    (r"gelu_fwd_kernel", "gelu_fwd_kernel<bf16>"),
-    (r"gelu_bwd_kernel", "gelu_bwd_kernel<bf16>"),
+    (r"gelu_fwd4?_kernel", "gelu_fwd_kernel<bf16>"),
+    (r"gelu_bwd4?_kernel", "gelu_bwd_kernel<bf16>"),
+    (r"Cijk_.*MT256x256x32", "library_gemm<wgrad, all shapes>"),
     (r"cast_rowscale_kernel", "cast_rowscale_kernel<bf16>"),
 ]
 

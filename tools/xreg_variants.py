@@ -3,7 +3,7 @@
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "octic_vits_amd", "csrc")
-outdir = os.path.join(ROOT, "gpurun_out", "variants")
+outdir = os.path.join(ROOT, "tools", "micro", "variants")
 os.makedirs(outdir, exist_ok=True)
 objs = [os.path.join(CS, "build", f) for f in os.listdir(os.path.join(CS, "build")) if f.endswith(".o") and f != "gemm.o"]
 rounds = int(os.environ.get("ROUNDS", "2"))
