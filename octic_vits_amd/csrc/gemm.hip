@@ -14,38 +14,9 @@
 // bf16: v_mfma_f32_16x16x32_bf16.  f32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain) for the
 // reference's fp32 tolerances.
 #include <stdlib.h>
-#include "octic_common.hpp"
+#include "gemm_args.hpp"
 
 namespace octic {
-
-struct GemmGroup {
-  const char* a;      // A rows
-  int64_t a_ld;       // row stride (elements)
-  const char* w;      // [N, K] row-major
-  char* y;
-  int64_t y_ld;
-  const char* resid;  // optional (same addressing as y unless lift)
-  int64_t r_ld;
-  const float* bias;  // optional [N]
-  const float* cs;    // optional [N]
-  int64_t rows;       // M (or 2M for the E pair group)
-  int K, N;
-  int pair;           // 1: row mm -> token mm>>1, half mm&1 (adjacent halves of width K / N)
-  int n_tiles, m_tiles;
-  int chunk, n_chunks;  // n-tiles walked by one block, number of such chunks
-  int tile_begin;     // first linear work-item id of this group
-};
-
-struct GemmArgs {
-  GemmGroup g[5];
-  int ngroups;
-  int total_tiles;
-  const float* rs;   // optional per-sample scale
-  int64_t rps;       // token rows per sample for rs
-  // lift mode: output row = (row / lift_np) * (lift_np + lift_tok0) + lift_tok0 + row % lift_np ; resid row = row % lift_np
-  int64_t lift_np;
-  int lift_tok0;
-};
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPC = 4; typedef f32x4 frag; };
@@ -1020,6 +991,8 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
 
 inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
   if (dtype == OCTIC_BF16) {
+    const int rw = launch_wreg(a, out_dtype, s);
+    if (rw != -100) return rw;
     const int r = out_dtype == OCTIC_BF16 ? launch_xreg<bf16>(a, s) : (out_dtype == OCTIC_F32 ? launch_xreg<float>(a, s) : -100);
     if (r != -100) return r;
   }

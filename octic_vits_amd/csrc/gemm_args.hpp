@@ -1,0 +1,40 @@
+// Argument block shared by the LinearD8 GEMM kernels (gemm.hip, gemm_wreg.hip).
+#pragma once
+#include "octic_common.hpp"
+
+namespace octic {
+
+struct GemmGroup {
+  const char* a;      // A rows
+  int64_t a_ld;       // row stride (elements)
+  const char* w;      // [N, K] row-major
+  char* y;
+  int64_t y_ld;
+  const char* resid;  // optional (same addressing as y unless lift)
+  int64_t r_ld;
+  const float* bias;  // optional [N]
+  const float* cs;    // optional [N]
+  int64_t rows;       // M (or 2M for the E pair group)
+  int K, N;
+  int pair;           // 1: row mm -> token mm>>1, half mm&1 (adjacent halves of width K / N)
+  int n_tiles, m_tiles;
+  int chunk, n_chunks;  // n-tiles walked by one block, number of such chunks
+  int tile_begin;     // first linear work-item id of this group
+  int wgs;            // W-stationary kernel: workgroups that share one column chunk's rows
+};
+
+struct GemmArgs {
+  GemmGroup g[5];
+  int ngroups;
+  int total_tiles;
+  const float* rs;   // optional per-sample scale
+  int64_t rps;       // token rows per sample for rs
+  // lift mode: output row = (row / lift_np) * (lift_np + lift_tok0) + lift_tok0 + row % lift_np ; resid row = row % lift_np
+  int64_t lift_np;
+  int lift_tok0;
+};
+
+// W-stationary streaming kernel (gemm_wreg.hip); returns -100 when the problem does not qualify.
+int launch_wreg(GemmArgs& a, int out_dtype, hipStream_t s);
+
+}  // namespace octic
