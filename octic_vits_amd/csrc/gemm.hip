@@ -525,361 +525,6 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
   }
 }
 
-// ================================================================================================
-// X-stationary variant for the short-K problems (K = 32*KSTEPS <= 320: qkv, proj, fc1 and the input gradient of
-// fc2 at ViT-H) — bf16 only.  Measured motivation: with a 128x80 tile the ring kernel pulls 877 MB through the
-// L1s for a 210 MB (fc1) problem, 560 MB of it X k-tiles re-read once per 80-column n-tile; L2->CU delivers
-// ~70 GB/s per CU, so operand re-fetch, not HBM, bounds it.  Here every wave loads the MFMA operand fragments
-// of ITS 32 token rows for the whole K once (<= 80 VGPRs) and keeps them while the workgroup walks all its
-// n-tiles; only W tiles [80 x 64k] stream through a 3-stage LDS-DMA ring (30 KiB LDS -> 3 workgroups per CU).
-// L2->CU traffic for fc1: 42 MB (X once) + 316 MB (W per 128-row block) = 358 MB.
-// ================================================================================================
-#ifndef OCTIC_XREG_ABL
-#define OCTIC_XREG_ABL 0   // developer ablation builds (tools/xreg_variants.py): 1 no W DMA, 2 no global stores, 4 no MFMAs, 8 no X loads
-#endif
-constexpr int kXStage = kRingBN * 128;   // one W tile: 80 rows x 128 B
-constexpr int kXS = 3;                   // ring depth (5 measured no faster)
-
-#ifdef OCTIC_XREG_TRACE
-// developer-only timeline (build with -DOCTIC_XREG_TRACE): s_memtime stamps of the first 256 workgroups
-__device__ unsigned long long g_xreg_trace[256 * 4 * 64];
-extern "C" void* octic_dbg_xreg_trace(void) {
-  void* p = nullptr;
-  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_xreg_trace));
-  return p;
-}
-#define XTRACE(slot)                                                                                   \
-  do {                                                                                                 \
-    if (tile < 256 && lane == 0 && (slot) < 64) g_xreg_trace[(tile * 4 + wid) * 64 + (slot)] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define XTRACE(slot) do {} while (0)
-#endif
-
-template <typename TOUT, int EPI, int KSTEPS>
-__global__ __launch_bounds__(256, 3) void linear_d8_xreg_kernel(GemmArgs args) {
-  constexpr int NT = 5, MT = 2;
-  constexpr int NKT = (KSTEPS + 1) / 2;      // 64-wide W tiles per n-tile
-  // epilogue staging: a wave writes 16 rows x 80 columns of results into its private LDS tile in the MFMA layout and
-  // reads it back row-wise, so a global store instruction writes 16 bytes per lane along rows (6.4 row segments of
-  // 80 columns per instruction) instead of 16 rows x 4 columns: the s_memtime timeline showed ~5000 cycles per
-  // n-tile epilogue with the direct stores (address-path bound: 16 partial lines per instruction).
-  constexpr int EPV = 16 / (int)sizeof(TOUT);            // elements per 16-byte chunk
-  constexpr int CPR = kRingBN / EPV;                     // chunks per staged row
-  constexpr int SRS = kRingBN * (int)sizeof(TOUT) + 16;  // staged row stride (bytes): conflict-free both ways
-  constexpr int SCH = (16 * CPR + 63) / 64;              // store instructions per 16-row half
-  constexpr int NSTORE = sizeof(TOUT) == 2 ? SCH * MT : NT * MT;
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // kXS stages x 80 rows x 128 B | 4 x staging tile
-
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  int gi = 0;
-#pragma unroll
-  for (int i = 1; i < 5; ++i)
-    if (i < args.ngroups && tile >= args.g[i].tile_begin) gi = i;
-  const GemmGroup& G = args.g[gi];
-  const int lt = tile - G.tile_begin;
-  const int mt = lt / G.n_chunks, nc = lt - mt * G.n_chunks;
-  const int64_t m0 = (int64_t)mt * kBM;
-  const int nt_begin = nc * G.chunk;
-  const int nt_count = (G.n_tiles - nt_begin) < G.chunk ? (G.n_tiles - nt_begin) : G.chunk;
-  const int K = G.K, N = G.N;
-  const int ksteps = K >> 5;                 // 32-wide MFMA k-steps of THIS group (<= KSTEPS; E has twice the 1-D count)
-  const int nkt = (ksteps + 1) >> 1;         // 64-wide W tiles per n-tile
-  const int steps = nt_count * nkt;
-
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int fr = lane & 15, kg = lane >> 4;
-  XTRACE(0);
-
-  // ---- W DMA sources (as in the ring kernel): 10 wave-instructions per tile, waves 0,1 take 3, waves 2,3 take 2
-  const int drow = lane >> 3;
-  const int dkc = (lane & 7) ^ drow;
-  const int w_first = wid < 2 ? wid * 3 : 6 + (wid - 2) * 2;
-  const int w_cnt = wid < 2 ? 3 : 2;
-  const char* wsrc[3];
-  auto set_w = [&](int nt) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      int n = nt * kRingBN + (w_first + q) * 8 + drow;
-      n = n < N ? n : N - 1;
-      wsrc[q] = G.w + (int64_t)n * K * 2;
-    }
-  };
-  int l_nt = nt_begin, l_kt = 0, l_stage = 0;
-  set_w(l_nt);
-  auto issue = [&]() {
-    int k = l_kt * 64 + dkc * 8;
-    k = k < K ? k : 0;
-    char* st = lds + l_stage * kXStage;
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (q < w_cnt && !(OCTIC_XREG_ABL & 1))
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + k * 2),
-                                         (__attribute__((address_space(3))) void*)(st + (w_first + q) * 1024), 16, 0, 0);
-    l_stage = l_stage == kXS - 1 ? 0 : l_stage + 1;
-    if (++l_kt == nkt) {
-      l_kt = 0;
-      ++l_nt;
-      if (l_nt < nt_begin + nt_count) set_w(l_nt);
-    }
-  };
-  // the W stream starts first so it overlaps the X fragment loads below
-#pragma unroll
-  for (int pz = 0; pz < kXS - 1; ++pz)
-    if (pz < steps) issue();
-
-  // ---- X fragments of this wave's 32 rows for the whole K: lane (fr,kg) holds X[row fr][32 ks + 8 kg .. +7]
-  bf16x8 xf[KSTEPS][MT];
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    int64_t mm = m0 + wid * 32 + j * 16 + fr;
-    mm = mm < G.rows ? mm : G.rows - 1;          // clamped rows feed outputs that go to the sink
-    const int64_t off = G.pair ? (mm >> 1) * G.a_ld + (mm & 1) * (int64_t)K : mm * G.a_ld;
-    const bf16* xr = (const bf16*)G.a + off + kg * 8;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {        // unconditional: k-steps a group does not have re-read its step 0
-      if constexpr (OCTIC_XREG_ABL & 8) {        // ablation: no X loads (operands = lane pattern)
-        xf[ks][j] = bf16x8{(bf16)1.f, (bf16)0.5f, (bf16)0.25f, (bf16)0.f, (bf16)1.f, (bf16)0.5f, (bf16)0.25f, (bf16)0.f};
-        asm volatile("" :: "v"(xr));
-      } else
-        xf[ks][j] = *(const bf16x8*)(xr + (ks < ksteps ? ks : 0) * 32);
-    }
-  }
-  // The X registers are re-defined by an empty asm once their loads have landed.  hipcc's waitcnt pass tracks
-  // pending VMEM results per register and cannot see that loads issued before a loop are complete after its first
-  // trip: left alone it protects EVERY MFMA block of the loop with `s_waitcnt vmcnt(0)`, which also drains the DMA
-  // ring and the epilogue stores at every step (the first version of this kernel did exactly that).  After this
-  // statement the registers' last writer is the asm, so the loop carries no VMEM dependence on them.
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-      asm volatile("" : "+v"(xf[ks][j]));
-  XTRACE(1);
-
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-  const int sw = fr & 7;
-  const int rd_w = fr * 128;                            // + i*2048
-  const int ch0 = (kg ^ sw) << 4, ch1 = ((4 + kg) ^ sw) << 4;
-
-  // ---- epilogue constants.  bf16 outputs go through the LDS staging tile (row-wise 16-byte stores); f32 outputs
-  // (fused residual) keep the direct MFMA-layout path: their 4 columns are already 16 bytes per lane, and the
-  // staged variant needs more registers than the 170 this kernel has (spills, 59 -> 70 us on proj+res).
-  constexpr bool kStaged = sizeof(TOUT) == 2;
-  TOUT* const sink = (TOUT*)(g_store_sink + lane * 16);
-  const bool has_bias = G.bias != nullptr;
-  const bool has_cs = EPI == 1 && G.cs != nullptr, has_rs = EPI == 1 && args.rs != nullptr,
-             has_res = EPI == 1 && G.resid != nullptr;
-  int e_nt = nt_begin;
-  // direct path state
-  TOUT* ybase[MT];
-  const TOUT* rbase[MT];
-  float rsv[MT];
-  bool rok[MT];
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    const int64_t mm = m0 + wid * 32 + j * 16 + fr;
-    rok[j] = mm < G.rows;
-    const int64_t mc = rok[j] ? mm : 0;
-    const int64_t token = G.pair ? (mc >> 1) : mc;
-    const int64_t yoff = G.pair ? (mc >> 1) * G.y_ld + (mc & 1) * (int64_t)N : mc * G.y_ld;
-    const int64_t roff = G.pair ? (mc >> 1) * G.r_ld + (mc & 1) * (int64_t)N : mc * G.r_ld;
-    ybase[j] = (TOUT*)G.y + yoff;
-    rbase[j] = (const TOUT*)G.resid + roff;
-    rsv[j] = (EPI == 1 && args.rs) ? args.rs[token / args.rps] : 1.0f;
-  }
-  // staged path state
-  char* const stg = lds + kXS * kXStage + wid * (16 * SRS);
-  // row-wise phase: chunk q = lane + 64 t of a 16-row half is row q / CPR, 16-byte column chunk q % CPR
-  auto epilogue_direct = [&]() {
-    const int nb = e_nt * kRingBN + kg * 4;
-    ++e_nt;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = nb + i * 16;
-      const bool nok = n < N;
-      const int nc2 = nok ? n : 0;
-      f32x4 bv = {0, 0, 0, 0}, sv = {1, 1, 1, 1};
-      if (has_bias) bv = *(const f32x4*)(G.bias + nc2);
-      if (has_cs) sv = *(const f32x4*)(G.cs + nc2);
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const bool ok = nok && rok[j];
-        f32x4 v = acc[i][j];
-        if (has_bias) v += bv;
-        if (has_cs) v *= sv;
-        if (has_rs) v *= rsv[j];
-        if (has_res) v += load_out4<TOUT>(ok ? rbase[j] + n : (const TOUT*)sink);
-        store_out4<TOUT>(ok ? ybase[j] + n : sink, v);
-        acc[i][j] = f32x4{0, 0, 0, 0};
-      }
-    }
-  };
-  auto epilogue_staged = [&]() {
-    const int n0 = e_nt * kRingBN;
-    ++e_nt;
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      // phase A: this wave's 16 x 80 block, MFMA layout -> LDS (lane: row fr, columns i*16 + kg*4 .. +3)
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int n = n0 + i * 16 + kg * 4;
-        const int nc2 = n < N ? n : 0;
-        f32x4 v = acc[i][j];
-        if (has_bias) v += *(const f32x4*)(G.bias + nc2);
-        if (has_cs) v *= *(const f32x4*)(G.cs + nc2);
-        if (has_rs) v *= rsv[j];
-        store_out4<TOUT>((TOUT*)(stg + fr * SRS) + i * 16 + kg * 4, v);
-        acc[i][j] = f32x4{0, 0, 0, 0};
-      }
-      // phase B: rows of the block, 16 bytes per lane (+ residual), always SCH store instructions
-#pragma unroll
-      for (int t = 0; t < SCH; ++t) {
-        const int q = lane + 64 * t;
-        const bool inb = q < 16 * CPR;
-        const int row = inb ? q / CPR : 0;
-        const int scolt = inb ? (q - row * CPR) * EPV : 0;
-        const int64_t mm = m0 + wid * 32 + j * 16 + row;
-        const int n = n0 + scolt;
-        const bool ok = inb && mm < G.rows && n < N;
-        const int64_t mc = ok ? mm : 0;
-        const int64_t yoff = G.pair ? (mc >> 1) * G.y_ld + (mc & 1) * (int64_t)N : mc * G.y_ld;
-        u32x4 v = *(const u32x4*)(stg + row * SRS + scolt * (int)sizeof(TOUT));
-        if (has_res) {
-          const int64_t roff = G.pair ? (mc >> 1) * G.r_ld + (mc & 1) * (int64_t)N : mc * G.r_ld;
-          const u32x4 r = *(const u32x4*)(ok ? (const TOUT*)G.resid + roff + n : (const TOUT*)sink);
-          if constexpr (sizeof(TOUT) == 4) {
-            f32x4 a = __builtin_bit_cast(f32x4, v) + __builtin_bit_cast(f32x4, r);
-            v = __builtin_bit_cast(u32x4, a);
-          } else {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, v), c = __builtin_bit_cast(bf16x8, r);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)a[e] + (float)c[e]);
-            v = __builtin_bit_cast(u32x4, o);
-          }
-        }
-        *(u32x4*)((ok && !(OCTIC_XREG_ABL & 2)) ? (TOUT*)G.y + yoff + n : sink) = v;
-      }
-    }
-  };
-  auto epilogue = [&]() {
-    if constexpr (kStaged) epilogue_staged();
-    else epilogue_direct();
-  };
-
-  // ---- ring over (n-tile, k-tile) steps; only W moves
-  const bool plain_waits = !(has_res || has_bias || has_cs);   // VGPR-destination loads in the epilogue: drain instead
-  // VMEM program order per step s: [wait tile s][barrier] DMA(s+P) compute(s) [stores if the n-tile is done], P = kXS-1.
-  // Younger than DMA(s) at that wait: DMA(s+1..s+P-1) and the stores of steps s-P..s-1.
-  int c_stage = 0, sth[kXS - 1];
-#pragma unroll
-  for (int pz = 0; pz < kXS - 1; ++pz) sth[pz] = 0;
-  for (int nt_i = 0; nt_i < nt_count; ++nt_i) {
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt >= nkt) break;                    // wave-uniform
-      const int s = nt_i * nkt + kt;
-      if (plain_waits) {
-        const int left = steps - 1 - s;          // DMA tiles younger than tile s: kXS-2 in steady state
-        int stores = 0;
-#pragma unroll
-        for (int pz = 0; pz < kXS - 1; ++pz) stores += sth[pz];
-        // tail of the workgroup: a smaller count than strictly needed is always safe (it only waits longer)
-#ifndef OCTIC_XREG_SLOWWAIT
-        // steady state first (two or three scalar compares instead of the 17-way ladder of wait_vmcnt)
-        if (kXS == 3 && left >= 1 && stores == 0) {
-          if (w_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else if (kXS == 3 && left >= 1 && stores == NSTORE && NSTORE == 6) {
-          if (w_cnt == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else
-#endif
-        wait_vmcnt(left >= kXS - 2 ? (kXS - 2) * w_cnt + (stores > 20 ? 20 : stores) : left * w_cnt);
-      } else {
-        wait_vmcnt(0);
-      }
-      XTRACE(2 + 3 * s);
-      __builtin_amdgcn_s_barrier();
-      XTRACE(3 + 3 * s);
-      if (s + kXS - 1 < steps) issue();
-      const char* base = lds + c_stage * kXStage + rd_w;
-      c_stage = c_stage == kXS - 1 ? 0 : c_stage + 1;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (kt * 2 + ks < ksteps) {
-          const int ch = ks ? ch1 : ch0;
-          bf16x8 af[NT];
-#pragma unroll
-          for (int i = 0; i < NT; ++i) af[i] = *(const bf16x8*)(base + i * 2048 + ch);
-#pragma unroll
-          for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-              if constexpr (OCTIC_XREG_ABL & 4) acc[i][j][0] += (float)af[i][0] * (float)xf[kt * 2 + ks][j][0];
-              else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], xf[kt * 2 + ks][j], acc[i][j], 0, 0, 0);
-        }
-      }
-      XTRACE(4 + 3 * s);
-#pragma unroll
-      for (int pz = kXS - 2; pz > 0; --pz) sth[pz] = sth[pz - 1];
-      sth[0] = 0;
-    }
-    epilogue();
-    sth[0] = NSTORE;
-  }
-}
-
-template <typename TOUT, int KSTEPS>
-int launch_xreg_k(GemmArgs& a, bool fused, int t, hipStream_t s) {
-  const size_t smem = (size_t)kXS * kXStage + (sizeof(TOUT) == 2 ? 4 * 16 * (kRingBN * sizeof(TOUT) + 16) : 0);
-  if (fused) linear_d8_xreg_kernel<TOUT, 1, KSTEPS><<<t, 256, smem, s>>>(a);
-  else linear_d8_xreg_kernel<TOUT, 0, KSTEPS><<<t, 256, smem, s>>>(a);
-  return launch_status();
-}
-
-// returns -100 when the problem does not qualify (caller falls through to the ring kernel)
-template <typename TOUT>
-int launch_xreg(GemmArgs& a, hipStream_t s) {
-  if (a.lift_np > 0) return -100;
-  int kmax = 0;
-  for (int i = 0; i < a.ngroups; ++i) {
-    if (a.g[i].K % 32) return -100;
-    kmax = a.g[i].K / 32 > kmax ? a.g[i].K / 32 : kmax;
-  }
-  if (kmax > 10) return -100;
-  int t = 0;
-  bool fused = a.rs != nullptr;
-  // n-tiles walked per workgroup: sized so the launch has ~2000 workgroups (measured sweet spot on MI355X: fewer,
-  // longer workgroups lose to imbalance, more of them re-load the X fragments too often)
-  int64_t items = 0;
-  for (int i = 0; i < a.ngroups; ++i)
-    items += ((a.g[i].rows + kBM - 1) / kBM) * ((a.g[i].N + kRingBN - 1) / kRingBN);
-  int max_tiles = (int)((items + 1024) / 2048);
-  max_tiles = max_tiles < 1 ? 1 : max_tiles;
-  for (int i = 0; i < a.ngroups; ++i) {
-    a.g[i].n_tiles = (a.g[i].N + kRingBN - 1) / kRingBN;
-    a.g[i].m_tiles = (int)((a.g[i].rows + kBM - 1) / kBM);
-    const int chunk = a.g[i].n_tiles < max_tiles ? a.g[i].n_tiles : max_tiles;
-    a.g[i].chunk = chunk;
-    a.g[i].n_chunks = (a.g[i].n_tiles + chunk - 1) / chunk;
-    a.g[i].tile_begin = t;
-    t += a.g[i].n_chunks * a.g[i].m_tiles;
-    fused = fused || a.g[i].cs || a.g[i].resid;
-  }
-  if (kmax <= 4) return launch_xreg_k<TOUT, 4>(a, fused, t, s);
-  if (kmax <= 6) return launch_xreg_k<TOUT, 6>(a, fused, t, s);
-  return launch_xreg_k<TOUT, 10>(a, fused, t, s);
-}
-
 template <typename TIN, typename TOUT, int NT, int S>
 int launch_ring_nt(GemmArgs& a, hipStream_t s) {
   constexpr int BN = 16 * NT;
@@ -991,10 +636,8 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
 
 inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
   if (dtype == OCTIC_BF16) {
-    const int rw = launch_wreg(a, out_dtype, s);
+    const int rw = launch_wreg(a, out_dtype, s);   // short-K problems: W-stationary streaming kernel (gemm_wreg.hip)
     if (rw != -100) return rw;
-    const int r = out_dtype == OCTIC_BF16 ? launch_xreg<bf16>(a, s) : (out_dtype == OCTIC_F32 ? launch_xreg<float>(a, s) : -100);
-    if (r != -100) return r;
   }
   if (ring_ok(a, dtype)) {
     if (dtype == OCTIC_F32 && out_dtype == OCTIC_F32) return launch_ring<float, float>(a, s);

@@ -3,9 +3,9 @@
 // one launch for the five irrep sub-problems.
 //
 // These problems move 5-10 bytes per MFMA flop-pair less than a dense GEMM of the same rows: they are bound by the
-// token rows going in and out, not by the matrix pipe.  The X-stationary kernel (gemm.hip) re-streamed the weights
-// once per 128 rows (316 MB of L2->LDS traffic for a 210 MB fc1) and ran load / multiply / store as phases of a
-// short-lived workgroup.  Here the roles are swapped:
+// token rows going in and out, not by the matrix pipe.  The X-stationary kernel of rounds 1-2 (removed) re-streamed the
+// weights once per 128 rows (316 MB of L2->LDS traffic for a 210 MB fc1) and ran load / multiply / store as phases of
+// a short-lived workgroup (fc1 80-89 us).  Here the roles are swapped (fc1 55-58 us):
 //   * a workgroup owns up to 320 (1-D irreps) or 256 (E irrep) OUTPUT COLUMNS of one irrep for its whole life and keeps
 //     that slice of W as MFMA A-operand fragments in registers (<= 160 VGPRs per lane), loaded once;
 //   * it then streams a contiguous range of token rows: 32-row tiles of X arrive through a 4-stage LDS-DMA ring
@@ -23,29 +23,63 @@
 namespace octic {
 namespace wr {
 
+#ifndef OCTIC_WREG_ABL
+#define OCTIC_WREG_ABL 0   // developer ablation builds (tools/wreg_variants.py): 1 no X DMA, 2 no global stores, 4 no MFMAs, 8 no W loads
+#endif
+#ifndef OCTIC_WREG_S
+#define OCTIC_WREG_S 4
+#endif
+#ifndef OCTIC_WREG_WGS
+#define OCTIC_WREG_WGS 2   // workgroups per CU the launch is sized for
+#endif
+// time model of the work partition (cycles; launch_t)
+#ifndef OCTIC_WREG_FIX0
+#define OCTIC_WREG_FIX0 5000.0
+#endif
+#ifndef OCTIC_WREG_FIX1
+#define OCTIC_WREG_FIX1 300.0
+#endif
+#ifndef OCTIC_WREG_STEP0
+#define OCTIC_WREG_STEP0 700.0
+#endif
+#ifndef OCTIC_WREG_EPI
+#define OCTIC_WREG_EPI 900.0
+#endif
+#ifndef OCTIC_WREG_CPB
+#define OCTIC_WREG_CPB 0.1   // cycles per byte of a workgroup at two per CU
+#endif
 constexpr int TM = 32;     // GEMM rows per ring stage
 constexpr int KSC = 5;     // MFMA k-steps per k-chunk (k-chunk <= 160 elements)
-constexpr int S = 4;       // ring stages
+constexpr int S = OCTIC_WREG_S;   // ring stages (3, 4, 5 measured within noise of each other)
 constexpr int MAXD = 3;    // DMA wave-instructions per wave and stage (<= 10 per stage over 4 waves)
 
 __device__ char g_sink[64 * 16];
 
-int g_off = 0;   // developer switch: 1 = never take this kernel (A/B against the X-stationary one)
+#ifdef OCTIC_WREG_TRACE
+// developer-only timeline (build with -DOCTIC_WREG_TRACE, tools/wreg_trace.py): clock stamps of every workgroup's waves
+__device__ unsigned long long g_trace[1024 * 4 * 128];
+#define WTRACE(slot)                                                                                                    \
+  do {                                                                                                                  \
+    if (trace_item < 1024 && lane == 0 && (slot) < 128) g_trace[(trace_item * 4 + wid) * 128 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define WTRACE(slot) do {} while (0)
+#endif
 
-#define OCTIC_WCASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-__device__ __forceinline__ void wait_vm(int n) {   // n wave-uniform; anything outside the table drains (always safe)
-  switch (n) {
-    OCTIC_WCASE(1) OCTIC_WCASE(2) OCTIC_WCASE(3) OCTIC_WCASE(4) OCTIC_WCASE(5) OCTIC_WCASE(6) OCTIC_WCASE(7) OCTIC_WCASE(8)
-    OCTIC_WCASE(9) OCTIC_WCASE(10) OCTIC_WCASE(11) OCTIC_WCASE(12) OCTIC_WCASE(13) OCTIC_WCASE(14) OCTIC_WCASE(15)
-    OCTIC_WCASE(16) OCTIC_WCASE(17) OCTIC_WCASE(18) OCTIC_WCASE(19) OCTIC_WCASE(20) OCTIC_WCASE(21) OCTIC_WCASE(22)
-    OCTIC_WCASE(23) OCTIC_WCASE(24) OCTIC_WCASE(25) OCTIC_WCASE(26) OCTIC_WCASE(27) OCTIC_WCASE(28) OCTIC_WCASE(29)
-    OCTIC_WCASE(30) OCTIC_WCASE(31) OCTIC_WCASE(32) OCTIC_WCASE(33) OCTIC_WCASE(34) OCTIC_WCASE(35) OCTIC_WCASE(36)
-    OCTIC_WCASE(37) OCTIC_WCASE(38) OCTIC_WCASE(39) OCTIC_WCASE(40) OCTIC_WCASE(41) OCTIC_WCASE(42) OCTIC_WCASE(43)
-    OCTIC_WCASE(44) OCTIC_WCASE(45) OCTIC_WCASE(46) OCTIC_WCASE(47) OCTIC_WCASE(48)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
+int g_off = 0;   // developer switch: 1 = never take this kernel (A/B against the ring kernel)
+
+// B-operand reads as inline asm with hand-counted waits: hipcc waits with lgkmcnt(0) before every MFMA group of this
+// loop (it does not count across the loop's blocks), which also waits for the fragment requested one group earlier.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
 }
-#undef OCTIC_WCASE
+template <int N>
+__device__ __forceinline__ void landed(bf16x8& v) {   // at most N younger LDS reads outstanding => v has arrived
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
 
 template <typename TOUT>
 __device__ __forceinline__ void stage_out4(char* p, f32x4 v);
@@ -72,17 +106,24 @@ __device__ __forceinline__ u32x4 add_resid(u32x4 v, u32x4 r) {
 
 // One workgroup's life.  NCH = k-chunks per row tile (1: one-dimensional irreps, 2: the E pair rows), NTW = 16-column
 // MFMA tiles a wave can own.
-template <typename TOUT, int EPI, int NCH, int NTW>
+template <typename TOUT, int EPI, int NCH, int NTW, bool FULLK>
 __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, const int lt, char* lds) {
   constexpr int ES = (int)sizeof(TOUT);
   constexpr int SRS = NTW * 16 * ES + 16;   // staged output row stride (bytes)
   constexpr int NSMAX = NTW * ES / 2;       // row-wise store instructions per tile when the wave owns NTW tiles
+  constexpr bool kPair = NCH == 2;          // the E irrep: GEMM row mm = token mm >> 1, half mm & 1
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, kg = lane >> 4;
+#ifdef OCTIC_WREG_TRACE
+  const int trace_item = lt + G.tile_begin;
+#endif
+  WTRACE(0);
   const int K = G.K, N = G.N;
-  const int Kc = K / NCH, ksteps = Kc >> 5, cpr = Kc >> 3, rowb = Kc * 2, stage_b = TM * rowb;
+  int g_rows = (int)G.rows;   // pinned in an SGPR below: a scalar re-load inside the loop would force lgkmcnt(0) waits
+  // FULLK: the k-chunk is exactly KSC MFMA k-steps (cin = 160, ViT-H): no k-step guards, pipelined fragment reads
+  const int Kc = K / NCH, ksteps = FULLK ? KSC : (Kc >> 5), cpr = Kc >> 3, rowb = Kc * 2, stage_b = TM * rowb;
 
   // ---- work: column chunk chunk_id of this irrep, row tiles [t_begin, t_end)
   const int chunk_id = lt % G.n_chunks, jw = lt / G.n_chunks;
@@ -112,7 +153,7 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
   const int n_inst = cpr >> 1;
   const int D = (n_inst - wid + 3) >> 2;     // this wave issues instructions wid, wid + 4, ...
   const int64_t a_row_b = G.a_ld * 2;
-  const int64_t tile_stride = G.pair ? (TM / 2) * a_row_b : TM * a_row_b;
+  const int64_t tile_stride = kPair ? (TM / 2) * a_row_b : TM * a_row_b;
   int xoff[MAXD];
   auto set_xoff = [&](int rows_valid) {
 #pragma unroll
@@ -121,7 +162,7 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
       int row = p / cpr;
       const int lc = (p - row * cpr) ^ swz(row);
       row = row < rows_valid ? row : rows_valid - 1;   // clamped rows only feed outputs that go to the sink
-      xoff[q] = (int)(G.pair ? (row >> 1) * a_row_b + (row & 1) * (int64_t)K * 2 : row * a_row_b) + lc * 16;
+      xoff[q] = (int)(kPair ? (row >> 1) * a_row_b + (row & 1) * (int64_t)K * 2 : row * a_row_b) + lc * 16;
     }
   };
   const int64_t last_row0 = (int64_t)(G.m_tiles - 1) * TM;
@@ -134,7 +175,7 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
     char* st = ring + l_stage * stage_b;
 #pragma unroll
     for (int q = 0; q < MAXD; ++q)
-      if (q < D)
+      if (q < D && !(OCTIC_WREG_ABL & 1))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(l_src + l_c * rowb + xoff[q]),
                                          (__attribute__((address_space(3))) void*)(st + (wid + 4 * q) * 1024), 16, 0, 0);
     l_stage = l_stage == S - 1 ? 0 : l_stage + 1;
@@ -167,41 +208,54 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) wf[i][c * KSC + ks] = *(const bf16x8*)(wrow + c * Kc + (ks < ksteps ? ks : 0) * 32);
+      for (int ks = 0; ks < KSC; ++ks) {
+        if constexpr (OCTIC_WREG_ABL & 8) {
+          wf[i][c * KSC + ks] = bf16x8{(bf16)1.f, (bf16)0.5f, (bf16)0.25f, (bf16)0.f, (bf16)1.f, (bf16)0.5f, (bf16)0.25f, (bf16)0.f};
+          asm volatile("" ::"v"(wrow));
+        } else
+          wf[i][c * KSC + ks] = *(const bf16x8*)(wrow + c * Kc + (ks < ksteps ? ks : 0) * 32);
+      }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  // re-define the fragments so the loop carries no pending-VMEM dependence on them (see the X-stationary kernel)
+  // re-define the fragments: hipcc's waitcnt pass cannot see that loads issued before a loop are complete after its
+  // first trip and would protect every MFMA block with `s_waitcnt vmcnt(0)`, draining the DMA ring at every step
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int k = 0; k < NCH * KSC; ++k) asm volatile("" : "+v"(wf[i][k]));
+  WTRACE(1);
 
   // ---- B-operand read addresses: row (16 jj + fr), chunk (4 ks + kg) ^ swz
   const int sw = swz(fr);
-  int o4[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) o4[m] = ((4 * m + kg) ^ sw) << 4;
-  const int rb0 = fr * rowb, rb1 = (16 + fr) * rowb;
+  int ksw16 = (kg ^ sw) << 4;   // chunk (4 m + kg) ^ sw = 4 m ^ (kg ^ sw): one register instead of four offsets
+  int rb0 = fr * rowb;
+  const int rb16 = 16 * rowb;
 
   // ---- row-wise store map of the wave's staged [32][16 ntw] block
   const int cprow = ntw * ES;              // 16-byte chunks per staged row
   const int NS = (TM * cprow) >> 6;        // store instructions per tile (every lane used)
   const int64_t y_row_b = G.y_ld * ES, r_row_b = G.r_ld * ES;
-  const int64_t y_tile_stride = G.pair ? (TM / 2) * y_row_b : TM * y_row_b;
-  const int64_t r_tile_stride = G.pair ? (TM / 2) * r_row_b : TM * r_row_b;
-  int so[NSMAX], go[NSMAX], srow[NSMAX], gr[NSMAX];
-#pragma unroll
-  for (int t = 0; t < NSMAX; ++t) {
-    const int q = lane + 64 * t;
-    const int row = cprow ? q / cprow : 0;
+  const int64_t y_tile_stride = kPair ? (TM / 2) * y_row_b : TM * y_row_b;
+  const int64_t r_tile_stride = kPair ? (TM / 2) * r_row_b : TM * r_row_b;
+  // row / chunk of store instruction t of this lane are re-derived at use (q / cprow by multiply-shift, exact for
+  // q < 384, cprow <= 20): precomputed offset arrays cost 20 VGPRs next to 160 of W fragments
+  const int inv_cprow = cprow ? (65536 + cprow - 1) / cprow : 0;
+  int lane_l = lane;   // re-defined inside the loop: keeps hipcc from hoisting every derived offset into its own VGPR
+  auto pk_of = [&](int t) {
+    const int q = lane_l + 64 * t;
+    const int row = (q * inv_cprow) >> 16;
     const int cc = q - row * cprow;
-    const int gcol = n0 + cc * (16 / ES);
-    const bool ok = t < NS && gcol < N;
-    so[t] = row * SRS + cc * 16;
-    go[t] = (int)(G.pair ? (row >> 1) * y_row_b + (row & 1) * (int64_t)N * ES : row * y_row_b) + gcol * ES;
-    gr[t] = (int)(G.pair ? (row >> 1) * r_row_b + (row & 1) * (int64_t)N * ES : row * r_row_b) + gcol * ES;
-    srow[t] = ok ? row : (1 << 20);
-  }
+    const bool ok = n0 + cc * (16 / ES) < N;
+    return row | (cc << 8) | (ok ? 0 : (1 << 30));
+  };
+  const int y_rb = (int)y_row_b, r_rb = (int)r_row_b, n_b = N * ES;
+  auto pk_row = [&](int v) { return v & 0xff; };
+  auto pk_so = [&](int v) { return (v & 0xff) * SRS + ((v >> 8) & 0xff) * 16; };
+  auto pk_go = [&](int v, int rowb_) {
+    const int row = v & 0xff, colb = n0 * ES + ((v >> 8) & 0xff) * 16;
+    return (kPair ? (row >> 1) * rowb_ + (row & 1) * n_b : row * rowb_) + colb;
+  };
+  auto pk_ok = [&](int v, int rows_valid) { return v < (1 << 30) && (v & 0xff) < rows_valid; };
   const bool has_res = EPI == 1 && G.resid != nullptr, has_rs = EPI == 1 && args.rs != nullptr;
   const int R = (has_res ? NS : 0) + (has_rs ? 2 : 0);
   char* const sink = g_sink + lane * 16;
@@ -209,28 +263,45 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
   const char* r_t = G.resid + (int64_t)t_begin * r_tile_stride;
   const int wave_col = wt0 * 16 + kg * 4;
 
-  // since[k]: vector-memory instructions this wave has issued after the DMA of in-flight stage k (0 = oldest)
-  int since[S - 1];
+  // ---- counted waits.  Per stage step a wave issues, in this order: [R residual / row-scale loads, first k-chunk
+  // only] D DMA instructions (stage u + S - 1) [NS stores, last k-chunk only].  At the top of step u the DMA of stage u
+  // (issued S - 1 steps earlier) is followed by younger[u % NCH] instructions; `s_waitcnt vmcnt(n)` with n <= that
+  // count guarantees it has landed (one in-order counter for loads, DMA and stores).  The immediate is fixed at 8 (or a
+  // drain when fewer are younger, during ramp-up and in the tail where no DMA is issued any more): what it additionally
+  // waits for are the OLDEST of the younger instructions - stores issued S - 1 steps ago, long complete.  (The first
+  // version tracked the exact count and dispatched over 48 immediates: ~550 cycles of scalar compare ladder per step.)
+  bool wait8[NCH];
 #pragma unroll
-  for (int k = 0; k < S - 1; ++k) since[k] = 0;
-  auto bump = [&](int x) {
+  for (int c = 0; c < NCH; ++c) {
+    int younger = 0;
 #pragma unroll
-    for (int k = 0; k < S - 1; ++k) since[k] += x;
-  };
+    for (int k = S - 1; k >= 1; --k) {           // step u - k has k-chunk index (c - k) mod NCH
+      const int ck = ((c - k) % NCH + NCH) % NCH;
+      if (k < S - 1) younger += (ck == 0 ? R : 0) + D;
+      younger += (ck == NCH - 1 && !(OCTIC_WREG_ABL & 2)) ? NS : 0;
+    }
+    wait8[c] = younger >= 8;
+  }
   int c_stage = 0;
   f32x4 acc[NTW][2];
   u32x4 rr[NSMAX];
   float rsv[2] = {1.f, 1.f};
+  // fast epilogue: every store instruction of the wave is whole (all NTW tiles owned, all columns inside N)
+  const bool cols_whole = ntw == NTW && n0 + NTW * 16 <= N;
 
+  asm volatile("" : "+s"(g_rows));
   for (int tile = 0; tile < ntiles; ++tile) {
-    const int64_t row0 = (int64_t)(t_begin + tile) * TM;
-    const int rows_valid = (int)(G.rows - row0) < TM ? (int)(G.rows - row0) : TM;
+    const int row0 = (t_begin + tile) * TM;
+    const int rows_valid = (g_rows - row0) < TM ? (g_rows - row0) : TM;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      wait_vm(since[0]);
+      const int u = tile * NCH + c;
+      asm volatile("" : "+v"(lane_l), "+v"(ksw16), "+v"(rb0));
+      if (wait8[c] && u >= S - 1 && u + S - 1 < steps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WTRACE(2 + 3 * u);
       __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int k = 0; k < S - 2; ++k) since[k] = since[k + 1];
+      WTRACE(3 + 3 * u);
       if (c == 0) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
@@ -242,36 +313,52 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
           if (has_rs) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-              int64_t mm = row0 + jj * 16 + fr;
-              mm = mm < G.rows ? mm : G.rows - 1;
-              rsv[jj] = args.rs[(int)(G.pair ? (mm >> 1) : mm) / (int)args.rps];
+              int mm = row0 + jj * 16 + fr;
+              mm = mm < g_rows ? mm : g_rows - 1;
+              rsv[jj] = args.rs[(kPair ? (mm >> 1) : mm) / (int)args.rps];
             }
           }
           if (has_res) {
 #pragma unroll
             for (int t = 0; t < NSMAX; ++t)
-              if (t < NS) rr[t] = *(const u32x4*)(srow[t] < rows_valid ? r_t + gr[t] : (const char*)sink);
+              if (t < NS) rr[t] = *(const u32x4*)(pk_ok(pk_of(t), rows_valid) ? r_t + pk_go(pk_of(t), r_rb) : (const char*)sink);
           }
-          bump(R);
         }
       }
-      if (tile * NCH + c + S - 1 < steps) {
-        issue();
-        bump(D);
-      }
-      since[S - 2] = 0;
+      if (u + S - 1 < steps) issue();
       const char* st = ring + c_stage * stage_b;
       c_stage = c_stage == S - 1 ? 0 : c_stage + 1;
+      const unsigned st_a = lds_addr(st) + rb0;
+      auto xload = [&](int jj, int ks) { return lds_read16(st_a + (jj ? rb16 : 0) + 256 * (ks >> 2) + ((64 * (ks & 3)) ^ ksw16)); };
+      auto mm = [&](int jj, int ks, const bf16x8 xb) {
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
+        for (int i = 0; i < NTW; ++i)
+          if constexpr (OCTIC_WREG_ABL & 4) acc[i][jj][0] += (float)wf[i][c * KSC + ks][0] * (float)xb[0];
+          else acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][c * KSC + ks], xb, acc[i][jj], 0, 0, 0);
+      };
+      if constexpr (FULLK) {
+        constexpr int PD = 3, NX = 2 * KSC;   // fragments in flight; fragment n = rows 16 (n / KSC) + fr, k-step n % KSC
+        bf16x8 xq[PD];
 #pragma unroll
-        for (int ks = 0; ks < KSC; ++ks)
-          if (ks < ksteps) {
-            const bf16x8 xb = *(const bf16x8*)(st + (jj ? rb1 : rb0) + 256 * (ks >> 2) + o4[ks & 3]);
+        for (int n = 0; n < PD; ++n) xq[n] = xload(n / KSC, n % KSC);
 #pragma unroll
-            for (int i = 0; i < NTW; ++i)
-              acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][c * KSC + ks], xb, acc[i][jj], 0, 0, 0);
+        for (int n = 0; n < NX; ++n) {
+          // fragments n + 1 .. min(NX, n + PD) - 1 are younger than fragment n
+          if (n + PD <= NX) landed<PD - 1>(xq[n % PD]);
+          else if (n + 2 == NX) landed<1>(xq[n % PD]);
+          else landed<0>(xq[n % PD]);
+          mm(n / KSC, n % KSC, xq[n % PD]);
+          if (n + PD < NX) xq[n % PD] = xload((n + PD) / KSC, (n + PD) % KSC);
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 2 * KSC; ++n)
+          if (n % KSC < ksteps) {
+            bf16x8 xb = xload(n / KSC, n % KSC);
+            landed<0>(xb);
+            mm(n / KSC, n % KSC, xb);
           }
+      }
       if (c == NCH - 1) {
         // phase A: MFMA layout (lane: token fr, 4 consecutive channels) -> the wave's staging block
 #pragma unroll
@@ -285,18 +372,35 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
             }
             stage_out4<TOUT>(stg + (jj * 16 + fr) * SRS + (i * 16 + kg * 4) * ES, v);
           }
-        // phase B: rows of the block, 16 bytes per lane (+ residual)
+        // phase B: rows of the block, 16 bytes per lane (+ residual); all reads first, then the stores
+        u32x4 ov[NSMAX];
+        if (cols_whole && rows_valid == TM) {       // no masks, no sink, no per-instruction branches
 #pragma unroll
-        for (int t = 0; t < NSMAX; ++t)
-          if (t < NS) {
-            u32x4 v = *(const u32x4*)(stg + so[t]);
+          for (int t = 0; t < NSMAX; ++t) ov[t] = *(const u32x4*)(stg + pk_so(pk_of(t)));
+#pragma unroll
+          for (int t = 0; t < NSMAX; ++t) {
+            u32x4 v = ov[t];
             if (has_res) v = add_resid<TOUT>(v, rr[t]);
-            *(u32x4*)(srow[t] < rows_valid ? y_t + go[t] : sink) = v;
+            if constexpr (OCTIC_WREG_ABL & 2) asm volatile("" ::"v"(v));   // no store at all: a shared sink line would serialise in L2
+            else *(u32x4*)(y_t + pk_go(pk_of(t), y_rb)) = v;
           }
-        bump(NS);
+        } else {
+#pragma unroll
+          for (int t = 0; t < NSMAX; ++t)
+            if (t < NS) ov[t] = *(const u32x4*)(stg + pk_so(pk_of(t)));
+#pragma unroll
+          for (int t = 0; t < NSMAX; ++t)
+            if (t < NS) {
+              u32x4 v = ov[t];
+              if (has_res) v = add_resid<TOUT>(v, rr[t]);
+              if constexpr (OCTIC_WREG_ABL & 2) asm volatile("" ::"v"(v));
+              else *(u32x4*)(pk_ok(pk_of(t), rows_valid) ? y_t + pk_go(pk_of(t), y_rb) : sink) = v;
+            }
+        }
         y_t += y_tile_stride;
         r_t += r_tile_stride;
       }
+      WTRACE(4 + 3 * u);
     }
   }
 }
@@ -314,8 +418,14 @@ __global__ __launch_bounds__(256, 2) void linear_d8_wreg_kernel(GemmArgs args) {
   for (int i = 1; i < 5; ++i)
     if (i < args.ngroups && item >= args.g[i].tile_begin) gi = i;
   const GemmGroup& G = args.g[gi];
-  if (G.pair) body<TOUT, EPI, 2, NTW_E>(args, G, item - G.tile_begin, lds);
-  else body<TOUT, EPI, 1, NTW_A>(args, G, item - G.tile_begin, lds);
+  const bool fullk = G.K == (G.pair ? 2 : 1) * 32 * KSC;
+  if (G.pair) {
+    if (fullk) body<TOUT, EPI, 2, NTW_E, true>(args, G, item - G.tile_begin, lds);
+    else body<TOUT, EPI, 2, NTW_E, false>(args, G, item - G.tile_begin, lds);
+  } else {
+    if (fullk) body<TOUT, EPI, 1, NTW_A, true>(args, G, item - G.tile_begin, lds);
+    else body<TOUT, EPI, 1, NTW_A, false>(args, G, item - G.tile_begin, lds);
+  }
 }
 
 static int cu_count() {
@@ -337,7 +447,7 @@ int launch_t(GemmArgs& a, hipStream_t s) {
   for (int i = 0; i < a.ngroups; ++i) {
     const GemmGroup& g = a.g[i];
     const int nch = g.pair ? 2 : 1;
-    if (g.K % (32 * nch) || g.rows <= 0) return -100;
+    if (g.K % (32 * nch) || g.rows <= 0 || g.rows >= (1ll << 31)) return -100;
     if (Kc && g.K / nch != Kc) return -100;
     Kc = g.K / nch;
     fused = fused || g.cs || g.resid;
@@ -345,42 +455,51 @@ int launch_t(GemmArgs& a, hipStream_t s) {
   if (Kc < 32 || Kc > 32 * KSC) return -100;
   // column tiles per wave: what fits next to the accumulators (and the residual registers of the fused epilogue)
   const int NTW_A = ES == 2 ? (fused ? 4 : 5) : 3, NTW_E = ES == 2 ? (fused ? 3 : 4) : 3, NTW_MAX = NTW_A;
-  // column chunks and the bytes one workgroup of a chunk moves per row tile
-  double cost[5], total = 0;
+  // column chunks, and a time model of one workgroup of a chunk in cycles (from the s_memtime timeline,
+  // tools/wreg_trace.py): a fixed part - its W fragments, 16 partial lines per load instruction - and a part per row
+  // tile - the MFMAs of two co-resident waves per SIMD plus the barrier / wait / epilogue overhead of a step.
+  // Workgroups per chunk are chosen so that every workgroup of the launch ends at about the same time.
+  double fixed[5], per_tile[5];
   for (int i = 0; i < a.ngroups; ++i) {
     GemmGroup& g = a.g[i];
-    const int cap = 4 * (g.pair ? NTW_E : NTW_A);
+    const int ntw = g.pair ? NTW_E : NTW_A, nch = g.pair ? 2 : 1, cap = 4 * ntw;
     g.n_tiles = (g.N + 15) / 16;
     g.n_chunks = (g.n_tiles + cap - 1) / cap;
     g.chunk = (g.n_tiles + g.n_chunks - 1) / g.n_chunks;
     g.n_chunks = (g.n_tiles + g.chunk - 1) / g.chunk;
     g.m_tiles = (int)((g.rows + TM - 1) / TM);
-    cost[i] = (double)g.m_tiles * TM * (g.chunk * 16.0 * ES + g.K * 2.0);
-    total += g.n_chunks * cost[i];
+    const double frags = (double)ntw * nch * (Kc / 32);          // W load instructions = MFMAs per 16 rows, per wave
+    fixed[i] = OCTIC_WREG_FIX0 + OCTIC_WREG_FIX1 * frags;
+    per_tile[i] = OCTIC_WREG_STEP0 * nch + OCTIC_WREG_EPI + 2 * 2 * 16.0 * frags;
+    // ... or the bytes of the tile at the workgroup's share of the HBM rate, whichever is longer (f32 + residual outputs)
+    const double bytes = TM * (g.chunk * 16.0 * ES * (g.resid ? 2 : 1) + g.K * 2.0);
+    per_tile[i] = per_tile[i] > OCTIC_WREG_CPB * bytes ? per_tile[i] : OCTIC_WREG_CPB * bytes;
   }
-  const int target = 2 * cu_count();
-  int used = 0;
+  const int target = OCTIC_WREG_WGS * cu_count();
+  // smallest common end time T whose workgroup counts  ceil(m_tiles per_tile / (T - fixed))  fit the launch
+  double lo = 0, hi = 0;
   for (int i = 0; i < a.ngroups; ++i) {
-    GemmGroup& g = a.g[i];
-    int w = (int)(target * cost[i] / total);
-    w = w < 1 ? 1 : (w > g.m_tiles ? g.m_tiles : w);
-    g.wgs = w;
-    used += w * g.n_chunks;
+    lo = fixed[i] + per_tile[i] > lo ? fixed[i] + per_tile[i] : lo;
+    hi = fixed[i] + per_tile[i] * a.g[i].m_tiles > hi ? fixed[i] + per_tile[i] * a.g[i].m_tiles : hi;
   }
-  for (;;) {   // hand the rounding leftover to the most loaded streams
-    int best = -1;
-    double load = 0;
+  auto fit = [&](double T, bool commit) {
+    int used = 0;
     for (int i = 0; i < a.ngroups; ++i) {
-      const GemmGroup& g = a.g[i];
-      if (g.wgs < g.m_tiles && used + g.n_chunks <= target && cost[i] / g.wgs > load) {
-        load = cost[i] / g.wgs;
-        best = i;
-      }
+      GemmGroup& g = a.g[i];
+      int w = (int)((g.m_tiles * per_tile[i]) / (T - fixed[i]) + 0.999);
+      w = w < 1 ? 1 : (w > g.m_tiles ? g.m_tiles : w);
+      if (commit) g.wgs = w;
+      used += w * g.n_chunks;
     }
-    if (best < 0) break;
-    ++a.g[best].wgs;
-    used += a.g[best].n_chunks;
+    return used;
+  };
+  if (fit(lo, false) <= target) hi = lo;
+  for (int it = 0; it < 40 && hi - lo > 1.0; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (fit(mid, false) <= target) hi = mid;
+    else lo = mid;
   }
+  fit(hi, true);
   int t = 0;
   for (int i = 0; i < a.ngroups; ++i) {
     a.g[i].tile_begin = t;
@@ -410,5 +529,13 @@ int launch_wreg(GemmArgs& a, int out_dtype, hipStream_t s) {
 
 }  // namespace octic
 
-// developer switch (not part of the ABI contract): 1 = route the short-K problems to the X-stationary kernel instead
+#ifdef OCTIC_WREG_TRACE
+extern "C" void* octic_dbg_wreg_trace(void) {
+  void* p = nullptr;
+  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(octic::wr::g_trace));
+  return p;
+}
+#endif
+
+// developer switch (not part of the ABI contract): 1 = route the short-K problems to the ring kernel instead
 extern "C" void octic_dbg_wreg_off(int off) { octic::wr::g_off = off; }

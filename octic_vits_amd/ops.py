@@ -232,9 +232,8 @@ def linear_fwd(xv, w5, bias, yv, M, cin, cout, dtype, out_dtype, ref, resid_v=No
 
 def linear_kernel_name(cin, dtype, out_dtype, fused):
     """Name of the kernel instantiation octic_linear_d8_fwd dispatches to (mirrors dispatch_gemm in csrc/gemm.hip)."""
-    if dtype == torch.bfloat16 and (2 * cin) % 32 == 0 and cin % 32 == 0 and 2 * cin // 32 <= 10:
-        ks = 2 * cin // 32
-        return f"linear_d8_xreg_kernel<{_DTN[out_dtype]},{fused},{4 if ks <= 4 else (6 if ks <= 6 else 10)}>"
+    if dtype == torch.bfloat16 and cin % 32 == 0 and cin <= 160:
+        return f"linear_d8_wreg_kernel<{_DTN[out_dtype]},{fused}>"
     kstep = 32 if dtype == torch.bfloat16 else 16
     if cin % kstep == 0:
         return f"linear_d8_ring_kernel<{_DTN[dtype]},{_DTN[out_dtype]},{fused}>"

@@ -13,8 +13,8 @@ import sys
 
 # rocprof kernel symbol (substring, mangled or demangled) -> ops.KernelTimer name
 NAMES = [
-    (r"linear_d8_xreg_kernel(IDF16bLi0ELi10E|<__bf16, 0, 10>)", "linear_d8_xreg_kernel<bf16,0,10>"),
-    (r"linear_d8_xreg_kernel(IfLi1ELi10E|<float, 1, 10>)", "linear_d8_xreg_kernel<f32,1,10>"),
+    (r"linear_d8_wreg_kernel(IDF16bLi0E|<__bf16, 0>)", "linear_d8_wreg_kernel<bf16,0>"),
+    (r"linear_d8_wreg_kernel(IfLi1E|<float, 1>)", "linear_d8_wreg_kernel<f32,1>"),
     (r"linear_d8_ring_kernel(IDF16bDF16bLi0E|<__bf16, __bf16, 0)", "linear_d8_ring_kernel<bf16,bf16,0>"),
     (r"linear_d8_ring_kernel(IDF16bfLi1E|<__bf16, float, 1|<bool _Accum, 1)", "linear_d8_ring_kernel<bf16,f32,1>"),
     (r"wgrad_ring_kernel", "wgrad_ring_kernel<bf16>"),
