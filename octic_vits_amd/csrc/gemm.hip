@@ -334,15 +334,32 @@ __device__ inline void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt nee
 // S = 2: 72 KiB, still two workgroups per CU) is for the long-K / narrow-N problems (fc2, input gradients of qkv and
 // fc1: N = 160 | 320): with 80-column tiles their X panel went through the L2->LDS path once per n-tile and each X
 // k-tile (16 KiB) fed only 20 MFMAs per wave - above the ~70 GB/s per CU that path sustains.
-template <typename TIN, typename TOUT, int EPI, int NT, int S>
-__global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
+#ifdef OCTIC_RING_TRACE
+// developer-only timeline (build with -DOCTIC_RING_TRACE, tools/ring_trace.py): clock stamps of the first 2048 workgroups
+__device__ unsigned long long g_ring_trace[2048 * 4 * 64];
+extern "C" void* octic_dbg_ring_trace(void) {
+  void* p = nullptr;
+  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_ring_trace));
+  return p;
+}
+#define RTRACE(slot)                                                                                                  \
+  do {                                                                                                                \
+    if (tile < 2048 && lane == 0 && wid < 4 && (slot) < 63) g_ring_trace[(tile * 4 + wid) * 64 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define RTRACE(slot) do {} while (0)
+#endif
+
+template <typename TIN, typename TOUT, int EPI, int NT, int S, int BM = 128>
+__global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args) {
+  constexpr int NW = BM / 32;                 // waves: each owns 32 rows x BN columns
   constexpr int EPC = Elem<TIN>::EPC;
   constexpr int BKE = 8 * EPC;
   constexpr int MT = 2;
   constexpr int BN = 16 * NT;
-  constexpr int STAGE = (kBM + BN) * 128;
+  constexpr int STAGE = (BM + BN) * 128;
   constexpr int WI = BN / 8;                  // W DMA instructions per tile (8 rows each)
-  constexpr int WQ = (WI + 3) / 4;            // per wave, at most
+  constexpr int WQ = (WI + NW - 1) / NW;      // per wave, at most
   constexpr int NSTORE = NT * MT;             // store instructions per wave per epilogue
   typedef typename Elem<TIN>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char lds[];  // S stages x (128 + BN) rows x 128 B
@@ -350,15 +367,50 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  int gi = 0;
+  // `tile` walks the launch XCD by XCD.  Every group's items are spread evenly over the eight XCDs, the E irrep's
+  // first: an E item takes 1.6x the time of a one-dimensional one, and with the groups laid out one after the other
+  // XCDs 0-3 ran only E items and XCDs 4-7 only short ones (HW_ID timeline, tools/ring_trace.py: per-CU spans of
+  // 95 k .. 200 k cycles for one launch).  Segment k of the order = [share k of group 0 | share k of group 1 | ...].
+  int gi = 0, lt = 0;
+  {
+#ifdef OCTIC_RING_OLDORDER
 #pragma unroll
-  for (int i = 1; i < 5; ++i)
-    if (i < args.ngroups && tile >= args.g[i].tile_begin) gi = i;
+    for (int i = 1; i < 5; ++i)
+      if (i < args.ngroups && tile >= args.g[i].tile_begin) gi = i;
+    lt = tile - args.g[gi].tile_begin;
+#else
+    int T[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      T[i] = i < args.ngroups ? (i + 1 < args.ngroups ? args.g[i + 1].tile_begin : nwg) - args.g[i].tile_begin : 0;
+    auto cum = [&](int k) {
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) c += (int)(((int64_t)k * T[i]) >> 3);
+      return c;
+    };
+    int k = (int)(((int64_t)tile * 8) / nwg);
+    k = k > 7 ? 7 : k;
+    while (k < 7 && cum(k + 1) <= tile) ++k;
+    while (k > 0 && cum(k) > tile) --k;
+    int r = tile - cum(k);
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int s0 = (int)(((int64_t)k * T[i]) >> 3), sz = (int)(((int64_t)(k + 1) * T[i]) >> 3) - s0;
+      if (!found && r < sz) {
+        gi = i;
+        lt = s0 + r;
+        found = true;
+      }
+      if (!found) r -= sz;
+    }
+#endif
+  }
   const GemmGroup& G = args.g[gi];
   // work item = (m-tile, chunk of consecutive n-tiles); the DMA ring runs continuously over its (n-tile, k-tile) steps
-  const int lt = tile - G.tile_begin;
   const int mt = lt / G.n_chunks, nc = lt - mt * G.n_chunks;
-  const int64_t m0 = (int64_t)mt * kBM;
+  const int64_t m0 = (int64_t)mt * BM;
   const int nt_begin = nc * G.chunk;
   const int nt_count = (G.n_tiles - nt_begin) < G.chunk ? (G.n_tiles - nt_begin) : G.chunk;
   const int K = G.K, N = G.N;
@@ -369,6 +421,15 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, kg = lane >> 4;
+  RTRACE(0);
+#ifdef OCTIC_RING_TRACE
+  {
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (tile < 2048 && lane == 0 && wid < 4) g_ring_trace[(tile * 4 + wid) * 64 + 63] = ((unsigned long long)hwid << 32) | xcc;
+  }
+#endif
 
   // ---- DMA sources.  A wave-instruction fills 8 LDS rows: lane -> row (lane>>3), chunk position (lane&7), which
   // must hold source chunk (lane&7) ^ (row&7) = (lane&7) ^ (lane>>3).
@@ -383,9 +444,9 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
     xsrc[q] = G.a + off * (int64_t)sizeof(TIN);
   }
   // W rows: WI instructions over 4 waves (10: waves 0,1 take 3, waves 2,3 take 2; 20: 5 each)
-  const int w_rem = WI & 3;
-  const int w_cnt = WI / 4 + (wid < w_rem ? 1 : 0);
-  const int w_first = wid * (WI / 4) + (wid < w_rem ? wid : w_rem);
+  const int w_rem = WI % NW;
+  const int w_cnt = WI / NW + (wid < w_rem ? 1 : 0);
+  const int w_first = wid * (WI / NW) + (wid < w_rem ? wid : w_rem);
   const int dma_cnt = 4 + w_cnt;              // this wave's DMA instructions per step
   const char* wsrc[WQ];
   auto set_w = [&](int nt) {
@@ -411,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
     for (int q = 0; q < WQ; ++q)
       if (q < w_cnt)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + kb),
-                                         (__attribute__((address_space(3))) void*)(st + kBM * 128 + (w_first + q) * 1024),
+                                         (__attribute__((address_space(3))) void*)(st + BM * 128 + (w_first + q) * 1024),
                                          16, 0, 0);
     l_stage = l_stage == S - 1 ? 0 : l_stage + 1;
     if (++l_kt == nkt) {
@@ -427,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
   const int sw = fr & 7;
-  const int rd_w = kBM * 128 + fr * 128;                // + i*2048
+  const int rd_w = BM * 128 + fr * 128;                // + i*2048
   const int rd_x = (wid * 32 + fr) * 128;               // + j*2048
   const int ch0 = (kg ^ sw) << 4, ch1 = ((4 + kg) ^ sw) << 4;
 
@@ -489,31 +550,79 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
   // so the ops younger than DMA(s) at the wait of step s are: stores(s-2)?, DMA(s+1), stores(s-1)?.
   issue();
   if (S > 2 && steps > 1) issue();
+  RTRACE(1);
   int c_kt = 0, c_stage = 0;
   int st1 = 0, st2 = 0;   // store instructions issued in step s-1 / s-2
   for (int s = 0; s < steps; ++s) {
     // S = 3: DMA runs two tiles ahead (tile s+1 may still be in flight at this wait); S = 2: one tile ahead, so
     // only the stores of step s-1 are younger than DMA(s)
-    if (has_res) wait_vmcnt(0);               // residual loads have VGPR destinations: keep hipcc's own waits exact
+    // (the immediates are picked by two or three scalar compares: a `switch` over all counts compiles to a compare
+    // ladder of ~500 cycles, most of a 640-cycle MFMA step)
+#ifdef OCTIC_RING_OLDWAIT
+    if (has_res) wait_vmcnt(0);
     else if (S > 2) wait_vmcnt(s + 1 < steps ? dma_cnt + st1 + st2 : 0);
     else wait_vmcnt(st1);
+    if (false) {
+#else
+    if (has_res) {
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // residual loads have VGPR destinations: keep hipcc's own waits exact
+    } else if (S > 2) {
+      // younger than DMA(s): DMA(s+1) (dma_cnt = 6 | 7) and the stores of steps s-1, s-2 (0 | NSTORE each); rounding the
+      // count down only waits for the oldest of them, stores issued two steps ago
+      const int n = s + 1 < steps ? dma_cnt + st1 + st2 : 0;
+      if (n >= 6 && n < 16) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (st1 == NSTORE && NSTORE == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if (st1 == NSTORE && NSTORE == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RTRACE(2 + 3 * s);
     __builtin_amdgcn_s_barrier();             // every wave's share of tile s has landed; the stage of tile s-1 is free
+    RTRACE(3 + 3 * s);
     if (s + S - 1 < steps) issue();
     const char* base = lds + c_stage * STAGE;
     c_stage = c_stage == S - 1 ? 0 : c_stage + 1;
+    const bool half_tile = last_half_only && c_kt == nkt - 1;
+    if constexpr (sizeof(TIN) == 2) {
+      // bf16: every fragment of the k-tile is requested before the first MFMA (one exposed LDS latency per step).  Left
+      // to itself hipcc emits  2 x ds_read, s_waitcnt lgkmcnt(0), 4 x MFMA  ten times per step: ten exposed latencies,
+      // ~2000 cycles for 640 cycles of MFMA (tools/ring_trace.py).
+      frag af[2][NT], bfr[2][MT];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 1 && last_half_only && c_kt == nkt - 1) break;
-      const int ch = ks ? ch1 : ch0;
-      frag af[NT], bfr[MT];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ks ? ch1 : ch0;
 #pragma unroll
-      for (int i = 0; i < NT; ++i) af[i] = *(const frag*)(base + rd_w + i * 2048 + ch);
+        for (int j = 0; j < MT; ++j) bfr[ks][j] = *(const frag*)(base + rd_x + j * 2048 + ch);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) bfr[j] = *(const frag*)(base + rd_x + j * 2048 + ch);
+        for (int i = 0; i < NT; ++i) af[ks][i] = *(const frag*)(base + rd_w + i * 2048 + ch);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 1 && half_tile) break;       // the second half holds chunks past K: loaded (valid LDS), never multiplied
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j) acc[i][j] = mfma_step(af[ks][i], bfr[ks][j], acc[i][j]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 1 && half_tile) break;
+        const int ch = ks ? ch1 : ch0;
+        frag af[NT], bfr[MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) af[i] = *(const frag*)(base + rd_w + i * 2048 + ch);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) bfr[j] = *(const frag*)(base + rd_x + j * 2048 + ch);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+      }
     }
     st2 = st1;
     st1 = 0;
@@ -522,17 +631,18 @@ __global__ __launch_bounds__(256, 2) void linear_d8_ring_kernel(GemmArgs args) {
       epilogue();
       st1 = NSTORE;
     }
+    RTRACE(4 + 3 * s);
   }
 }
 
-template <typename TIN, typename TOUT, int NT, int S>
+template <typename TIN, typename TOUT, int NT, int S, int BM = 128>
 int launch_ring_nt(GemmArgs& a, hipStream_t s) {
   constexpr int BN = 16 * NT;
   int t = 0;
   bool fused = a.rs != nullptr || a.lift_np > 0;
   for (int i = 0; i < a.ngroups; ++i) {
     a.g[i].n_tiles = (a.g[i].N + BN - 1) / BN;
-    a.g[i].m_tiles = (int)((a.g[i].rows + kBM - 1) / kBM);
+    a.g[i].m_tiles = (int)((a.g[i].rows + BM - 1) / BM);
     constexpr int target_steps = 1;    // one output tile per workgroup (measured best in situ on MI355X)
     const int bke = 128 / (int)sizeof(TIN);
     const int nkt = (a.g[i].K + bke - 1) / bke;
@@ -545,16 +655,16 @@ int launch_ring_nt(GemmArgs& a, hipStream_t s) {
     fused = fused || a.g[i].cs || a.g[i].resid;
   }
   a.total_tiles = t;
-  const size_t smem = (size_t)S * (kBM + BN) * 128;
+  const size_t smem = (size_t)S * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 0, NT, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 1, NT, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 0, NT, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 1, NT, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipGetLastError();
     attr_done = true;
   }
-  if (fused) linear_d8_ring_kernel<TIN, TOUT, 1, NT, S><<<t, 256, smem, s>>>(a);
-  else linear_d8_ring_kernel<TIN, TOUT, 0, NT, S><<<t, 256, smem, s>>>(a);
+  if (fused) linear_d8_ring_kernel<TIN, TOUT, 1, NT, S, BM><<<t, BM * 2, smem, s>>>(a);
+  else linear_d8_ring_kernel<TIN, TOUT, 0, NT, S, BM><<<t, BM * 2, smem, s>>>(a);
   return launch_status();
 }
 

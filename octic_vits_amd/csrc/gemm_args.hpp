@@ -34,6 +34,21 @@ struct GemmArgs {
   int lift_tok0;
 };
 
+// MFMA operand reads as inline asm with hand-counted waits: inside the GEMM loops hipcc protects every MFMA group with
+// `s_waitcnt lgkmcnt(0)` right after the ds_read that feeds it (it does not count LDS returns across the loops' blocks),
+// exposing one LDS latency per group.  LDS returns are in order, so "at most N younger reads outstanding" is exact as
+// long as no scalar load is in flight (keep kernel-argument reads out of the loops).
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void landed(bf16x8& v) {   // at most N younger LDS reads outstanding => v has arrived
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+
 // W-stationary streaming kernel (gemm_wreg.hip); returns -100 when the problem does not qualify.
 int launch_wreg(GemmArgs& a, int out_dtype, hipStream_t s);
 

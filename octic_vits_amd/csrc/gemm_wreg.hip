@@ -68,19 +68,6 @@ __device__ unsigned long long g_trace[1024 * 4 * 128];
 
 int g_off = 0;   // developer switch: 1 = never take this kernel (A/B against the ring kernel)
 
-// B-operand reads as inline asm with hand-counted waits: hipcc waits with lgkmcnt(0) before every MFMA group of this
-// loop (it does not count across the loop's blocks), which also waits for the fragment requested one group earlier.
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
-__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void landed(bf16x8& v) {   // at most N younger LDS reads outstanding => v has arrived
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
-}
-
 template <typename TOUT>
 __device__ __forceinline__ void stage_out4(char* p, f32x4 v);
 template <>
@@ -349,6 +336,7 @@ __device__ __forceinline__ void body(const GemmArgs& args, const GemmGroup& G, c
           else landed<0>(xq[n % PD]);
           mm(n / KSC, n % KSC, xq[n % PD]);
           if (n + PD < NX) xq[n % PD] = xload((n + PD) / KSC, (n + PD) % KSC);
+          __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs between the reads
         }
       } else {
 #pragma unroll

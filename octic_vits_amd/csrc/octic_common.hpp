@@ -122,6 +122,17 @@ __device__ inline float wave_total(float v) { return total_from16(sum16_from8(su
 __device__ inline float wave_sum(float v) { return wave_total(v); }
 
 
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4) as inline asm: lane L's 16 bytes land at lds_dst + 16 L
+// (lds_dst wave-uniform).  Why not __builtin_amdgcn_global_load_lds: hipcc tracks the builtin as a pending LDS write and
+// puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint (every ds_read_b64_tr_b16 builtin of
+// the weight-gradient ring: the whole DMA queue, including the tile issued a few instructions earlier, was drained at
+// every step).  The kernels order DMA and reads themselves with counted `s_waitcnt vmcnt(n)` + `s_barrier`.
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ void dma16_to_lds(unsigned lds_dst, const void* src) {
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(src) : "memory");
+}
+
 // ---- host-side argument checks -------------------------------------------------------------
 inline int elem_size(int dtype) { return dtype == OCTIC_BF16 ? 2 : 4; }
 

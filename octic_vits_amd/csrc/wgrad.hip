@@ -260,14 +260,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(WgArgs args) {
   }
   int l_step = 0, l_stage = 0;
   auto issue = [&]() {
-    char* st = lds + l_stage * kWgStage;
+    const unsigned st = lds_offset(lds) + l_stage * kWgStage;
     const bool tail = (int64_t)(l_step + 1) * kWgR > r1 - r0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const char* p = src[j];
       if (tail && r0 + (int64_t)l_step * kWgR + row_in_tile[j] >= r1) p = (const char*)g_wg_zero + cbyte[j];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                       (__attribute__((address_space(3))) void*)(st + ldst[j]), 16, 0, 0);
+      dma16_to_lds(st + ldst[j], p);
       src[j] += inc[j];
     }
     l_stage = l_stage == kWgS - 1 ? 0 : l_stage + 1;

@@ -87,13 +87,15 @@ def run(M, cin, cout, out_dt, fused, bias_on=True, time_it=False):
 
 
 ok = True
-if "--bench" not in sys.argv:
+if "--bench" not in sys.argv and "--long" not in sys.argv:
     for (M, cin, cout) in [(96, 32, 32), (77, 64, 24), (500, 96, 40), (640, 128, 128), (37 * 9, 160, 160), (1001, 160, 480), (257 * 4, 160, 640), (33, 32, 8)]:
         for out_dt, fused in ((bf, False), (f32, True), (bf, True), (f32, False)):
             ok = run(M, cin, cout, out_dt, fused) and ok
 M = 64 * 257
-for name, cin, cout, out_dt, fused in (("qkv", 160, 480, bf, False), ("fc1", 160, 640, bf, False), ("proj+res", 160, 160, f32, True),
-                                       ("dgrad fc2", 160, 640, bf, False), ("proj bf16 res", 160, 160, bf, True)):
+SHORT = (("qkv", 160, 480, bf, False), ("fc1", 160, 640, bf, False), ("proj+res", 160, 160, f32, True),
+         ("dgrad fc2", 160, 640, bf, False), ("proj bf16 res", 160, 160, bf, True))
+LONG = (("fc2+res", 640, 160, f32, True), ("dgrad fc1", 640, 160, bf, False), ("dgrad qkv", 480, 160, bf, False))
+for name, cin, cout, out_dt, fused in (LONG if "--long" in sys.argv else SHORT):
     ok = run(M, cin, cout, out_dt, fused, bias_on=name != "dgrad fc2", time_it=True) and ok
 print("ALL OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
