@@ -99,6 +99,9 @@ def main():
                          "replayed as one hipGraph; the kernel-timing steps stay eager.  With DDP the steps are always eager)")
     ap.add_argument("--no-wgrad-slabs", action="store_true",
                     help="developer A/B: library weight gradients as one GEMM instead of a batched GEMM over row slabs")
+    ap.add_argument("--lib-wgrad", action="store_true",
+                    help="developer A/B: every standard-half weight gradient on the BLAS library (default: functional.WGRAD_HIP "
+                         "shapes on csrc/dense_wgrad.hip)")
     ap.add_argument("--no-packed-attn", action="store_true",
                     help="developer A/B: AttentionD8 through the pack / unpack kernels instead of the packed-row attention")
     ap.add_argument("--wgrad-f32-out", action="store_true",
@@ -138,6 +141,9 @@ def main():
     if args.no_wgrad_slabs:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_SLABS = {}
+    if args.lib_wgrad:
+        from octic_vits_amd import functional as _OF
+        _OF.WGRAD_HIP = set()
     if args.no_packed_attn:
         from octic_vits_amd import functional as _OF
         _OF.ATTN_PACKED = False

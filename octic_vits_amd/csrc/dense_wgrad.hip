@@ -1,0 +1,474 @@
+// Weight gradients of the standard half's nn.Linear layers (deit/vit.py:14-56 Attention.qkv / .proj, timm Mlp.fc1 / .fc2):
+//
+//   TN problem:  dW[N,K] = dY[M,N]^T · X[M,K]
+//
+// bf16 operands exactly as they lie in HBM (token rows M are the slow, strided dimension of BOTH operands), f32 result
+// in the nn.Linear layout [N,K] — no transposed copy of the activations, no bf16 round trip of the gradient.
+//
+// Same machinery as the forward kernel (csrc/dense_gemm.hip): 256 x 256 output tile per workgroup, 8 waves as 2 x 4 with
+// 128 (n) x 64 (k) per wave on v_mfma_f32_16x16x32_bf16, reduction walked in steps of 64 token rows, each step cut into
+// four 16 KiB units that stream through an 8-slot LDS ring by buffer-addressed LDS-DMA with counted vmcnt waits, the
+// two wave groups alternating between "read fragments + issue DMA" and "16 MFMAs" intervals.  What differs:
+//   * a unit is 64 token rows x 128 columns (256-byte rows); MFMA operands need 8 consecutive token rows per lane, i.e. a
+//     COLUMN of the staged tile: fragments come from ds_read_b64_tr_b16 (transposing read, 4 rows x 16 columns per
+//     16-lane group).  32-byte slots are XOR-swizzled with ((row & 3) | ((row >> 3) & 1) << 2) on the DMA source side and
+//     in the read address, so the 8 (row, slot) pieces a half-wave touches land in 8 different bank groups;
+//   * the output is small (N x K) and the reduction long (M = 16 448 rows = 257 steps): there are only 25-100 tiles for
+//     256 CUs, so the reduction is cut into S ROW SLABS and a workgroup owns one (slab, tile) item.  All tiles of a slab
+//     are dealt to consecutive workgroups and walk the same token rows in lockstep, tiles that share a dY column panel
+//     sit on one XCD: an operand row is fetched from HBM once per slab and then served out of L2 / the Infinity Cache.
+//     (Round 2's stream-K split - equal contiguous ranges of tiles x steps - gave concurrent workgroups disjoint token
+//     rows: every workgroup streamed its own operands, 1.7 GB of HBM traffic per launch instead of 0.2 GB, and the
+//     kernel ran at the HBM rate, 0.53 PFLOP/s.)  Every item leaves an f32 partial slab; the LAST workgroup to finish
+//     a tile (agent-scope ticket) adds the S slabs in slab order and writes dW (bitwise reproducible).
+//     (Bias gradients come from the row kernels that already stream dY: csrc/dense.hip.)
+#include <type_traits>
+#include "octic_common.hpp"
+
+namespace octic {
+
+constexpr int DW_T = 256;                     // output tile side
+constexpr int DW_BR = 64;                     // token rows per reduction step
+constexpr int DW_UNIT = 64 * 256;             // bytes per unit: 64 rows x 128 bf16 columns
+#ifndef DW_NSLOT
+#define DW_NSLOT 8
+#endif
+#ifndef DW_DIST
+#define DW_DIST 6
+#endif
+#ifndef DW_MAP
+#define DW_MAP 1        // 1: an XCD works on 32 consecutive (slab, tile) items per round; 0: one slab spread over all XCDs
+#endif
+#ifndef DW_AUX
+#define DW_AUX 0        // cache policy bits of the LDS-DMA loads (2 = nt)
+#endif
+constexpr int DW_SLOTS = DW_NSLOT;
+constexpr int DW_D = DW_DIST;
+
+struct DwArgs {
+  const bf16* Y;      // dY [M, N]
+  const bf16* X;      // X  [M, K]
+  int64_t ldy, ldx;
+  int M, N, K;
+  float* W;           // dW [N, K]
+  int tiles_k;        // K / 256
+  int tiles;          // (N / 256) * (K / 256), tile = tn * tiles_k + tk
+  int tiles8;         // tiles rounded up to a multiple of 8: items per slab (the padding items exit at once)
+  int steps;          // ceil(M / 64) reduction steps per tile
+  int S;              // row slabs: slab s covers steps [steps s / S, steps (s + 1) / S)
+  float* slabs;       // [tiles][S] x 256 x 256 f32 partial tiles
+  int* tickets;       // [tiles], zero when the workspace is created; the last arriver of a tile re-arms its ticket
+};
+
+__device__ inline void dw_wait_vmcnt(int n) {
+  switch (n) {
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+__device__ inline void dw_wait_steady() {          // steady state: all but the 2 (D - 2) youngest DMA instructions landed
+  static_assert(DW_D == 4 || DW_D == 6 || DW_D == 8, "add the immediate");
+  if constexpr (DW_D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (DW_D == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // DW_SLOTS x 16 KiB
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 2, wc = wid & 3;      // wr: 128-wide n half of the tile, wc: 64-wide k quarter
+  const bool hi = wr != 0;
+  const int fr = lane & 15, kg = lane >> 4;
+
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // buffer descriptors (raw, 32-bit offsets; rows past M read as zero) for the inline-asm LDS-DMA below
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  auto make_rs = [](const void* base, int64_t bytes) {
+    const uint64_t q = (uint64_t)base;
+    return i32x4{(int)(uint32_t)q, (int)(uint32_t)((q >> 32) & 0xFFFF), (int)bytes, 0x27000};
+  };
+  const i32x4 rsY = make_rs(a.Y, (int64_t)a.M * a.ldy * 2), rsX = make_rs(a.X, (int64_t)a.M * a.ldx * 2);
+  // LDS-DMA as inline asm: hipcc tracks the buffer_load_lds BUILTIN as a pending LDS write and drains the whole ring with
+  // `s_waitcnt vmcnt(0)` in front of every transposing read (that is what held this kernel at 0.45-0.61 PFLOP/s in
+  // round 3's first attempt; see dma16_to_lds in octic_common.hpp)
+  auto dma16 = [](unsigned lds_dst, unsigned voff, int soff, const i32x4 rs) {
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  };
+  const unsigned lds0 = lds_offset(lds);
+
+  // ---- DMA lane constants.  A wave-instruction fills 4 unit rows (256 B each): lane -> row (lane >> 4), 16-byte chunk
+  // position (lane & 15) = 32-byte slot (lane >> 1) & 7, half (lane & 1); the slot holds source slot ^ f(row), with
+  // f(row) = (row & 3) | ((row >> 3) & 1) << 2 and row = 8 * wid + 4 * j + (lane >> 4) for instruction j of the wave.
+  // Unit column c (0..127) of dY-units = tile column (c >> 6) * 128 + (c & 63) (+64 for the second halves); of X-units =
+  // (c >> 5) * 64 + (c & 31) (+32).
+  const int drow = lane >> 4;                 // 0..3
+  const int dpos = lane & 15;
+  unsigned voY[2], voX[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * wid + 4 * j + drow;                         // unit row 0..63
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    const int src_slot = ((dpos >> 1) & 7) ^ f;
+    const int c = src_slot * 16 + (dpos & 1) * 8;                    // first unit column of this lane's 8 bf16
+    voY[j] = (unsigned)(((int64_t)row * a.ldy + (c >> 6) * 128 + (c & 63)) * 2);
+    voX[j] = (unsigned)(((int64_t)row * a.ldx + (c >> 5) * 64 + (c & 31)) * 2);
+  }
+
+  // ---- fragment read constants (transposing reads): lane fr = 4 q + p of a 16-lane group addresses row q, columns
+  // 4 p .. 4 p + 3 of a 4 x 16 block and receives column fr of its 4 rows
+  const int frow = kg * 8 + (fr >> 2);
+  const int ff = ((fr >> 2) & 3) | ((kg & 1) << 2);                  // f(row) for rows frow (+4) (+32 ks)
+  int offY[4], offX[2];                                              // byte offsets inside a unit, k-step 0, "lo" rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offY[j] = frow * 256 + (((wr * 4 + j) ^ ff) << 5) + (fr & 3) * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offX[i] = frow * 256 + (((wc * 2 + i) ^ ff) << 5) + (fr & 3) * 8;
+
+  // ---- this workgroup's (slab, tile) item.  Items of a slab are consecutive; item j of a slab runs on XCD j % 8
+  // (workgroups are dealt round-robin over the XCDs), which owns a contiguous chunk of the tn-major tile list: the
+  // tiles of one dY column panel (same tn) share an L2, and a tile's S partial slabs are written and reduced there.
+#if DW_MAP == 1
+  // Items are numbered slab-major, tiles tn-major inside a slab.  Workgroups are dealt round-robin over the 8 XCDs and
+  // 32 of them are resident per XCD: XCD x takes items [32 (8 r + x), + 32) in round r - a compact patch of ~6 dY
+  // column panels x all X panels of ONE slab, so an XCD fetches ~11 operand panels per step for 32 tiles (0.36 panel
+  // fetches per tile-step; spreading a slab over all XCDs costs 0.6 and made the kernel wait on the fabric).
+  int slab_i, tile;
+  {
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int item = ((slot >> 5) * 8 + x) * 32 + (slot & 31);
+    if (item >= a.tiles * a.S) return;                       // padding item
+    slab_i = item / a.tiles;
+    tile = item - slab_i * a.tiles;
+  }
+#else
+  const int slab_i = blockIdx.x / a.tiles8;
+  int tile;
+  {
+    const int j = blockIdx.x - slab_i * a.tiles8;
+    const int x = j & 7, l = j >> 3, q8 = a.tiles >> 3, r8 = a.tiles & 7;
+    if (l >= q8 + (x < r8 ? 1 : 0)) return;                  // padding item
+    tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + l;
+  }
+#endif
+  {
+    const int s0 = (int)((int64_t)a.steps * slab_i / a.S);
+    const int s1 = (int)((int64_t)a.steps * (slab_i + 1) / a.S);
+    const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+    const int n0 = tn * DW_T, k0 = tk * DW_T;
+    const int nkt = s1 - s0;                                 // >= 1 (the launcher keeps S <= max(1, steps / 2))
+    const int nunits = 4 * nkt;
+
+    f32x4 acc[2][2][4][2];               // [n-half][k-half][n-tile][k-tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) acc[i][j][p][q] = f32x4{0, 0, 0, 0};
+
+    // scalar offsets of this segment: first token row, tile columns
+    const int sbY = (int)(((int64_t)s0 * DW_BR * a.ldy + n0) * 2);
+    const int sbX = (int)(((int64_t)s0 * DW_BR * a.ldx + k0) * 2);
+    const int stepY = (int)(a.ldy * DW_BR * 2), stepX = (int)(a.ldx * DW_BR * 2);
+
+    int u_issue = 0;
+    // KIND 0 / 3: first / second 64-column halves of the dY tile halves; KIND 1 / 2: first / second 32-column halves of X
+    auto issue_unit = [&](auto kind_c) {
+      constexpr int KIND = decltype(kind_c)::value;
+      constexpr bool isY = KIND == 0 || KIND == 3;
+      constexpr bool second = KIND >= 2;
+      const unsigned dst = lds0 + (u_issue % DW_SLOTS) * DW_UNIT + wid * 2048;
+      const int t = u_issue >> 2;
+      if constexpr (isY) {
+        const int so = sbY + t * stepY + (second ? 128 : 0);
+        dma16(dst, voY[0], so, rsY);
+        dma16(dst + 1024, voY[1], so, rsY);
+      } else {
+        const int so = sbX + t * stepX + (second ? 64 : 0);
+        dma16(dst, voX[0], so, rsX);
+        dma16(dst + 1024, voX[1], so, rsX);
+      }
+      ++u_issue;
+    };
+#define DW_IC(v) std::integral_constant<int, v>()
+
+    bf16x8 Yf[2][4];                     // [k-step][n-tile]   (the n half in use)
+    bf16x8 Xf[2][2][2];                  // [k-half][k-step][k-tile]
+    auto tr8 = [&](const char* p) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * 256));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    auto readY = [&](int unit) {
+      const char* base = lds + (unit % DW_SLOTS) * DW_UNIT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Yf[ks][j] = tr8(base + ks * (32 * 256) + offY[j]);
+    };
+    auto readX = [&](int kh, int unit) {
+      const char* base = lds + (unit % DW_SLOTS) * DW_UNIT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) Xf[kh][ks][i] = tr8(base + ks * (32 * 256) + offX[i]);
+    };
+    auto mma = [&](int nh, int kh) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[nh][kh][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Xf[kh][ks][i], Yf[ks][j], acc[nh][kh][j][i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int g = 0;
+    auto wait_landed = [&]() {
+      int need = g + 2;
+      need = need < nunits - 1 ? need : nunits - 1;
+      const int ok = (u_issue - 1) - need;
+      if (ok == DW_D - 2) dw_wait_steady();
+      else dw_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+    };
+
+    // ---- prologue (see csrc/dense_gemm.hip for the protocol)
+#define DW_PRO(i) if (u_issue < nunits) issue_unit(DW_IC((i) & 3));
+    DW_PRO(0) DW_PRO(1) DW_PRO(2) DW_PRO(3)
+    if constexpr (DW_D > 4) { DW_PRO(4) DW_PRO(5) }
+    if constexpr (DW_D > 6) { DW_PRO(6) DW_PRO(7) }
+#undef DW_PRO
+    {
+      const int ok = (u_issue - 1) - 1;
+      dw_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+    }
+    if (hi) __builtin_amdgcn_s_barrier();
+
+    auto ktile = [&](int t, auto steady_c) {
+      constexpr bool STEADY = decltype(steady_c)::value != 0;
+      const int b0 = 4 * t;
+      auto dma = [&](auto kind_c) {
+        if (STEADY || u_issue < nunits) issue_unit(kind_c);
+      };
+      auto landed = [&]() {
+        if constexpr (STEADY) dw_wait_steady();
+        else wait_landed();
+      };
+      // phase 0: first n half x first k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((0 + DW_D) & 3));
+      readY(b0);
+      readX(0, b0 + 1);
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(0, 0);
+      if (!hi) landed();
+      ++g;
+      // phase 1: first n half x second k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((1 + DW_D) & 3));
+      readX(1, b0 + 2);
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(0, 1);
+      if (!hi) landed();
+      ++g;
+      // phase 2: second n half x second k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((2 + DW_D) & 3));
+      readY(b0 + 3);
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(1, 1);
+      if (!hi) landed();
+      ++g;
+      // phase 3: second n half x first k half
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);
+      dma(DW_IC((3 + DW_D) & 3));
+      __builtin_amdgcn_s_setprio(0);
+      if (hi) landed();
+      __builtin_amdgcn_s_barrier();
+      mma(1, 0);
+      if (!hi) landed();
+      ++g;
+    };
+    const int t_steady = (nunits - 4 - DW_D) >= 0 ? (nunits - 4 - DW_D) / 4 + 1 : 0;
+    int t = 0;
+#pragma unroll 1
+    for (; t < t_steady; ++t) ktile(t, DW_IC(1));
+#pragma unroll 1
+    for (; t < nkt; ++t) ktile(t, DW_IC(0));
+    if (!hi) __builtin_amdgcn_s_barrier();   // re-align the two groups
+    __builtin_amdgcn_s_barrier();            // the ring is idle
+
+    // ---- partial tile: publish, last arriver of the tile reduces (plain stores -> drain -> barrier -> agent release ->
+    // ticket; reducer: agent acquire -> barrier).
+    bool reducer = a.S == 1;
+    if (a.S > 1) {
+      float* slab = a.slabs + ((int64_t)tile * a.S + slab_i) * (DW_T * DW_T);
+      f32x4* sw4 = (f32x4*)slab + (int64_t)wid * 32 * 64 + lane;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sw4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64] = acc[nh][kh][j][i];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* flag = (int*)lds;
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = (old == a.S - 1) ? 1 : 0;
+        if (old == a.S - 1) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
+      }
+      __syncthreads();
+      reducer = flag[0] != 0;
+      __syncthreads();
+      if (reducer) {
+        // fixed order: slab 0 + slab 1 + ... (the reducer's own partial is re-read from its slab)
+        for (int w = 0; w < a.S; ++w) {
+          const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)tile * a.S + w) * (DW_T * DW_T)) + (int64_t)wid * 32 * 64 + lane;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  const f32x4 o = o4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64];
+                  acc[nh][kh][j][i] = w == 0 ? o : acc[nh][kh][j][i] + o;
+                }
+        }
+      }
+    }
+
+    // ---- epilogue: lane (fr, kg) of MFMA tile (n-tile j, k-tile i) holds dW[n = .. + fr][k = .. + 4 kg .. + 3]
+    if (reducer) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wr * 128 + nh * 64 + j * 16 + fr;
+          if (n < a.N) {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int k = k0 + wc * 64 + kh * 32 + i * 16 + kg * 4;
+                if (k < a.K) *(f32x4*)(a.W + (int64_t)n * a.K + k) = acc[nh][kh][j][i];
+              }
+          }
+        }
+    }
+  }
+}
+
+}  // namespace octic
+
+using namespace octic;
+
+extern "C" {
+
+// Row slabs: the items (tiles8 x S) run in ceil(items / CUs) rounds of ceil(steps / S) reduction steps each; every item
+// also pays a fixed prologue + slab epilogue (about 8 steps' worth).  Pick the S with the shortest estimate.
+static int g_tn_slabs_override = 0;
+static int dw_slabs(int tiles, int steps) {
+  if (g_tn_slabs_override > 0) return g_tn_slabs_override <= steps / 2 ? g_tn_slabs_override : (steps / 2 > 0 ? steps / 2 : 1);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    (void)hipGetLastError();
+  }
+  const int tiles8 = (tiles + 7) / 8 * 8;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int S = 1; S <= 16 && S <= steps / 2; ++S) {
+    const int rounds = ((DW_MAP == 1 ? tiles : tiles8) * S + cus - 1) / cus;
+    const double cost = rounds * ((steps + S - 1) / S + (S > 1 ? 8.0 : 2.0));
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+  }
+  return best;
+}
+
+int octic_dbg_dense_wgrad_slabs(int S) {      // developer knob: force the number of row slabs (0 = automatic)
+  const int old = g_tn_slabs_override;
+  g_tn_slabs_override = S;
+  return old;
+}
+
+int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K) {
+  const int tiles = (N / DW_T) * (K / DW_T);
+  const int steps = (M + DW_BR - 1) / DW_BR;
+  const int S = g_tn_slabs_override > 0 ? 16 : dw_slabs(tiles, steps);      // room for any forced value
+  return (int64_t)tiles * S * (DW_T * DW_T) * 4 + 4096;      // [4 KiB tickets (<= 1024 tiles) | slabs]
+}
+
+int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
+                         void* workspace, void* stream) {
+  if (!dY || !X || !dW || !workspace) return OCTIC_ENULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (N % DW_T) || (K % DW_T) || (ldy % 8) || (ldx % 8)) return OCTIC_ESHAPE;
+  if ((N / DW_T) * (K / DW_T) > 1024) return OCTIC_ESHAPE;    // ticket region
+  if ((int64_t)M * ldy * 2 >= (1ll << 31) || (int64_t)M * ldx * 2 >= (1ll << 31)) return OCTIC_ESHAPE;   // 32-bit buffer offsets
+  if ((((uintptr_t)dY) | ((uintptr_t)X) | ((uintptr_t)dW)) & 15) return OCTIC_EALIGN;
+  DwArgs a = {};
+  a.Y = (const bf16*)dY; a.X = (const bf16*)X; a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  a.W = dW;
+  a.tiles_k = K / DW_T;
+  a.tiles = (N / DW_T) * a.tiles_k;
+  a.tiles8 = (a.tiles + 7) / 8 * 8;
+  a.steps = (M + DW_BR - 1) / DW_BR;
+  a.S = dw_slabs(a.tiles, a.steps);
+  a.tickets = (int*)workspace;
+  char* p = (char*)workspace + 4096;         // fixed ticket region: a workspace shared by several shapes keeps its zeros
+  a.slabs = (float*)p;
+  hipStream_t s = (hipStream_t)stream;
+  const int smem = DW_SLOTS * DW_UNIT;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)dense_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+#if DW_MAP == 1
+  dense_tn_kernel<<<(a.tiles * a.S + 255) / 256 * 256, 512, smem, s>>>(a);
+#else
+  dense_tn_kernel<<<a.tiles8 * a.S, 512, smem, s>>>(a);
+#endif
+  return launch_status();
+}
+
+}  // extern "C"

@@ -635,9 +635,19 @@ def _timed_lib(kind, fn, M, N, K):
 WGRAD_SLABS = {(5120, 1280): 4, (1280, 5120): 4, (3840, 1280): 2, (1280, 1280): 2}
 
 
+# Weight-gradient shapes (N, K) that run on csrc/dense_wgrad.hip (dW = dY^T X straight from the row-major operands, f32
+# result, fixed-order slab reduction).  Measured against the library's batched row slabs on one MI355X (tools/bench_tn.py):
+# 5120x1280 262 vs 296 us, 1280x5120 236 vs 246, 3840x1280 168 vs 187; 1280x1280 is a tie (101 vs 100) and stays put.
+WGRAD_HIP = {(5120, 1280), (1280, 5120), (3840, 1280)}
+
+
 def _wgrad_lib(g2, x2):
-    """dW = g^T x (f32 result).  Weight gradients of the standard half stay on the BLAS library."""
+    """dW = g^T x (f32 result): the hand-written TN kernel for the shapes in WGRAD_HIP, else the BLAS library."""
     M, N, K = g2.shape[0], g2.shape[1], x2.shape[1]
+    if ((N, K) in WGRAD_HIP and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+            and g2.stride(1) == 1 and x2.stride(1) == 1 and ops.dense_wgrad_ok(M, N, K)
+            and M * max(g2.stride(0), x2.stride(0)) * 2 < 2 ** 31):
+        return ops.dense_wgrad_tn(g2, x2)
     S = WGRAD_SLABS.get((N, K), 1)
     if S > 1 and M % S == 0 and g2.is_contiguous() and x2.is_contiguous():
         with torch.autocast("cuda", enabled=False):

@@ -217,6 +217,31 @@ def layernorm_bwd(g, x, stats, alpha5, dres, c, want_param_grads=True):
     return dx, dal, dbeta
 
 
+_DW_WS = {}
+
+
+def dense_wgrad_ok(M, N, K):
+    return N % 256 == 0 and K % 256 == 0 and (N // 256) * (K // 256) <= 256 and M > 0
+
+
+def dense_wgrad_tn(dy, x, name=None):
+    """dW[N,K] = dy[M,N]^T @ x[M,K] in f32 on csrc/dense_wgrad.hip."""
+    _require_cuda(dy)
+    M, N = dy.shape
+    K = x.shape[1]
+    if dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != M:
+        raise ValueError("dense_wgrad_tn: operands must be [M,N] / [M,K] row-major")
+    need = int(lib().octic_dense_wgrad_workspace_bytes(M, N, K))
+    ws = _DW_WS.get(dy.device)
+    if ws is None or ws.numel() < need:          # one workspace per device: launches on a stream are serial
+        ws = _DW_WS[dy.device] = torch.zeros(need, dtype=torch.uint8, device=dy.device)
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_wgrad_tn(_p(dy), _p(x), M, N, K, dy.stride(0), x.stride(0), _p(dw), _p(ws), _stream(dy)))
+    KERNEL_TIMER.stop(t, name or f"dense_tn_kernel<{N}x{K}>", 2 * (M * N + M * K) + 4 * N * K, 2.0 * M * N * K)
+    return dw
+
+
 def linear_fwd(xv, w5, bias, yv, M, cin, cout, dtype, out_dtype, ref, resid_v=None, rs=None, rps=1, cs5=None):
     t = KERNEL_TIMER.start()
     check(lib().octic_linear_d8_fwd(ctypes.byref(xv), _arr5(w5), _p(bias), ctypes.byref(yv),

@@ -151,3 +151,32 @@ def test_standard_block_on_dense_hip_matches_library_path():
     for n, a, b, c in zip(names, res[True], res[False], res["default"]):
         close(a, b, 2e-2, f"block {n} (all GEMMs hand-written vs all on the library)")
         close(c, b, 2e-2, f"block {n} (default routing vs all on the library)")
+
+
+# ------------------------------------------------------------------------------------------------ weight gradient (TN)
+WG_SHAPES = [(200, 256, 256), (64, 512, 256), (1000, 256, 768), (16448, 1280, 1280), (16448, 3840, 1280),
+             (16448, 5120, 1280), (16448, 1280, 5120)]
+
+
+@pytest.mark.parametrize("M,N,K", WG_SHAPES)
+def test_dense_wgrad_tn(M, N, K):
+    """dW = dY^T X in f32 vs fp64 matmul of the same bf16 operands (f32 accumulation over M rows: 2e-4 of scale), and
+    bitwise reproducibility (fixed-order reduction of the stream-K partial tiles)."""
+    o = ops()
+    dy, x = rnd((M, N), 51), rnd((M, K), 52)
+    dw = o.dense_wgrad_tn(dy, x)
+    want = dy.double().t() @ x.double()
+    close(dw, want, 2e-4, f"wgrad {M}x{N}x{K}")
+    dw2 = o.dense_wgrad_tn(dy, x)
+    assert torch.equal(dw, dw2), "wgrad not bitwise reproducible"
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (16448, 1280, 1280), (16448, 5120, 1280)])
+def test_dense_wgrad_tn_integer_operands_exact(M, N, K):
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    dy = torch.randint(-2, 3, (M, N), generator=g, device=DEV).to(torch.bfloat16)
+    x = torch.randint(-3, 4, (M, K), generator=g, device=DEV).to(torch.bfloat16)
+    dw = o.dense_wgrad_tn(dy, x)
+    want = dy.double().t() @ x.double()          # |sum| <= 6 * 16448 < 2^24: exact in f32
+    assert torch.equal(dw.double(), want), f"{int((dw.double() != want).sum())} wrong elements"
