@@ -637,8 +637,8 @@ WGRAD_SLABS = {(5120, 1280): 4, (1280, 5120): 4, (3840, 1280): 2, (1280, 1280): 
 
 # Weight-gradient shapes (N, K) that run on csrc/dense_wgrad.hip (dW = dY^T X straight from the row-major operands, f32
 # result, fixed-order slab reduction).  Measured against the library's batched row slabs on one MI355X (tools/bench_tn.py):
-# 5120x1280 262 vs 296 us, 1280x5120 236 vs 246, 3840x1280 168 vs 187; 1280x1280 is a tie (101 vs 100) and stays put.
-WGRAD_HIP = {(5120, 1280), (1280, 5120), (3840, 1280)}
+# 5120x1280 224-234 vs 296 us, 1280x5120 211 vs 246, 3840x1280 156 vs 187, 1280x1280 93 vs 100.
+WGRAD_HIP = {(5120, 1280), (1280, 5120), (3840, 1280), (1280, 1280)}
 
 
 def _wgrad_lib(g2, x2):
