@@ -119,7 +119,9 @@ extern "C" void* octic_dbg_dense_trace(void) {
 // Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, one v_exp + one v_rcp + 6 fma) is far inside the bf16 output's 2^-9.
 __device__ inline float dg_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  // v_rcp_f32 (1 ulp): __frcp_rn / 1.0f/x expand to the IEEE division sequence (div_scale x2, rcp, 4 fma, div_fmas,
+  // div_fixup) - ten instructions per element in a VALU-bound epilogue
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
