@@ -317,14 +317,17 @@ def main():
             # `roofline` = the kernel with the largest total time in the timed steps.  Library GEMMs are ranked the way a
             # profiler sees them - per operation kind (all weight-gradient shapes run the same hipBLASLt kernel family),
             # not split by shape - so a 10 % library family is not hidden behind a 6 % hand-written kernel.
-            cands = {n: a for n, a in agg.items() if not n.startswith("library_gemm")}
+            cands = {n: a for n, a in agg.items() if not n.startswith(("library_gemm", "dense_tn_kernel<"))}
+            tn = [n for n in agg if n.startswith("dense_tn_kernel<")]
+            if tn:    # one kernel symbol (csrc/dense_wgrad.hip) over the four weight-gradient shapes
+                cands["dense_tn_kernel<wgrad, all shapes>"] = merged(tn, "dense_tn_kernel<wgrad, all shapes>")
             for kind in ("fwd", "dgrad", "wgrad"):
                 names = [n for n in agg if n.startswith(f"library_gemm<{kind} ")]
                 if names:
                     cands[f"library_gemm<{kind}, all shapes>"] = merged(names, f"library_gemm<{kind}, all shapes>")
             top = max(cands.values(), key=lambda a: a["total_us"])
             line["roofline"] = roof(top)
-            hand = [a for n, a in agg.items() if not n.startswith("library_gemm")]
+            hand = [a for n, a in cands.items() if not n.startswith("library_gemm")]
             if hand:
                 kh = max(hand, key=lambda a: a["total_us"])
                 if kh["name"] != top["name"]:

@@ -158,10 +158,16 @@ __global__ __launch_bounds__(256, PK ? 4 : 2) void ln_fwd_kernel(View x, View y,
 //   dx_s = (ghat_s - mean(ghat_s))*rstd + w_s*dS*2*(x_s-mu_s)/n_s       (w = 1 | 1/2, n = c | 2c)
 // Parameter partials: dalpha += g*xhat, dbeta += g, accumulated per wave in registers over its
 // rows, then reduced over the block's 4 waves through LDS into partials[blk][2][8c].
-constexpr int kLnBwdWaves = 8;   // 512 slabs x 8 waves = 4 waves per SIMD: enough rows in flight to cover HBM latency
+#ifndef OCTIC_LNBWD_WAVES
+#define OCTIC_LNBWD_WAVES 8
+#endif
+#ifndef OCTIC_LNBWD_OCC
+#define OCTIC_LNBWD_OCC 4
+#endif
+constexpr int kLnBwdWaves = OCTIC_LNBWD_WAVES;   // 512 slabs x 8 waves = 4 waves per SIMD: enough rows in flight to cover HBM latency
 
 template <typename TG, int NV, bool PK>
-__global__ __launch_bounds__(kLnBwdWaves * 64, PK ? 4 : 2) void ln_bwd_kernel(View g, View x, const float* stats, const float* a0,
+__global__ __launch_bounds__(kLnBwdWaves * 64, PK ? OCTIC_LNBWD_OCC : 2) void ln_bwd_kernel(View g, View x, const float* stats, const float* a0,
                                                      const float* a1, const float* a2, const float* a3,
                                                      const float* a4, View dres, int has_dres, View dx,
                                                      float* partials, int64_t M, int c) {
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256, 4) void ln_fwd_g8_kernel(const float* __restri
 // and the d beta partials (A1 lanes only) live in LDS - each lane re-reads / updates only its own addresses.
 // LDS: [2][8c] slab image | [8c] alpha by packed column | [waves][c] d beta partials.
 template <typename TG, int NV>
-__global__ __launch_bounds__(kLnBwdWaves * 64, 4) void ln_bwd_g8_kernel(
+__global__ __launch_bounds__(kLnBwdWaves * 64, OCTIC_LNBWD_OCC) void ln_bwd_g8_kernel(
     const TG* __restrict__ g, int64_t ldg, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
     const float* a0, const float* a1, const float* a2, const float* a3, const float* a4,
     const float* __restrict__ dres, int64_t ldr, float* __restrict__ dx, int64_t ldd, float* __restrict__ partials,

@@ -34,14 +34,37 @@ to_2tuple = _ntuple(2)
 drop_path_mask_source = None
 
 
+# Masks are drawn DROP_PATH_POOL at a time (one bernoulli_ + one scale launch per pool instead of two launches per mask:
+# a ViT-H step uses 64 masks, i.e. 128 launches of ~4.5 us each).  Same distribution as one draw per call; the order in
+# which torch's generator is consumed differs from the reference's per-call draws (the parity tests inject masks through
+# drop_path_mask_source).  A captured step refills at the same points on every replay.
+DROP_PATH_POOL = 64
+_mask_pool = {}
+
+
+def reset_drop_path_pool():
+    """Start of a model forward: the next mask triggers a fresh draw (so a captured step always contains its draw and
+    every replay gets new masks)."""
+    for pool in _mask_pool.values():
+        pool[1] = DROP_PATH_POOL
+
+
 def _drop_path_mask(B, drop_prob, device, scale_by_keep=True):
     keep = 1.0 - drop_prob
     if drop_path_mask_source is not None:
         m = drop_path_mask_source(B, keep, device)
-    else:
-        m = torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep)
-    if keep > 0.0 and scale_by_keep:
-        m = m / keep
+        if keep > 0.0 and scale_by_keep:
+            m = m / keep
+        return m
+    key = (str(device), int(B), float(keep), bool(scale_by_keep))
+    pool = _mask_pool.get(key)
+    if pool is None or pool[1] >= DROP_PATH_POOL:
+        t = torch.empty(DROP_PATH_POOL, B, device=device, dtype=torch.float32).bernoulli_(keep)
+        if keep > 0.0 and scale_by_keep:
+            t = t / keep
+        pool = _mask_pool[key] = [t, 0]
+    m = pool[0][pool[1]]
+    pool[1] += 1
     return m
 
 

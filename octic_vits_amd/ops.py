@@ -64,7 +64,7 @@ class KernelTimer:
     def bound_of(name):
         """Roofline that bounds a kernel family: the attention kernels are MFMA/VALU-bound (q,k,v,o are read once,
         14 T^2 hd flops per head), every other kernel of the engine moves more bytes than it can compute on."""
-        return "mfma" if name.startswith(("attn_", "dense_nt_kernel", "library_gemm")) else "hbm"
+        return "mfma" if name.startswith(("attn_", "dense_nt_kernel", "dense_tn_kernel", "library_gemm")) else "hbm"
 
     def dominant(self, bound=None):
         agg = [a for a in self._agg().values() if bound is None or self.bound_of(a["name"]) == bound]

@@ -19,6 +19,7 @@ NAMES = [
     (r"linear_d8_ring_kernel(IDF16bfLi1E|<__bf16, float, 1|<bool _Accum, 1)", "linear_d8_ring_kernel<bf16,f32,1>"),
     (r"wgrad_ring_kernel", "wgrad_ring_kernel<bf16>"),
     (r"attn_fwd(_persist)?_kernel|a80.{0,4}fwd(_os)?_kernel|fwd_os_kernel", "attn_fwd_kernel"),
+    (r"dense_tn_kernel", "dense_tn_kernel<wgrad, all shapes>"),
     (r"dense_nt_kernel(ILi0E|<0>)", "dense_nt_kernel<0>"),
     (r"dense_nt_kernel(ILi1E|<1>)", "dense_nt_kernel<1>"),
     (r"heads_permute_kernel", "heads_permute_kernel<bf16>"),

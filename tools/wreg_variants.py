@@ -20,6 +20,12 @@ for name, flags in specs:
 for r in range(rounds):
     for name, so in libs:
         env = dict(os.environ, OCTIC_LIB=so)
+        if os.environ.get("RUN"):
+            res = subprocess.run([sys.executable] + os.environ["RUN"].split(), env=env, capture_output=True, text=True)
+            flt = os.environ.get("GREP", "")
+            out = [ln for ln in res.stdout.splitlines() if flt in ln]
+            print(f"round {r} {name:12s} " + " | ".join(" ".join(ln.split()) for ln in out) + (res.stderr[-300:] if res.returncode else ""), flush=True)
+            continue
         if name.startswith("trace"):
             if r == 0:
                 res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ring_trace.py" if SRC == "gemm" else "wreg_trace.py")] + os.environ.get("TRACE_ARGS", "").split(), env=env, capture_output=True, text=True)
