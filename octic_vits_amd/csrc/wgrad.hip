@@ -543,7 +543,10 @@ int octic_linear_d8_wgrad_splits(int64_t M, int cin, int cout) {
   const int bw = 32 * pick_tt(a);
   const int tiles_e = ((2 * cin + bw - 1) / bw) * ((2 * cout + bw - 1) / bw);
   const int tiles_1 = 4 * ((cin + bw - 1) / bw) * ((cout + bw - 1) / bw);
-  constexpr double target = 512.0;
+#ifndef OCTIC_WG_TARGET
+#define OCTIC_WG_TARGET 512.0
+#endif
+  constexpr double target = OCTIC_WG_TARGET;
   int s = (int)((target / (tiles_e + 0.5 * tiles_1)) + 0.5);
   const int64_t max_by_rows = (2 * M + 255) / 256;
   if (s > max_by_rows) s = (int)max_by_rows;

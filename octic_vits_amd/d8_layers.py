@@ -34,25 +34,33 @@ to_2tuple = _ntuple(2)
 drop_path_mask_source = None
 
 
-# Masks are drawn DROP_PATH_POOL at a time (one bernoulli_ + one scale launch per pool instead of two launches per mask:
-# a ViT-H step uses 64 masks, i.e. 128 launches of ~4.5 us each).  Same distribution as one draw per call; the order in
-# which torch's generator is consumed differs from the reference's per-call draws (the parity tests inject masks through
-# drop_path_mask_source).  A captured step refills at the same points on every replay.
+# Inside a model forward (OcticVisionTransformer.forward_features arms the pool) masks are drawn DROP_PATH_POOL at a time:
+# one bernoulli_ + one scale launch per pool instead of two launches per mask (a ViT-H step uses 64 masks = 128 launches
+# of ~4.5 us).  Same distribution as one draw per call; the order in which torch's generator is consumed differs from
+# the reference's per-call draws (the parity tests inject masks through drop_path_mask_source).  The pool is re-drawn at
+# the start of every forward, so a seeded forward is reproducible and a captured step contains its own draw.  Blocks
+# called on their own (pool not armed) draw per call as before.
 DROP_PATH_POOL = 64
 _mask_pool = {}
+_pool_armed = False
 
 
-def reset_drop_path_pool():
-    """Start of a model forward: the next mask triggers a fresh draw (so a captured step always contains its draw and
-    every replay gets new masks)."""
-    for pool in _mask_pool.values():
-        pool[1] = DROP_PATH_POOL
+def arm_drop_path_pool(on=True):
+    """on: start of a model forward (the next mask triggers a fresh pooled draw); off: end of it."""
+    global _pool_armed
+    _pool_armed = on
+    if on:
+        for pool in _mask_pool.values():
+            pool[1] = DROP_PATH_POOL
 
 
 def _drop_path_mask(B, drop_prob, device, scale_by_keep=True):
     keep = 1.0 - drop_prob
-    if drop_path_mask_source is not None:
-        m = drop_path_mask_source(B, keep, device)
+    if drop_path_mask_source is not None or not _pool_armed:
+        if drop_path_mask_source is not None:
+            m = drop_path_mask_source(B, keep, device)
+        else:
+            m = torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0.0 and scale_by_keep:
             m = m / keep
         return m

@@ -101,8 +101,14 @@ class OcticVisionTransformer(nn.Module):
         return torch.cat([t[0].flatten(), t[1].flatten(), t[2].flatten(), t[3].flatten(), t[4].flatten()])
 
     def forward_features(self, x):
-        from .d8_layers import reset_drop_path_pool
-        reset_drop_path_pool()
+        from .d8_layers import arm_drop_path_pool
+        arm_drop_path_pool(True)
+        try:
+            return self._forward_features(x)
+        finally:
+            arm_drop_path_pool(False)
+
+    def _forward_features(self, x):
         B, C_in, H, W = x.shape
         if self.num_register_tokens > 0:
             raise RuntimeError("num_register_tokens > 0 is broken in the reference (model.py:183-191) and unsupported")

@@ -117,9 +117,9 @@ def _drop_path_scale(dp, x):
     """Per-sample stochastic-depth factor [B] drawn exactly like DropPath.forward draws its mask, or None."""
     if not isinstance(dp, DropPath) or dp.drop_prob == 0. or not dp.training:
         return None
-    if x.dtype == torch.float32:                # the pooled draw of d8_layers (one launch pair per 64 masks)
-        from .d8_layers import _drop_path_mask
-        return _drop_path_mask(x.shape[0], dp.drop_prob, x.device, dp.scale_by_keep)
+    from . import d8_layers as _L
+    if x.dtype == torch.float32 and _L._pool_armed:       # the pooled draw (one launch pair per 64 masks)
+        return _L._drop_path_mask(x.shape[0], dp.drop_prob, x.device, dp.scale_by_keep)
     keep = 1 - dp.drop_prob
     mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
     if keep > 0.0 and dp.scale_by_keep:
