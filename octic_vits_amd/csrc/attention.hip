@@ -28,112 +28,172 @@ inline int attn_rsv(int dp) { int r = dp * 2; return ((r / 4) % 32 == 0) ? r + 6
 #define OCTIC_STAGE_BATCH 5
 #endif
 constexpr int kStageBatch = OCTIC_STAGE_BATCH;
+// No integer division anywhere in here: the first version turned a linear item index into (row, chunk) with `q / wc`
+// (and `q / T` for the packed pieces) twice per item - ~28 divisions of ~30 VALU instructions per thread; the s_memtime
+// timeline showed the staging at 12-13 k cycles per image pair (HALF of the backward kernels), VALU-bound, not memory-bound.
+// Now a thread owns chunk column tid & 15 and walks rows (wc <= 16 chunks per image row).
 __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA, int64_t stA, int kcA, int wcA,
                                           char* imgB, int rsB, const bf16* srcB, int64_t stB, int kcB, int wcB,
                                           int T, int Tp, int tid, int nthr, const HeadMap mA = HeadMap{0, 0},
                                           const HeadMap mB = HeadMap{0, 0}) {
+  const int c = tid & 15, t0 = tid >> 4, tstep = nthr >> 4;
   if (mA.cv != 0) {
     // Packed rows: stage by PIECES - a thread fetches one whole piece (20 bytes of a one-dimensional irrep: 16 + 4, or
     // 40 bytes of an E row: 16 + 16 + 8) and spreads it over the row image's groups.  One cache-line request per
-    // piece instead of one per 16-byte group (6 instead of 16 per row: with one request per group the staging phases
-    // of the backward kernels doubled).  Work items are ordered [piece][row], so a wave never mixes the two piece kinds.
+    // piece instead of one per 16-byte group (6 instead of 16 per row).
     // pads first: rows >= T, and groups >= hd / 8 of every row
-    for (int q = tid; q < Tp * (wcA > wcB ? wcA : wcB); q += nthr) {
-      const int tA = q / wcA, cA = q - tA * wcA, tB = q / wcB, cB = q - tB * wcB;
-      if (tA < Tp && (tA >= T || cA >= kcA)) *(u32x4*)(imgA + (size_t)tA * rsA + cA * 16) = u32x4{0, 0, 0, 0};
-      if (tB < Tp && (tB >= T || cB >= kcB)) *(u32x4*)(imgB + (size_t)tB * rsB + cB * 16) = u32x4{0, 0, 0, 0};
+    for (int t = t0; t < Tp; t += tstep) {
+      if (c < wcA && (t >= T || c >= kcA)) *(u32x4*)(imgA + (size_t)t * rsA + c * 16) = u32x4{0, 0, 0, 0};
+      if (c < wcB && (t >= T || c >= kcB)) *(u32x4*)(imgB + (size_t)t * rsB + c * 16) = u32x4{0, 0, 0, 0};
     }
-    constexpr int PB = 3;                         // pieces in flight per thread and image
-    for (int base = 0; base < 4 * T; base += PB * nthr) {          // one-dimensional pieces: p = item / T
-      u32x4 a4[PB], b4[PB];
-      unsigned a1[PB], b1[PB];
-#pragma unroll
-      for (int it = 0; it < PB; ++it) {
-        const int q = base + it * nthr + tid;
-        if (q < 4 * T) {
-          const int pz = q / T, t = q - pz * T;
-          const bf16* ra = srcA + (int64_t)t * stA + pz * mA.cv + mA.bs;
-          const bf16* rb = srcB + (int64_t)t * stB + pz * mB.cv + mB.bs;
-          a4[it] = *(const u32x4_u*)ra; a1[it] = *(const unsigned*)(ra + 8);
-          b4[it] = *(const u32x4_u*)rb; b1[it] = *(const unsigned*)(rb + 8);
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < PB; ++it) {
-        const int q = base + it * nthr + tid;
-        if (q < 4 * T) {
-          const int pz = q / T, t = q - pz * T;
-          char* la = imgA + (size_t)t * rsA;
-          char* lb = imgB + (size_t)t * rsB;
-          *(u32x4*)(la + pz * 16) = a4[it]; *(unsigned*)(la + 8 * 16 + pz * 4) = a1[it];
-          *(u32x4*)(lb + pz * 16) = b4[it]; *(unsigned*)(lb + 8 * 16 + pz * 4) = b1[it];
-        }
-      }
-    }
-    for (int base = 0; base < 2 * T; base += 2 * nthr) {             // E pieces: 16 + 16 + 8 bytes
-      u32x4 a4[2][2], b4[2][2];
+    // a thread takes row t = tid, tid + nthr, ...; all six pieces of the row of both images are requested before the
+    // first LDS write
+    for (int t = tid; t < T; t += nthr) {
+      u32x4 a4[4], b4[4], ae[2][2], be[2][2];
+      unsigned a1[4], b1[4];
       u32x2 a2[2], b2[2];
+      const bf16* rowa = srcA + (int64_t)t * stA;
+      const bf16* rowb = srcB + (int64_t)t * stB;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int q = base + it * nthr + tid;
-        if (q < 2 * T) {
-          const int pz = q / T, t = q - pz * T;
-          const bf16* ra = srcA + (int64_t)t * stA + (4 + 2 * pz) * mA.cv + 2 * mA.bs;
-          const bf16* rb = srcB + (int64_t)t * stB + (4 + 2 * pz) * mB.cv + 2 * mB.bs;
-          a4[it][0] = *(const u32x4_u*)ra; a4[it][1] = *(const u32x4_u*)(ra + 8);
-          b4[it][0] = *(const u32x4_u*)rb; b4[it][1] = *(const u32x4_u*)(rb + 8);
-          const u32x2_u ta = *(const u32x2_u*)(ra + 16), tb = *(const u32x2_u*)(rb + 16);
-          a2[it] = u32x2{ta[0], ta[1]}; b2[it] = u32x2{tb[0], tb[1]};
-        }
+      for (int pz = 0; pz < 4; ++pz) {
+        const bf16* ra = rowa + pz * mA.cv + mA.bs;
+        const bf16* rb = rowb + pz * mB.cv + mB.bs;
+        a4[pz] = *(const u32x4_u*)ra; a1[pz] = *(const unsigned*)(ra + 8);
+        b4[pz] = *(const u32x4_u*)rb; b1[pz] = *(const unsigned*)(rb + 8);
       }
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int q = base + it * nthr + tid;
-        if (q < 2 * T) {
-          const int pz = q / T, t = q - pz * T;
-          char* la = imgA + (size_t)t * rsA;
-          char* lb = imgB + (size_t)t * rsB;
-          *(u32x4*)(la + (4 + 2 * pz) * 16) = a4[it][0]; *(u32x4*)(la + (5 + 2 * pz) * 16) = a4[it][1];
-          *(u32x2*)(la + 9 * 16 + pz * 8) = a2[it];
-          *(u32x4*)(lb + (4 + 2 * pz) * 16) = b4[it][0]; *(u32x4*)(lb + (5 + 2 * pz) * 16) = b4[it][1];
-          *(u32x2*)(lb + 9 * 16 + pz * 8) = b2[it];
-        }
+      for (int pz = 0; pz < 2; ++pz) {
+        const bf16* ra = rowa + (4 + 2 * pz) * mA.cv + 2 * mA.bs;
+        const bf16* rb = rowb + (4 + 2 * pz) * mB.cv + 2 * mB.bs;
+        ae[pz][0] = *(const u32x4_u*)ra; ae[pz][1] = *(const u32x4_u*)(ra + 8);
+        be[pz][0] = *(const u32x4_u*)rb; be[pz][1] = *(const u32x4_u*)(rb + 8);
+        const u32x2_u ta = *(const u32x2_u*)(ra + 16), tb = *(const u32x2_u*)(rb + 16);
+        a2[pz] = u32x2{ta[0], ta[1]}; b2[pz] = u32x2{tb[0], tb[1]};
+      }
+      char* la = imgA + (size_t)t * rsA;
+      char* lb = imgB + (size_t)t * rsB;
+#pragma unroll
+      for (int pz = 0; pz < 4; ++pz) {
+        *(u32x4*)(la + pz * 16) = a4[pz]; *(unsigned*)(la + 8 * 16 + pz * 4) = a1[pz];
+        *(u32x4*)(lb + pz * 16) = b4[pz]; *(unsigned*)(lb + 8 * 16 + pz * 4) = b1[pz];
+      }
+#pragma unroll
+      for (int pz = 0; pz < 2; ++pz) {
+        *(u32x4*)(la + (4 + 2 * pz) * 16) = ae[pz][0]; *(u32x4*)(la + (5 + 2 * pz) * 16) = ae[pz][1];
+        *(u32x2*)(la + 9 * 16 + pz * 8) = a2[pz];
+        *(u32x4*)(lb + (4 + 2 * pz) * 16) = be[pz][0]; *(u32x4*)(lb + (5 + 2 * pz) * 16) = be[pz][1];
+        *(u32x2*)(lb + 9 * 16 + pz * 8) = b2[pz];
       }
     }
     return;
   }
   // wc = chunks written per row (>= kc: the extra ones are zeros), kc = chunks that exist in the source row
-  const int totA = Tp * wcA, totB = Tp * wcB;
-  const int tot = totA > totB ? totA : totB;
-  for (int base = 0; base < tot; base += kStageBatch * nthr) {
+  for (int base = t0; base < Tp; base += kStageBatch * tstep) {
     u32x4 va[kStageBatch], vb[kStageBatch];
 #pragma unroll
     for (int it = 0; it < kStageBatch; ++it) {
-      const int q = base + it * nthr + tid;
+      const int t = base + it * tstep;
       va[it] = u32x4{0, 0, 0, 0};
       vb[it] = u32x4{0, 0, 0, 0};
-      if (q < totA) {
-        const int t = q / wcA, c = q - t * wcA;
-        if (t < T && c < kcA) va[it] = hm_load16(srcA + (int64_t)t * stA, c, mA);
-      }
-      if (q < totB) {
-        const int t = q / wcB, c = q - t * wcB;
-        if (t < T && c < kcB) vb[it] = hm_load16(srcB + (int64_t)t * stB, c, mB);
-      }
+      if (t < T && c < kcA) va[it] = hm_load16(srcA + (int64_t)t * stA, c, mA);
+      if (t < T && c < kcB) vb[it] = hm_load16(srcB + (int64_t)t * stB, c, mB);
     }
 #pragma unroll
     for (int it = 0; it < kStageBatch; ++it) {
-      const int q = base + it * nthr + tid;
-      if (q < totA) {
-        const int t = q / wcA, c = q - t * wcA;
-        *(u32x4*)(imgA + (size_t)t * rsA + c * 16) = va[it];
-      }
-      if (q < totB) {
-        const int t = q / wcB, c = q - t * wcB;
-        *(u32x4*)(imgB + (size_t)t * rsB + c * 16) = vb[it];
-      }
+      const int t = base + it * tstep;
+      if (t < Tp && c < wcA) *(u32x4*)(imgA + (size_t)t * rsA + c * 16) = va[it];
+      if (t < Tp && c < wcB) *(u32x4*)(imgB + (size_t)t * rsB + c * 16) = vb[it];
     }
   }
+}
+
+// ---- the same staging split into "request" and "write to LDS", so that a kernel can have EVERY global load of its
+// prologue in flight at once.  The backward kernels need two image pairs one after the other (the wave's own rows come
+// out of the first pair, then the pair is overwritten); staged pair by pair, each in two batches, the prologue was a
+// chain of five dependent memory round trips of ~3 us under load: 25-29 k of a workgroup's 50 k cycles
+// (tools/attn_trace.py).  Register cost: 72 VGPRs per pair on plain rows, 80 on packed rows - free in a prologue.
+constexpr int kStageRows = 9;      // rows per thread: Tp / (threads / 16) = 8, or 9 for nine tiles on eight waves
+struct StagePlain { u32x4 a[kStageRows], b[kStageRows]; };
+__device__ __forceinline__ void stage_request(StagePlain& R, const bf16* srcA, int64_t stA, int kcA, const bf16* srcB,
+                                              int64_t stB, int kcB, int T, int tid, int nthr) {
+  const int c = tid & 15, t0 = tid >> 4, tstep = nthr >> 4;
+#pragma unroll
+  for (int it = 0; it < kStageRows; ++it) {
+    const int t = t0 + it * tstep;
+    R.a[it] = u32x4{0, 0, 0, 0};
+    R.b[it] = u32x4{0, 0, 0, 0};
+    if (t < T && c < kcA) R.a[it] = *(const u32x4*)(srcA + (int64_t)t * stA + c * 8);
+    if (t < T && c < kcB) R.b[it] = *(const u32x4*)(srcB + (int64_t)t * stB + c * 8);
+  }
+}
+__device__ __forceinline__ void stage_write(const StagePlain& R, char* imgA, int rsA, int wcA, char* imgB, int rsB, int wcB,
+                                            int Tp, int tid, int nthr) {
+  const int c = tid & 15, t0 = tid >> 4, tstep = nthr >> 4;
+#pragma unroll
+  for (int it = 0; it < kStageRows; ++it) {
+    const int t = t0 + it * tstep;
+    if (t < Tp && c < wcA) *(u32x4*)(imgA + (size_t)t * rsA + c * 16) = R.a[it];
+    if (t < Tp && c < wcB) *(u32x4*)(imgB + (size_t)t * rsB + c * 16) = R.b[it];
+  }
+}
+// packed rows: a thread owns row tid (T <= threads in every backward launch) and fetches its six pieces per image
+struct StagePacked {
+  u32x4 a4[4], b4[4], ae[2][2], be[2][2];
+  unsigned a1[4], b1[4];
+  u32x2 a2[2], b2[2];
+};
+__device__ __forceinline__ void stage_request(StagePacked& R, const bf16* srcA, int64_t stA, const bf16* srcB, int64_t stB,
+                                              int T, int tid, const HeadMap mA, const HeadMap mB) {
+  const int t = tid < T ? tid : T - 1;
+  const bf16* rowa = srcA + (int64_t)t * stA;
+  const bf16* rowb = srcB + (int64_t)t * stB;
+#pragma unroll
+  for (int pz = 0; pz < 4; ++pz) {
+    const bf16* ra = rowa + pz * mA.cv + mA.bs;
+    const bf16* rb = rowb + pz * mB.cv + mB.bs;
+    R.a4[pz] = *(const u32x4_u*)ra; R.a1[pz] = *(const unsigned*)(ra + 8);
+    R.b4[pz] = *(const u32x4_u*)rb; R.b1[pz] = *(const unsigned*)(rb + 8);
+  }
+#pragma unroll
+  for (int pz = 0; pz < 2; ++pz) {
+    const bf16* ra = rowa + (4 + 2 * pz) * mA.cv + 2 * mA.bs;
+    const bf16* rb = rowb + (4 + 2 * pz) * mB.cv + 2 * mB.bs;
+    R.ae[pz][0] = *(const u32x4_u*)ra; R.ae[pz][1] = *(const u32x4_u*)(ra + 8);
+    R.be[pz][0] = *(const u32x4_u*)rb; R.be[pz][1] = *(const u32x4_u*)(rb + 8);
+    const u32x2_u ta = *(const u32x2_u*)(ra + 16), tb = *(const u32x2_u*)(rb + 16);
+    R.a2[pz] = u32x2{ta[0], ta[1]}; R.b2[pz] = u32x2{tb[0], tb[1]};
+  }
+}
+__device__ __forceinline__ void stage_write(const StagePacked& R, char* imgA, int rsA, int kcA, int wcA, char* imgB, int rsB,
+                                            int kcB, int wcB, int T, int Tp, int tid, int nthr) {
+  const int c = tid & 15;
+  for (int t = tid >> 4; t < Tp; t += nthr >> 4) {       // pads: rows >= T, and groups >= hd / 8 of every row
+    if (c < wcA && (t >= T || c >= kcA)) *(u32x4*)(imgA + (size_t)t * rsA + c * 16) = u32x4{0, 0, 0, 0};
+    if (c < wcB && (t >= T || c >= kcB)) *(u32x4*)(imgB + (size_t)t * rsB + c * 16) = u32x4{0, 0, 0, 0};
+  }
+  if (tid < T) {
+    char* la = imgA + (size_t)tid * rsA;
+    char* lb = imgB + (size_t)tid * rsB;
+#pragma unroll
+    for (int pz = 0; pz < 4; ++pz) {
+      *(u32x4*)(la + pz * 16) = R.a4[pz]; *(unsigned*)(la + 8 * 16 + pz * 4) = R.a1[pz];
+      *(u32x4*)(lb + pz * 16) = R.b4[pz]; *(unsigned*)(lb + 8 * 16 + pz * 4) = R.b1[pz];
+    }
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      *(u32x4*)(la + (4 + 2 * pz) * 16) = R.ae[pz][0]; *(u32x4*)(la + (5 + 2 * pz) * 16) = R.ae[pz][1];
+      *(u32x2*)(la + 9 * 16 + pz * 8) = R.a2[pz];
+      *(u32x4*)(lb + (4 + 2 * pz) * 16) = R.be[pz][0]; *(u32x4*)(lb + (5 + 2 * pz) * 16) = R.be[pz][1];
+      *(u32x2*)(lb + 9 * 16 + pz * 8) = R.b2[pz];
+    }
+  }
+}
+__device__ __forceinline__ float dot8(const u32x4 x, const u32x4 y) {
+  const bf16x8 a = __builtin_bit_cast(bf16x8, x), b = __builtin_bit_cast(bf16x8, y);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)b[j];
+  return s;
 }
 
 // ---- work split ------------------------------------------------------------------------------------------------
@@ -755,12 +815,91 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   ATRACE(1, 0);
   DqRows<KS> mine, shared;                          // the shared tile's rows are fetched up front too
   const HeadMaps hm = head_maps(a, h);
-  load_dq_rows<KS>(mine, a, in_off, o_off, stat_off, wid, lane, hm);
-  if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane, hm);
-  stage_two(Ks, rs, a.k + in_off, a.sT, hd / 8, hd / 8, Vs, rs, a.v + in_off, a.sT, hd / 8, hd / 8, T, Tp, tid,
-            blockDim.x, hm.k, hm.v);
-  finish_dq_rows<KS>(mine, a, stat_off, wid, lane, true);
-  if (nt != W) finish_dq_rows<KS>(shared, a, stat_off, W, lane, wid == 0);
+  // Prologue in ONE memory round trip: Q, dO, O, K and V of the head are all requested before anything is used.
+  //  * the wave's own 32 query rows (Q, dO fragments; delta = <dO, O>) come out of LDS images of Q and dO staged with
+  //    row-contiguous requests, not from fragment-shaped global loads (lane (r, half) taking 16 bytes of row r = 32
+  //    partial lines per instruction, 45 instructions per wave);
+  //  * delta: the thread that stages chunk (row, c) of dO also holds chunk (row, c) of O: partial dot products -> LDS;
+  //  * the images are then overwritten with K and V, which have been waiting in registers.
+  // The shared ninth tile has one real row: its clamped fragment loads touch two lines.
+  float* part = (float*)(smem + (size_t)2 * Tp * rs);          // [Tp][hd / 8] delta partials
+  const int kc = hd / 8;
+  if (hm.q.cv == 0) {
+    StagePlain qd, kv;
+    u32x4 oo[kStageRows];
+    const int c = tid & 15, t0 = tid >> 4, tstep = blockDim.x >> 4;
+    stage_request(qd, a.q + in_off, a.sT, kc, a.dout + o_off, a.oT, kc, T, tid, blockDim.x);
+#pragma unroll
+    for (int it = 0; it < kStageRows; ++it) {
+      const int t = t0 + it * tstep;
+      oo[it] = u32x4{0, 0, 0, 0};
+      if (t < T && c < kc) oo[it] = *(const u32x4*)(a.o + o_off + (int64_t)t * a.oT + c * 8);
+    }
+    stage_request(kv, a.k + in_off, a.sT, kc, a.v + in_off, a.sT, kc, T, tid, blockDim.x);
+    stage_write(qd, Ks, rs, kc, Vs, rs, kc, Tp, tid, blockDim.x);
+#pragma unroll
+    for (int it = 0; it < kStageRows; ++it) {
+      const int t = t0 + it * tstep;
+      if (t < T && c < kc) part[t * kc + c] = dot8(qd.b[it], oo[it]);
+    }
+    __syncthreads();
+    if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane, hm);   // (the staging registers are free now)
+    {
+      const int qi = wid * 32 + r, qc = qi < T ? qi : T - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        mine.qf[ks] = *(const bf16x8*)(Ks + (size_t)qc * rs + (2 * ks + half) * 16);
+        mine.dof[ks] = *(const bf16x8*)(Vs + (size_t)qc * rs + (2 * ks + half) * 16);
+      }
+      mine.lse = a.lse[stat_off + qc];
+      float delta = 0.f;
+      for (int cc = 0; cc < kc; ++cc) delta += part[qc * kc + cc];
+      mine.delta = delta;
+      if (qi < T && half == 0) a.delta[stat_off + qi] = delta;
+    }
+    __syncthreads();                                 // every wave has its fragments: the images may be overwritten
+    stage_write(kv, Ks, rs, kc, Vs, rs, kc, Tp, tid, blockDim.x);
+    if (nt != W) finish_dq_rows<KS>(shared, a, stat_off, W, lane, wid == 0);
+  } else {
+    StagePacked qd, kv, oo;                          // oo.a*: the O row of this thread (its b half is unused)
+    stage_request(qd, a.q + in_off, a.sT, a.dout + o_off, a.oT, T, tid, hm.q, hm.o);
+    stage_request(oo, a.o + o_off, a.oT, a.o + o_off, a.oT, T, tid, hm.o, hm.o);
+    stage_request(kv, a.k + in_off, a.sT, a.v + in_off, a.sT, T, tid, hm.k, hm.v);
+    stage_write(qd, Ks, rs, kc, kc, Vs, rs, kc, kc, T, Tp, tid, blockDim.x);
+    if (tid < T) {                                    // the whole row of dO and of O sits in this thread
+      float sum = 0.f;
+#pragma unroll
+      for (int pz = 0; pz < 4; ++pz) {
+        sum += dot8(qd.b4[pz], oo.a4[pz]);
+        const bf16 *x = (const bf16*)&qd.b1[pz], *y = (const bf16*)&oo.a1[pz];
+        sum += (float)x[0] * (float)y[0] + (float)x[1] * (float)y[1];
+      }
+#pragma unroll
+      for (int pz = 0; pz < 2; ++pz) {
+        sum += dot8(qd.be[pz][0], oo.ae[pz][0]) + dot8(qd.be[pz][1], oo.ae[pz][1]);
+        const bf16 *x = (const bf16*)&qd.b2[pz], *y = (const bf16*)&oo.a2[pz];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += (float)x[j] * (float)y[j];
+      }
+      part[tid] = sum;
+    }
+    __syncthreads();
+    if (nt != W) load_dq_rows<KS>(shared, a, in_off, o_off, stat_off, W, lane, hm);   // (the staging registers are free now)
+    {
+      const int qi = wid * 32 + r, qc = qi < T ? qi : T - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        mine.qf[ks] = *(const bf16x8*)(Ks + (size_t)qc * rs + (2 * ks + half) * 16);
+        mine.dof[ks] = *(const bf16x8*)(Vs + (size_t)qc * rs + (2 * ks + half) * 16);
+      }
+      mine.lse = a.lse[stat_off + qc];
+      mine.delta = part[qc];
+      if (qi < T && half == 0) a.delta[stat_off + qi] = mine.delta;
+    }
+    __syncthreads();
+    stage_write(kv, Ks, rs, kc, kc, Vs, rs, kc, kc, T, Tp, tid, blockDim.x);
+    if (nt != W) finish_dq_rows<KS>(shared, a, stat_off, W, lane, wid == 0);
+  }
   ATRACE(1, 1);
   __syncthreads();
   ATRACE(1, 2);
@@ -862,11 +1001,44 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   ATRACE(2, 0);
-  KvRows<KS> kv;                                     // own key rows first: their round trip overlaps the staging
+  KvRows<KS> kv;
   const HeadMaps hm = head_maps(a, h);
-  load_kv_rows<KS>(kv, a, in_off, wid, lane, hm);
-  stage_two(Qs, rs, a.q + in_off, a.sT, hd / 8, hd / 8, Ds, rs, a.dout + o_off, a.oT, hd / 8, hd / 8, T, Tp, tid,
-            blockDim.x, hm.q, hm.o);
+  // Prologue in one memory round trip (see attn_bwd_dq_kernel): K, V, Q and dO are all requested up front; the own key
+  // rows' fragments are read from the LDS images of K and V, which are then overwritten with Q and dO.
+  const int kc = hd / 8;
+  if (hm.q.cv == 0) {
+    StagePlain kvr, qdr;
+    stage_request(kvr, a.k + in_off, a.sT, kc, a.v + in_off, a.sT, kc, T, tid, blockDim.x);
+    stage_request(qdr, a.q + in_off, a.sT, kc, a.dout + o_off, a.oT, kc, T, tid, blockDim.x);
+    stage_write(kvr, Qs, rs, kc, Ds, rs, kc, Tp, tid, blockDim.x);
+    __syncthreads();
+    {
+      const int ki = wid * 32 + r, kcl = ki < T ? ki : T - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kv.kf[ks] = *(const bf16x8*)(Qs + (size_t)kcl * rs + (2 * ks + half) * 16);
+        kv.vf[ks] = *(const bf16x8*)(Ds + (size_t)kcl * rs + (2 * ks + half) * 16);
+      }
+    }
+    __syncthreads();
+    stage_write(qdr, Qs, rs, kc, Ds, rs, kc, Tp, tid, blockDim.x);
+  } else {
+    StagePacked kvr, qdr;
+    stage_request(kvr, a.k + in_off, a.sT, a.v + in_off, a.sT, T, tid, hm.k, hm.v);
+    stage_request(qdr, a.q + in_off, a.sT, a.dout + o_off, a.oT, T, tid, hm.q, hm.o);
+    stage_write(kvr, Qs, rs, kc, kc, Ds, rs, kc, kc, T, Tp, tid, blockDim.x);
+    __syncthreads();
+    {
+      const int ki = wid * 32 + r, kcl = ki < T ? ki : T - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kv.kf[ks] = *(const bf16x8*)(Qs + (size_t)kcl * rs + (2 * ks + half) * 16);
+        kv.vf[ks] = *(const bf16x8*)(Ds + (size_t)kcl * rs + (2 * ks + half) * 16);
+      }
+    }
+    __syncthreads();
+    stage_write(qdr, Qs, rs, kc, kc, Ds, rs, kc, kc, T, Tp, tid, blockDim.x);
+  }
   for (int t = tid; t < Tp; t += blockDim.x) {
     const int64_t stat = ((int64_t)b * a.H + h) * T + t;
     lse_s[t] = t < T ? a.lse[stat] : INFINITY;    // padded queries: P = exp2(x - inf) = 0
@@ -917,12 +1089,13 @@ static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream
   // DT*32 columns, so rows must hold that many (the pad columns meet zero accumulator columns / are discarded).
   const int cols = DT * 32 > a.hd ? DT * 32 : a.hd;
   const int rs = cols * 2 + 16;
-  size_t smem_dq = (size_t)2 * nt * 32 * rs;
-  size_t smem_kv = smem_dq + (size_t)2 * nt * 32 * sizeof(float);
+  const size_t img = (size_t)2 * nt * 32 * rs;
+  size_t smem_dq = img + (size_t)nt * 32 * (a.hd / 8) * sizeof(float);      // + the delta partials [Tp][hd / 8]
+  size_t smem_kv = img + (size_t)2 * nt * 32 * sizeof(float);
   const size_t comb = (size_t)W * 32 * (DT * 32 + kPartPad) * sizeof(float);
   if (nt != W && comb > smem_dq) smem_dq = comb;
   if (nt != W && comb > smem_kv) smem_kv = comb;
-  if (smem_kv > 160 * 1024) return OCTIC_ESHAPE;
+  if (smem_kv > 160 * 1024 || smem_dq > 160 * 1024) return OCTIC_ESHAPE;
   static bool done = false;
   if (!done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<KS, DT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

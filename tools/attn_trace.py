@@ -13,7 +13,7 @@ from octic_vits_amd import functional as OF  # noqa: E402
 _lib.LIB_PATH = os.environ.get("OCTIC_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "liboctic_trace.so"))
 L = _lib.lib()
 L.octic_dbg_attn_trace.restype = ctypes.c_void_p
-B, H, T, hd = 64, 16, 257, 80
+B, H, T, hd = int(os.environ.get("B", "64")), 16, 257, 80
 PACKED = os.environ.get("PACKED", "0") == "1"       # AttentionD8 core on packed rows (octic_attn_*_packed)
 if PACKED:
     c = 10 * H
