@@ -118,3 +118,27 @@ def test_dinov2_entrypoints_keep_the_reference_state_dict():
     with torch.device("meta"):
         big = deit_models.create_model("hybrid_dinov2_vit_large_patch16")
     assert sum(p.numel() for p in big.parameters()) == 170296704
+
+
+def test_drop_path_pool_is_armed_only_inside_a_model_forward_and_is_seed_reproducible():
+    """d8_layers._drop_path_mask: outside a model forward every call draws on its own (reference behaviour,
+    octic_vits/d8_layers.py:140-152); inside (pool armed by OcticVisionTransformer.forward_features) masks come 64 at a
+    time from one draw, a new draw per forward, identical for identical seeds, and scaled by 1 / keep."""
+    import torch
+    from octic_vits_amd import d8_layers as L
+    torch.manual_seed(3)
+    a = L._drop_path_mask(8, 0.25, torch.device("cpu"))
+    torch.manual_seed(3)
+    b = L._drop_path_mask(8, 0.25, torch.device("cpu"))
+    assert torch.equal(a, b) and set(a.tolist()) <= {0.0, float(torch.tensor(1.0) / 0.75)}
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        L.arm_drop_path_pool(True)
+        try:
+            runs.append(torch.stack([L._drop_path_mask(8, 0.25, torch.device("cpu")) for _ in range(70)]))
+        finally:
+            L.arm_drop_path_pool(False)
+    assert torch.equal(runs[0], runs[1])                      # same seed -> same masks, across the pool refill at 64
+    assert len({tuple(r.tolist()) for r in runs[0]}) > 8      # rows of the pool differ
+    assert not L._pool_armed
