@@ -307,28 +307,6 @@ constexpr int kRingStage = (kBM + kRingBN) * 128;
 // write are pointed here.
 __device__ char g_store_sink[64 * 16 * 2];
 
-__device__ inline void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt needs an immediate
-  switch (n) {
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
-    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
-    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0 and anything else: drain (always safe)
-  }
-}
 
 // NT = 16-column MFMA tiles per wave (tile width BN = 16 NT: 80 or 160), S = ring stages.  The wide tile (NT = 10,
 // S = 2: 72 KiB, still two workgroups per CU) is for the long-K / narrow-N problems (fc2, input gradients of qkv and
@@ -373,12 +351,6 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
   // 95 k .. 200 k cycles for one launch).  Segment k of the order = [share k of group 0 | share k of group 1 | ...].
   int gi = 0, lt = 0;
   {
-#ifdef OCTIC_RING_OLDORDER
-#pragma unroll
-    for (int i = 1; i < 5; ++i)
-      if (i < args.ngroups && tile >= args.g[i].tile_begin) gi = i;
-    lt = tile - args.g[gi].tile_begin;
-#else
     int T[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -405,7 +377,6 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
       }
       if (!found) r -= sz;
     }
-#endif
   }
   const GemmGroup& G = args.g[gi];
   // work item = (m-tile, chunk of consecutive n-tiles); the DMA ring runs continuously over its (n-tile, k-tile) steps
@@ -558,14 +529,7 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
     // only the stores of step s-1 are younger than DMA(s)
     // (the immediates are picked by two or three scalar compares: a `switch` over all counts compiles to a compare
     // ladder of ~500 cycles, most of a 640-cycle MFMA step)
-#ifdef OCTIC_RING_OLDWAIT
-    if (has_res) wait_vmcnt(0);
-    else if (S > 2) wait_vmcnt(s + 1 < steps ? dma_cnt + st1 + st2 : 0);
-    else wait_vmcnt(st1);
-    if (false) {
-#else
     if (has_res) {
-#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // residual loads have VGPR destinations: keep hipcc's own waits exact
     } else if (S > 2) {
       // younger than DMA(s): DMA(s+1) (dma_cnt = 6 | 7) and the stores of steps s-1, s-2 (0 | NSTORE each); rounding the
