@@ -198,14 +198,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs args) {
 // chunk that belongs at its LDS position), which makes the transposing reads of rows r and r+8 hit disjoint banks.
 // 60 KiB of LDS and <= 128 VGPRs: two workgroups per CU (the register-staged kernel above fits one).
 // Row tails: rows >= r1 fetch from a zero page, so they add nothing.
-constexpr int kWgS = 3, kWgR = 32;
+#ifndef OCTIC_WG_STAGES
+#define OCTIC_WG_STAGES 3
+#endif
+constexpr int kWgS = OCTIC_WG_STAGES, kWgR = 32;   // ring stages (tiles in flight behind the one being multiplied: kWgS - 1)
 constexpr int kWgTile = kWgR * 320;
 constexpr int kWgStage = 2 * kWgTile;
 __device__ __attribute__((aligned(256))) unsigned char g_wg_zero[512];
 
-__device__ inline void wg_wait_vmcnt(int n) {
-  if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+// wait until this wave's share of the oldest tile in flight has landed: `ahead` younger tiles (5 DMA instructions each)
+// may stay outstanding
+__device__ inline void wg_wait_tiles(int ahead) {
+  if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (ahead == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
 __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(WgArgs args) {
@@ -299,13 +306,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(WgArgs args) {
     offb[i] = kWgTile + frow * 320 + ((cb + rot) % 20) * 16 + (fr & 1) * 8;
   }
 
-  if (nsteps > 0) issue();
-  if (nsteps > 1) issue();
+#pragma unroll
+  for (int pz = 0; pz < kWgS - 1; ++pz)
+    if (pz < nsteps) issue();
   int c_stage = 0;
   for (int sidx = 0; sidx < nsteps; ++sidx) {
-    wg_wait_vmcnt(sidx + 1 < nsteps ? 5 : 0);
+    const int left = nsteps - 1 - sidx;      // tiles after this one; kWgS - 2 of them are in flight in steady state
+    wg_wait_tiles(left < kWgS - 2 ? left : kWgS - 2);
     __builtin_amdgcn_s_barrier();          // every wave's share of tile sidx has landed; stage of tile sidx-1 is free
-    if (sidx + 2 < nsteps) issue();
+    if (sidx + kWgS - 1 < nsteps) issue();
     const char* base = lds + c_stage * kWgStage;
     c_stage = c_stage == kWgS - 1 ? 0 : c_stage + 1;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -482,6 +491,12 @@ inline int launch_wgrad_ring(WgArgs& a, hipStream_t s) {
     t += a.g[i].k_tiles * a.g[i].n_tiles * a.g[i].splits;
   }
   a.wgs = t;
+  static bool attr_done = false;
+  if (!attr_done && kWgS * kWgStage > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)wgrad_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgS * kWgStage);
+    (void)hipGetLastError();
+  }
+  attr_done = true;
   wgrad_ring_kernel<<<t, 256, kWgS * kWgStage, s>>>(a);
   return launch_status();
 }
