@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as OF
-from .d8_utils import SQRT2, SQRT2_OVER_4, convert_5tuple_to_8tuple, convert_8tuple_to_5tuple, expand_lift_kernel
+from .d8_utils import SQRT2, SQRT2_OVER_4, convert_5tuple_to_8tuple, convert_8tuple_to_5tuple, expand_lift_kernel, packed_lift_weight
 from .functional import Octic, as_packed, compute_dtype
 
 
@@ -361,6 +361,13 @@ class LiftD8(nn.Module):
     def packed_weight(self):
         """[8c, Cin*p*p] kernel matrix with rows in packed channel order A1|A2|B1|B2|E_row0|E_row1:
         E_row0 = (E_left K, E_right K), E_row1 = (E_left rot K, E_right rot K)."""
+        ws = [c.weight for c in (self.conv_A1, self.conv_A2, self.conv_B1, self.conv_B2, self.conv_E_left, self.conv_E_right)]
+        if all(w.dtype == ws[0].dtype and w.device == ws[0].device and w.shape == ws[0].shape for w in ws):
+            return packed_lift_weight(ws)            # one signed gather (d8_utils._LiftWeightFn) instead of ~55 small launches
+        return self.packed_weight_composed()
+
+    def packed_weight_composed(self):
+        """The same matrix built the way the reference composes it (expand, rot90, flatten, cat)."""
         el, er = self.conv_E_left.kernels(), self.conv_E_right.kernels()
         ks = [self.conv_A1.expand_weight(), self.conv_A2.expand_weight(), self.conv_B1.expand_weight(),
               self.conv_B2.expand_weight(), el[0], er[0], el[1], er[1]]

@@ -247,6 +247,77 @@ def expand_lift_kernel(weight, irrep):
     return unfold_quarter(scale * weight, irrep, -2, -1)
 
 
+# --------------------------------------------------------------------------------------------
+# The lift's whole kernel matrix in one gather.  LiftD8.packed_weight (d8_layers.py:384-411 + 329-381 of the
+# reference) = six expand_lift_kernel calls, two rot90s, eight flattens and a cat: ~55 launches of a few
+# microseconds forward and as many backward, every step.  All of it is one signed gather from the concatenated
+# quarter kernels: W[row, col] = P[idx1] * s1 + P[idx2] * s2 (second term: the one-dimensional irreps), and its
+# backward a gather over the inverse table (every quarter entry is read 8 times: fixed-order sum, reproducible).
+# Same products and the same order of additions as the composed version: bitwise equal forward.
+# --------------------------------------------------------------------------------------------
+_LIFT_BLOCKS = ((0, "A1", 0), (1, "A2", 0), (2, "B1", 0), (3, "B2", 0), (4, "E", 0), (5, "E", 0), (4, "E", 1), (5, "E", 1))
+
+
+@lru_cache(maxsize=None)
+def _lift_tables_on(O: int, Cin: int, h: int, device: str, dtype):
+    with torch.inference_mode(False):
+        P2, Q = (2 * h) * (2 * h), h * h
+        rot = torch.arange(P2).view(2 * h, 2 * h).rot90(1, (0, 1)).flatten()     # source position of every rotated position
+        base = (torch.arange(O * Cin) * Q).view(O, Cin, 1)
+        i1, s1, i2, s2 = [], [], [], []
+        for conv, kind, r in _LIFT_BLOCKS:
+            ia, sa, ib, sb = _unfold_tables(h, kind)
+            scale = 0.5 if kind == "E" else SQRT2_OVER_4
+            if r:
+                ia, sa = ia[rot], sa[rot]
+            off = conv * O * Cin * Q
+            i1.append((off + base + ia.view(1, 1, P2)).reshape(-1))
+            s1.append((scale * sa).view(1, 1, P2).expand(O, Cin, P2).reshape(-1))
+            if ib is None:
+                i2.append(torch.zeros(O * Cin * P2, dtype=torch.long))
+                s2.append(torch.zeros(O * Cin * P2))
+            else:
+                i2.append((off + base + ib.view(1, 1, P2)).reshape(-1))
+                s2.append((scale * sb).view(1, 1, P2).expand(O, Cin, P2).reshape(-1))
+        i1, s1, i2, s2 = torch.cat(i1), torch.cat(s1), torch.cat(i2), torch.cat(s2)
+        # inverse: for every parameter entry the output positions that read it (either term), with their factors
+        used2 = s2 != 0
+        src = torch.cat([i1, i2[used2]])
+        pos = torch.cat([torch.arange(i1.numel()), torch.arange(i2.numel())[used2]])
+        fac = torch.cat([s1, s2[used2]])
+        order = torch.argsort(src, stable=True)
+        counts = torch.bincount(src, minlength=6 * O * Cin * Q)
+        n = int(counts[0])
+        assert bool((counts == n).all()), "lift table is not uniform"
+        dev = torch.device(device)
+        return (i1.to(dev), s1.to(dev, dtype), i2.to(dev), s2.to(dev, dtype),
+                pos[order].view(-1, n).to(dev).clone(), fac[order].view(-1, n).to(dev, dtype).clone())
+
+
+class _LiftWeightFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *ws):
+        O, Cin, h, _ = ws[0].shape
+        i1, s1, i2, s2, _, _ = _lift_tables_on(O, Cin, h, str(ws[0].device), ws[0].dtype)
+        flat = torch.cat([w.reshape(-1) for w in ws])
+        out = flat.index_select(0, i1) * s1 + flat.index_select(0, i2) * s2
+        ctx.meta = (O, Cin, h)
+        return out.view(8 * O, Cin * 4 * h * h)
+
+    @staticmethod
+    def backward(ctx, g):
+        O, Cin, h = ctx.meta
+        _, _, _, _, inv, fac = _lift_tables_on(O, Cin, h, str(g.device), g.dtype)
+        gp = (g.reshape(-1).index_select(0, inv.reshape(-1)).view(inv.shape) * fac).sum(1)
+        return tuple(gp.view(6, O, Cin, h, h).unbind(0))
+
+
+def packed_lift_weight(ws):
+    """[8 O, Cin (2h)^2] kernel matrix of LiftD8 (rows A1|A2|B1|B2|E_left K|E_right K|E_left rot K|E_right rot K) from the
+    six quarter kernels [O, Cin, h, h] (order A1, A2, B1, B2, E_left, E_right)."""
+    return _LiftWeightFn.apply(*ws)
+
+
 def isotypic_dim_interpolation(xs, dim: int = 0):
     """d8_utils.py:388-451: 6 quarter grids [.., G/2, G/2, c] -> 8 full grids [.., G, G, c]."""
     d0, d1 = dim, dim + 1
@@ -256,10 +327,69 @@ def isotypic_dim_interpolation(xs, dim: int = 0):
             el, el.rot90(dims=(d0, d1)), er, er.rot90(dims=(d0, d1)))
 
 
-def packed_pos_embed(pos_params):
-    """Unfolded positional embedding as packed rows [G*G, 8c] (order A1|A2|B1|B2|x4|x6|x5|x7)."""
+@lru_cache(maxsize=None)
+def _pos_tables_on(h: int, device: str, dtype):
+    """Row tables of packed_pos_embed: output row block b (A1|A2|B1|B2|E_left|E_right|rot E_left|rot E_right) x grid
+    position -> row of the concatenated quarter grids [6 h^2, c], two terms, no scaling; and the inverse table."""
+    with torch.inference_mode(False):
+        P2, Q = 4 * h * h, h * h
+        rot = torch.arange(P2).view(2 * h, 2 * h).rot90(1, (0, 1)).flatten()
+        i1, s1, i2, s2 = [], [], [], []
+        for conv, kind, r in _LIFT_BLOCKS:
+            ia, sa, ib, sb = _unfold_tables(h, kind)
+            if r:
+                ia, sa = ia[rot], sa[rot]
+            i1.append(conv * Q + ia)
+            s1.append(sa)
+            i2.append(torch.zeros(P2, dtype=torch.long) if ib is None else conv * Q + ib)
+            s2.append(torch.zeros(P2) if ib is None else sb)
+        i1, s1, i2, s2 = torch.cat(i1), torch.cat(s1), torch.cat(i2), torch.cat(s2)
+        used2 = s2 != 0
+        src = torch.cat([i1, i2[used2]])
+        pos = torch.cat([torch.arange(i1.numel()), torch.arange(i2.numel())[used2]])
+        fac = torch.cat([s1, s2[used2]])
+        order = torch.argsort(src, stable=True)
+        counts = torch.bincount(src, minlength=6 * Q)
+        n = int(counts[0])
+        assert bool((counts == n).all()), "pos-embed table is not uniform"
+        dev = torch.device(device)
+        return (i1.to(dev), s1.to(dev, dtype).view(-1, 1), i2.to(dev), s2.to(dev, dtype).view(-1, 1),
+                pos[order].view(-1, n).to(dev).clone(), fac[order].view(-1, n, 1).to(dev, dtype).clone())
+
+
+class _PosEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *ps):
+        h, _, c = ps[0].shape
+        i1, s1, i2, s2, _, _ = _pos_tables_on(h, str(ps[0].device), ps[0].dtype)
+        flat = torch.cat([p.reshape(h * h, c) for p in ps])                       # [6 h^2, c]
+        out = flat.index_select(0, i1) * s1 + flat.index_select(0, i2) * s2         # [8 G^2, c], block-major
+        ctx.meta = (h, c)
+        return out.view(8, 4 * h * h, c).permute(1, 0, 2).reshape(4 * h * h, 8 * c)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, c = ctx.meta
+        _, _, _, _, inv, fac = _pos_tables_on(h, str(g.device), g.dtype)
+        gb = g.view(4 * h * h, 8, c).permute(1, 0, 2).reshape(8 * 4 * h * h, c)
+        gp = (gb.index_select(0, inv.reshape(-1)).view(inv.shape[0], inv.shape[1], c) * fac).sum(1)
+        return tuple(gp.view(6, h, h, c).unbind(0))
+
+
+def packed_pos_embed_composed(pos_params):
+    """The reference's composition (d8_utils.py:388-451): eight unfolded grids, packed order A1|A2|B1|B2|x4|x6|x5|x7."""
     a = isotypic_dim_interpolation(tuple(pos_params), dim=0)
     return torch.cat([t.flatten(0, 1) for t in (a[0], a[1], a[2], a[3], a[4], a[6], a[5], a[7])], dim=-1)
+
+
+def packed_pos_embed(pos_params):
+    """Unfolded positional embedding as packed rows [G*G, 8c] (order A1|A2|B1|B2|x4|x6|x5|x7): one signed row gather from
+    the six quarter grids (same products and order of additions as the composition; ~25 launches fewer each way)."""
+    ps = tuple(pos_params)
+    if len(ps) == 6 and all(p.dim() == 3 and p.shape == ps[0].shape and p.dtype == ps[0].dtype and p.device == ps[0].device
+                            and p.shape[0] == p.shape[1] for p in ps):
+        return _PosEmbedFn.apply(*ps)
+    return packed_pos_embed_composed(ps)
 
 
 def interpolate_spatial_tuple(xs, interpolant, h: int, w: int, patch_size):

@@ -142,3 +142,40 @@ def test_drop_path_pool_is_armed_only_inside_a_model_forward_and_is_seed_reprodu
     assert torch.equal(runs[0], runs[1])                      # same seed -> same masks, across the pool refill at 64
     assert len({tuple(r.tolist()) for r in runs[0]}) > 8      # rows of the pool differ
     assert not L._pool_armed
+
+
+def test_packed_lift_weight_equals_the_composed_construction():
+    """LiftD8.packed_weight as one signed gather (d8_utils._LiftWeightFn) against the reference's composition
+    (expand_lift_kernel per irrep, rot90 for the E rows, flatten, cat: octic_vits/d8_layers.py:329-411): bitwise equal
+    forward (same products, same order of additions), gradients to 1e-6 (fixed-order gather instead of autograd's chain)."""
+    import torch
+    from octic_vits_amd.d8_layers import LiftD8
+    torch.manual_seed(5)
+    for cin, cout, p in ((3, 16, 4), (3, 24, 14), (2, 8, 2)):
+        try:
+            m = LiftD8(cin, cout, p, p, bias=True)
+        except ValueError:
+            continue                      # p = 2 has no A2 / B1 kernels
+        fused, composed = m.packed_weight(), m.packed_weight_composed()
+        assert fused.shape == composed.shape and torch.equal(fused, composed)
+        g = torch.randn_like(fused)
+        ws = [c.weight for c in (m.conv_A1, m.conv_A2, m.conv_B1, m.conv_B2, m.conv_E_left, m.conv_E_right)]
+        ga = torch.autograd.grad(m.packed_weight(), ws, g)
+        gb = torch.autograd.grad(m.packed_weight_composed(), ws, g)
+        for a, b in zip(ga, gb):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
+def test_packed_pos_embed_equals_the_composed_construction():
+    """packed_pos_embed as one signed row gather (d8_utils._PosEmbedFn) against the reference's composition
+    (isotypic_dim_interpolation, octic_vits/d8_utils.py:388-451, + packing): bitwise forward, gradients to 1e-6."""
+    import torch
+    from octic_vits_amd import d8_utils as U
+    torch.manual_seed(9)
+    for h, c in ((2, 8), (8, 20), (7, 3)):
+        ps = [torch.randn(h, h, c, requires_grad=True) for _ in range(6)]
+        fused, composed = U.packed_pos_embed(ps), U.packed_pos_embed_composed(ps)
+        assert fused.shape == composed.shape == (4 * h * h, 8 * c) and torch.equal(fused, composed)
+        g = torch.randn_like(fused)
+        for a, b in zip(torch.autograd.grad(U.packed_pos_embed(ps), ps, g), torch.autograd.grad(U.packed_pos_embed_composed(ps), ps, g)):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
