@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 4
+#define OCTIC_ABI_VERSION 5
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -283,6 +283,10 @@ int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, f
  * bias-gradient reduction of the standard MLP (deit/vit.py Mlp).                                          */
 int octic_dense_gelu_blocks(void);
 int octic_dense_gelu_bwd(const void* h, const void* g, void* dh, float* partials, int64_t rows, int d, void* stream);
+/* octic_dense_colsum: octic_dense_gelu_blocks() slabs [d] of f32 column sums of a bf16 [rows, d] tensor (row stride ld
+ * elements, d % 8 == 0), in a fixed order; reduce with octic_dense_finish as above.  The bias gradient of the fused-qkv
+ * projection (autograd of deit/vit.py:33: grad.sum(0) over the token rows).                                      */
+int octic_dense_colsum(const void* g, int64_t rows, int d, int64_t ld, float* partials, void* stream);
 int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, float* out, int64_t rows, int d, void* stream);
 int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
@@ -311,15 +315,18 @@ int octic_dense_prep_batch(const octic_dense_prep_item* items_dev, int n_items, 
  *   1 GELU  : C = acc + bias (pre-activation, kept for backward), C2 = gelu(C) exact erf (fc1 + nn.GELU, vit.py:131-134)
  *   2 RESID : C = acc + bias (branch output, kept for d gamma),  OUT = X + rs[row / rows_per_sample] * gamma * C
  *             = x + drop_path(gamma * f(x)) of deit/vit.py:131-134 with f32 residual stream X / OUT [M,N] dense
- *   3 DGELU : C = gelu'(H) * acc   with H the saved pre-activation (fc2 input gradient fused with GELU backward)
+ *   3 DGELU : C = gelu'(H) * acc   with H the saved pre-activation (fc2 input gradient fused with GELU backward);
+ *             colsum (may be NULL): octic_dense_gemm_colsum_rows(M,N,K) slabs [N] f32 whose sum over slabs is the column
+ *             sum of C (= fc1's bias gradient), every element written by each launch, fixed order -> octic_dense_finish
  * C / C2 / H are bf16 [M,N] with row stride ldc.  bias, gamma [N] f32 and rs f32 may be NULL.  workspace:
- * octic_dense_gemm_workspace_bytes(M,N,K) bytes (split-K slabs of the last partial round of tiles + tickets), ZEROED once
- * by the caller when it is allocated (the kernels re-arm their tickets; calls sharing a workspace must be stream-ordered). */
+ * octic_dense_gemm_workspace_bytes(M,N,K) bytes (split-K slabs of the last partial round of tiles + counters), ZEROED once
+ * by the caller when it is allocated (the kernels re-arm their counters; calls sharing a workspace must be stream-ordered). */
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K);
+int octic_dense_gemm_colsum_rows(int M, int N, int K);
 int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs,
-                        int64_t rows_per_sample, const float* X, float* OUT, const void* H, void* workspace,
-                        void* stream);
+                        int64_t rows_per_sample, const float* X, float* OUT, const void* H, float* colsum,
+                        void* workspace, void* stream);
 
 /* Weight gradient of an nn.Linear of the standard half (the autograd of deit/vit.py:33,46 and of timm Mlp.fc1 / fc2):
  *     dW[N,K] = dY[M,N]^T . X[M,K]     f32, nn.Linear layout

@@ -287,6 +287,41 @@ __global__ __launch_bounds__(256) void dense_gelu_bwd_kernel(const bf16* __restr
   }
 }
 
+// Column sums of a bf16 [rows, d] tensor (row stride ld) in f32: kGeluRowBlocks slabs [d] in a fixed order, reduced by
+// dense_finish_kernel.  The bias gradient of the fused-qkv projection (deit/vit.py:33; autograd's `grad.sum(0)`), whose
+// cotangent comes out of the attention backward and is read by nothing else row-wise.
+__global__ __launch_bounds__(256) void dense_colsum_kernel(const bf16* __restrict__ g, float* __restrict__ partials,
+                                                           long rows, int d, long ld) {
+  __shared__ float red[4][64][8];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + cl) * 8;
+  const long per = (rows + kGeluRowBlocks - 1) / kGeluRowBlocks;
+  const long r0 = (long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < d) {
+    long r = r0 + ph;
+    for (; r + 12 < r1; r += 16) {        // four rows per trip: four 16-byte loads in flight per lane
+      const bf16x8 v0 = *(const bf16x8*)(g + r * ld + col), v1 = *(const bf16x8*)(g + (r + 4) * ld + col);
+      const bf16x8 v2 = *(const bf16x8*)(g + (r + 8) * ld + col), v3 = *(const bf16x8*)(g + (r + 12) * ld + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+    }
+    for (; r < r1; r += 4) {
+      const bf16x8 v = *(const bf16x8*)(g + r * ld + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ph][cl][e] = acc[e];
+  __syncthreads();
+  if (ph == 0 && col < d) {
+    float* out = partials + (long)blockIdx.y * d + col;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = (red[0][cl][e] + red[1][cl][e]) + (red[2][cl][e] + red[3][cl][e]);
+  }
+}
+
 static inline int dense_nv(int d) { return (d + 255) / 256; }
 static inline int dense_check(long rows, int d) {
   if (rows < 0 || d <= 0 || (d & 3) || d > 2048) return OCTIC_ESHAPE;
@@ -432,6 +467,15 @@ int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, f
 }
 
 int octic_dense_gelu_blocks(void) { return kGeluRowBlocks; }
+
+int octic_dense_colsum(const void* g, int64_t rows, int d, int64_t ld, float* partials, void* stream) {
+  if (!g || !partials) return OCTIC_ENULL;
+  if (rows <= 0 || d <= 0 || (d & 7) || (ld & 7) || ld < d) return OCTIC_ESHAPE;
+  if (((uintptr_t)g) & 15) return OCTIC_EALIGN;
+  dense_colsum_kernel<<<dim3((d / 8 + 63) / 64, kGeluRowBlocks), dim3(256), 0, (hipStream_t)stream>>>(
+      (const bf16*)g, partials, rows, d, ld);
+  return launch_status();
+}
 
 int octic_dense_gelu_bwd(const void* h, const void* g, void* dh, float* partials, int64_t rows, int d, void* stream) {
   if (rows == 0) return OCTIC_OK;

@@ -22,8 +22,8 @@
 //
 // Scheduling: tiles are dealt to XCDs in contiguous chunks walked in groups of 8 row-panels (operand panels stay in the
 // XCD's L2).  M = 16 448 gives 65 x {5,15,20} tiles on 256 CUs: the last partial round would idle most of the chip, so
-// the tiles of that round are split along K over `split` workgroups each (f32 partial slabs + a ticket; the last
-// arriver of a tile reduces and runs the epilogue) - see dense_plan().
+// the tiles of that round are split along K over `split` workgroups each, placed at the FRONT of the grid (f32 partial
+// slabs + a ticket; the last arriver of a tile reduces and runs the epilogue) where that pays - see dense_plan().
 #include <type_traits>
 #ifndef DG_DMA_IN_MMA
 #define DG_DMA_IN_MMA 0      // 0: DMA issued in the R interval (beside the partner's MFMAs); 1: mid-MFMA; 2: M start
@@ -72,11 +72,12 @@ struct DgArgs {
   const float* X;     // [M, N] f32 residual stream in  (RESID)
   float* OUT;         // [M, N] f32 residual stream out (RESID)
   const bf16* H;      // [M, N] saved pre-activation     (DGELU)
-  float* colsum;      // [gridDim-row-panels, N] partial column sums of the output (DGELU, optional)
+  float* colsum;      // [tiles_m * 2][N] partial column sums of the output (DGELU, optional; see the epilogue)
   // schedule
   int tiles_m, tiles_n;
   int full_tiles;     // tiles computed by one workgroup each
   int split;          // K-split factor of the remaining tiles (>= 1)
+  int tail_pad;       // workgroups in front of the full tiles: the split parts of the remaining tiles, padded to 8
   float* slabs;       // [(tiles - full_tiles) * split] x 256 x 256 f32 partials
   int* tickets;       // [(tiles - full_tiles)] arrival counters (zeroed by the host per launch)
 };
@@ -112,6 +113,22 @@ extern "C" void* octic_dbg_dense_trace(void) {
   } while (0)
 #else
 #define DGT() do {} while (0)
+#endif
+#ifdef DG_TRACE2
+// developer-only (tools/dense_phases.py builds with -DDG_TRACE2): per workgroup, wave 0 stamps s_memrealtime (100 MHz) at
+// kernel start / first K-tile / end of the K loop / end of the epilogue, plus XCC_ID and HW_ID
+__device__ unsigned long long g_dg_trace2[4096 * 8];
+extern "C" void* octic_dbg_dense_trace2(void) {
+  void* p = nullptr;
+  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_dg_trace2));
+  return p;
+}
+#define DGT2(slot)                                                                                            \
+  do {                                                                                                        \
+    if (wid == 0 && lane == 0 && blockIdx.x < 4096) g_dg_trace2[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define DGT2(slot) do {} while (0)
 #endif
 
 // GELU for the fused epilogues.  The epilogue runs after the main loop with nothing to hide its VALU work behind (one
@@ -156,20 +173,34 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   if (blockIdx.x == 0 && lane == 0) g_dg_trace[wid * 256 + 254] = __builtin_amdgcn_s_memrealtime();
 #endif
   DGT();
+  DGT2(0);
+#ifdef DG_TRACE2
+  if (wid == 0 && lane == 0 && blockIdx.x < 4096) {
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    g_dg_trace2[blockIdx.x * 8 + 7] = ((unsigned long long)hwid << 32) | xcc;
+  }
+#endif
 
   // ---- work item -> (tile, k-range)
   const int bid = blockIdx.x;
   int tile, kt_begin, kt_end, part = 0, rem_idx = -1;
   const int nkt_all = a.K / DG_BK;
-  if (bid < a.full_tiles) {
-    // XCD-aware bijective remap over the full tiles
+  if (bid >= a.tail_pad) {
+    // XCD-aware bijective remap over the full tiles (tail_pad is a multiple of 8: j & 7 is still the XCD of this workgroup)
+    const int j = bid - a.tail_pad;
     const int nf = a.full_tiles;
-    const int xcd = bid & 7, q8 = nf >> 3, r8 = nf & 7;
-    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int xcd = j & 7, q8 = nf >> 3, r8 = nf & 7;
+    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (j >> 3);
     kt_begin = 0;
     kt_end = nkt_all;
   } else {
-    const int r = bid - a.full_tiles;
+    // The split parts of the last partial round go FIRST: the short items and their slab round trip (publish, last arriver
+    // re-reads `split` partial tiles) then run beside everybody's full tiles instead of forming the end of the launch
+    // (tools/dense_phases.py: N 5120 K 1280 203.5 -> 197.7 us; with K 5120 the reducers' CUs still end the launch).
+    const int r = bid;
+    if (r >= (a.tiles_m * a.tiles_n - a.full_tiles) * a.split) return;       // padding
     rem_idx = r / a.split;
     part = r - rem_idx * a.split;
     tile = a.full_tiles + rem_idx;
@@ -338,6 +369,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #endif
   }
   if (hi) __builtin_amdgcn_s_barrier();
+  DGT2(1);
 
   // One K-tile = four phases.  STEADY: every unit issued here exists and the ring is full, so the DMA issue and the
   // landed-wait need no conditions (one immediate vmcnt); the last K-tiles of the range take the guarded path.
@@ -436,9 +468,20 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   for (; t < nkt; ++t) ktile(t, DG_IC(0));
   if (!hi) __builtin_amdgcn_s_barrier();   // re-align the two groups
   __builtin_amdgcn_s_barrier();            // every wave is done with the ring: LDS is free for the epilogue
+  DGT2(2);
 
   // ---- split-K tail tiles: publish the partial tile, the last arriver of the tile reduces (MI355X guide, split-K recipe:
-  // plain stores -> every wave drains -> barrier -> lane 0 agent release -> ticket; reducer: agent acquire -> barrier)
+  // plain stores -> every wave drains -> barrier -> lane 0 agent release -> ticket; reducer: agent acquire -> barrier).
+  // Only row tiles with rows below M travel: the tail round of M = 16 448 is mostly the 64-row last panel, a quarter of
+  // whose slabs is data.  What a split costs is this slab round trip (tools/dense_phases.py, 207 parts of full tiles:
+  // publish 9 us = 53 MB of f32 partials at HBM write rate, agent release / acquire 6-8 us of L2 write-back, reducer
+  // 15-20 us reading split x 256 KiB through one CU) - dense_plan() splits only where the K loop it saves is longer.
+  // (A cooperative variant - the parts meet at a counter and each reduces 1/split of the tile - measured no faster even
+  // with the parts at the front of the grid: the wait replaces the reducer's reads, the fences and the 53 MB stay; and
+  // it would forbid two of these GEMMs on two streams.)
+  const int rt_lo = 0;
+  int rt_hi = (a.M - m0 - wr * 128 + 15) >> 4;           // row tiles (mh * 4 + mi) of this wave with rows below M
+  rt_hi = rt_hi < 0 ? 0 : (rt_hi > 8 ? 8 : rt_hi);
   if (rem_idx >= 0 && a.split > 1) {
     float* slab = a.slabs + ((int64_t)rem_idx * a.split + part) * (DG_BM * DG_BN);
     // slab layout: [wave][acc register index][lane] float4 -> fully coalesced 16-byte stores and loads
@@ -446,13 +489,16 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
+      for (int mi = 0; mi < 4; ++mi) {
+        if (mh * 4 + mi >= rt_hi) continue;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) sw4[(((mh * 2 + nh) * 4 + mi) * 2 + ni) * 64] = acc[mh][nh][mi][ni];
+      }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    DGT2(5);
     int* flag = (int*)lds;                 // the ring is idle now
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -471,6 +517,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     const int last = flag[0];
     __syncthreads();                       // flag word is part of the staging area below
     if (last == 0) return;
+    DGT2(6);
     // fixed summation order slab 0 + slab 1 + ... whichever part arrived last (its own partial is re-read from its
     // slab): the result does not depend on the arrival order, so identical launches give identical bits
     for (int p = 0; p < a.split; ++p) {
@@ -479,14 +526,16 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
+        for (int mi = 0; mi < 4; ++mi) {
+          if (mh * 4 + mi >= rt_hi) continue;
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+          for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
               const f32x4 o = o4[(((mh * 2 + nh) * 4 + mi) * 2 + ni) * 64];
               acc[mh][nh][mi][ni] = p == 0 ? o : acc[mh][nh][mi][ni] + o;
             }
+        }
     }
   }
 
@@ -507,6 +556,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
+          if (mh * 4 + mi < rt_lo || mh * 4 + mi >= rt_hi) continue;
           const f32x4 v = acc[mh][nh][mi][ni] + bv;
           const bf16x4 cb = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
           *(bf16x4*)(stg + (mh * 64 + mi * 16 + fr) * SRS + nl * 2) = cb;
@@ -525,11 +575,12 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   // or 16 B of h per lane in flight), so the pass pays the memory latency once instead of once per row
   f32x4 xin[MODE == DG_RESID ? 16 : 1][2];
   bf16x8 hin[MODE == DG_DGELU ? 16 : 1];
+  float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DGELU: column sums of this lane's rows (bias gradient of fc1)
   if (MODE == DG_RESID || MODE == DG_DGELU) {
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int m = m0 + wr * 128 + it * 8 + srow;
-      const bool ok = m < a.M && nok;
+      const bool ok = m < a.M && nok && (it >> 1) >= rt_lo && (it >> 1) < rt_hi;
       if (MODE == DG_RESID) {
         const float* xp = a.X + (int64_t)(ok ? m : 0) * a.N + (ok ? n : 0);
         xin[it][0] = *(const f32x4*)xp;
@@ -543,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   for (int it = 0; it < 16; ++it) {
     const int row = it * 8 + srow;
     const int m = m0 + wr * 128 + row;
-    if (m >= a.M || !nok) continue;
+    if (m >= a.M || !nok || (it >> 1) < rt_lo || (it >> 1) >= rt_hi) continue;
     const u32x4 raw = *(const u32x4*)(stg + row * SRS + sch * 16);
     const bf16x8 cb = __builtin_bit_cast(bf16x8, raw);
     bf16* cp = a.C + (int64_t)m * a.ldc + n;
@@ -571,16 +622,41 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
       const bf16x8 h = hin[it];
       bf16x8 d;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d[e] = (bf16)(dg_gelu_grad((float)h[e]) * (float)cb[e]);
+      for (int e = 0; e < 8; ++e) {
+        d[e] = (bf16)(dg_gelu_grad((float)h[e]) * (float)cb[e]);
+        csum[e] += (float)d[e];                // sum what the GEMMs downstream actually see
+      }
       *(bf16x8*)cp = d;
     }
   }
+  // DGELU column sums: slab row 2 tm + wr holds the sums over this wave's rows (the tile's epilogue runs in exactly one
+  // workgroup): every element of the [tiles_m * 2, N] buffer is written once per launch, octic_dense_finish adds the rows
+  if (MODE == DG_DGELU && a.colsum != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = csum[e];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      csum[e] = v;
+    }
+    if (srow == 0 && nok) {
+      float* base = a.colsum + (int64_t)(tm * 2 + wr) * a.N + n;
+      *(f32x4*)base = f32x4{csum[0], csum[1], csum[2], csum[3]};
+      *(f32x4*)(base + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
+    }
+  }
+#ifdef DG_TRACE2
+  DGT2(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DGT2(4);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Schedule: `full` tiles get one workgroup each; the remaining r = tiles - full tiles (the partial last round on the
 // `cus` workgroup slots) are split along K over `split` workgroups each, so the last round also fills the chip.
-struct DgPlan { int tiles_m, tiles_n, full, rem, split, grid; };
+struct DgPlan { int tiles_m, tiles_n, full, rem, split, tail_pad, grid; };
 
 inline DgPlan dense_plan(int M, int N, int K, int cus) {
   DgPlan p;
@@ -599,9 +675,29 @@ inline DgPlan dense_plan(int M, int N, int K, int cus) {
     s = s > 8 ? 8 : s;
     // a tail that nearly fills a round is cheaper unsplit (no slab traffic)
     if (p.rem * 10 >= cus * 8) s = 1;
+    // ... and so is a short K: a split tile pays the slab round trip (f32 partial out, `s` partials back through the
+    // reducer's CU: ~26 us = 17 K-tiles of this kernel for a tile of 256 real rows, tools/dense_phases.py), in proportion
+    // to the rows that exist (the tail of M = 16 448 is mostly the 64-row last panel).  Split only if K/s + that < K.
+    if (s > 1) {
+      int64_t rows = 0;
+      for (int tile = p.full; tile < tiles; ++tile) {
+        const int G = 8, per_group = G * p.tiles_n, gidx = tile / per_group, first_m = gidx * G;
+        const int gsz = (p.tiles_m - first_m) < G ? (p.tiles_m - first_m) : G;
+        const int tm = first_m + (tile - gidx * per_group) % gsz;
+        const int left = M - tm * DG_BM;
+        rows += left < DG_BM ? left : DG_BM;
+      }
+      const double f = (double)rows / ((double)p.rem * DG_BM);
+      if ((double)nkt / s + 17.0 * f + 1.0 >= (double)nkt) s = 1;
+    }
     p.split = s;
+    if (s == 1) {            // an unsplit tail is just more full tiles
+      p.full = tiles;
+      p.rem = 0;
+    }
   }
-  p.grid = p.full + p.rem * p.split;
+  p.tail_pad = (p.rem * p.split + 7) & ~7;
+  p.grid = p.tail_pad + p.full;
   return p;
 }
 
@@ -611,17 +707,36 @@ using namespace octic;
 
 extern "C" {
 
+// CUs of the current device (the split-K parts of a tile wait for each other: the plan must not assume more workgroup
+// slots than the device has); 256 when no device is visible (host-only callers sizing a workspace)
+static int dense_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    (void)hipGetLastError();
+    cus = n;
+  }
+  return cus;
+}
+
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K) {
-  const DgPlan p = dense_plan(M, N, K, 256);
+  const DgPlan p = dense_plan(M, N, K, dense_cus());
   if (p.split <= 1) return 256;
   return (int64_t)p.rem * p.split * DG_BM * DG_BN * 4 + (int64_t)p.rem * 4 + 256;
 }
 
+int octic_dense_gemm_colsum_rows(int M, int N, int K) {
+  (void)N; (void)K;
+  return 2 * ((M + DG_BM - 1) / DG_BM);
+}
+
 // mode: 0 plain (C = A B^T + bias), 1 GELU (C = pre-activation, C2 = gelu(C)), 2 RESID (C = branch, OUT = X + rs*gamma*C),
-// 3 DGELU (C = gelu'(H) * (A B^T)).
+// 3 DGELU (C = gelu'(H) * (A B^T); colsum != NULL: octic_dense_gemm_colsum_rows() slabs [N] of column sums of C).
 int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs, int64_t rps,
-                        const float* X, float* OUT, const void* H, void* workspace, void* stream) {
+                        const float* X, float* OUT, const void* H, float* colsum, void* workspace, void* stream) {
   if (!A || !B || !C) return OCTIC_ENULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % DG_BK) || K < 2 * DG_BK || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 4)) return OCTIC_ESHAPE;
   // buffer descriptors and per-lane offsets are 32-bit: operands of 2 GiB or more are refused (callers fall back to
@@ -634,9 +749,9 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
   DgArgs a = {};
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.lda = lda; a.ldb = ldb; a.M = M; a.N = N; a.K = K;
   a.C = (bf16*)C; a.C2 = (bf16*)C2; a.ldc = ldc; a.bias = bias; a.gamma = gamma; a.rs = rs; a.rps = rs ? rps : 1;
-  a.X = X; a.OUT = OUT; a.H = (const bf16*)H;
-  const DgPlan p = dense_plan(M, N, K, 256);
-  a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.full_tiles = p.full; a.split = p.split;
+  a.X = X; a.OUT = OUT; a.H = (const bf16*)H; a.colsum = mode == DG_DGELU ? colsum : nullptr;
+  const DgPlan p = dense_plan(M, N, K, dense_cus());
+  a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.full_tiles = p.full; a.split = p.split; a.tail_pad = p.tail_pad;
   hipStream_t s = (hipStream_t)stream;
   if (p.split > 1) {
     if (!workspace) return OCTIC_ENULL;

@@ -594,14 +594,17 @@ def track_optimizer(model, optimizer):
 
 
 # --------------------------------------------------------------- standard half on the hand-written MFMA GEMMs
-# Which GEMMs of a standard block run on csrc/dense_gemm.hip (the others stay on the BLAS library + the row kernels of
-# csrc/dense.hip).  Measured in the train step on MI355X (same device, back to back): the
-# hand-written kernel wins where the tile count fills whole rounds of the 256 CUs or the fused tail removes a full pass
-# (qkv forward and input gradient, fc1 + GELU); on the N = 1280 problems (325 tiles = 1.27 rounds at B = 64) the library's
-# stream-K kernels are ahead and a fused heavy epilogue cannot overlap with anything (one workgroup per CU).
+# Which GEMMs of a standard block run on csrc/dense_gemm.hip (the others would go to the BLAS library + the row kernels
+# of csrc/dense.hip).  Measured in the train step on MI355X (same device, back to back; DESIGN.md section 3.5;
+# tools/ab_dense.sh): since round 3 (tail tiles in front of the grid, rows past M never travel, no split where the slab
+# round trip costs more than the K loop it saves, fc1's bias gradient out of the GELU' epilogue) all eight on the
+# hand-written kernel is level with or ahead of every mixed routing (72.2 vs 72.3-72.9 ms per step), so the whole
+# standard half is hand-written; per shape the library is still ahead on proj (N = K = 1280: 62 vs 67 us, two rounds of
+# 256 x 256 tiles against its 256 x 192 ones) and that is paid back by the fused tails (no scale_residual_fwd, no
+# dense_gelu_bwd pass).
 WGRAD_F32_OUT = False      # True: library weight gradients as torch.mm(..., out_dtype=float32) (no bf16 rounding of
                            # dW; measured equal in step time, but outside the shipped TunableOp table)
-DENSE_HIP = {"qkv", "dqkv", "fc1"}          # subset of {"qkv", "dqkv", "proj", "dproj", "fc1", "dfc1", "fc2", "dfc2"}
+DENSE_HIP = {"qkv", "dqkv", "proj", "dproj", "fc1", "dfc1", "fc2", "dfc2"}    # any subset (bench.py --dense-hip)
 
 
 def dense_hip_ok(x, w, which=None):
@@ -699,7 +702,10 @@ class DenseLinearNTFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = (ops.dense_gemm_nt(g2, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
                   else _mm_lib(g2, wb)).view(x_shape).to(x_dtype)
-        gb = g2.sum(0, dtype=torch.float32) if has_b else None
+        gb = None
+        if has_b:
+            gb = (ops.dense_colsum(g2) if g2.is_cuda and g2.dtype == torch.bfloat16 and g2.shape[1] % 8 == 0
+                  else g2.sum(0, dtype=torch.float32))
         return gx, _wgrad_lib(g2, x2), gb, None, None
 
 
@@ -772,8 +778,10 @@ class DenseMlpFn(torch.autograd.Function):
         gbr, dgamma, db2 = ops.scale_residual_bwd(gout.view(br.shape), br, g32, rs32, rps, want_gamma=has_gamma,
                                                   want_colsum=has_b2)
         if w2t is not None:
-            dh = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>")     # gelu'(h) * (gbr W2)
-            db1 = dh.sum(0, dtype=torch.float32) if has_b1 else None
+            if has_b1:                                                                  # gelu'(h) * (gbr W2), + db1
+                dh, db1 = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>", want_colsum=True)
+            else:
+                dh, db1 = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>"), None
         else:
             dh, db1 = ops.dense_gelu_bwd(h, _mm_lib(gbr, w2b), want_colsum=has_b1)
         gw2 = _wgrad_lib(gbr, a)

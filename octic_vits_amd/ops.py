@@ -598,9 +598,28 @@ def _dense_ws(M, N, K, dev):
     return ws
 
 
-def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None):
+def dense_colsum(g):
+    """f32 column sums of a bf16 [rows, d] tensor (unit column stride): the bias gradient of a dense nn.Linear."""
+    _require_cuda(g)
+    rows, d = g.shape
+    if g.stride(1) != 1:
+        raise ValueError("dense_colsum: rows must be contiguous along d")
+    nblk = lib().octic_dense_gelu_blocks()
+    partials = torch.empty((nblk, d), dtype=torch.float32, device=g.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_colsum(_p(g), rows, d, g.stride(0), _p(partials), _stream(g)))
+    KERNEL_TIMER.stop(t, "dense_colsum_kernel", rows * d * 2)
+    out = torch.empty(d, dtype=torch.float32, device=g.device)
+    half = d // 2
+    check(lib().octic_dense_finish(_p(partials), nblk, half, _p(out), ctypes.c_void_p(out.data_ptr() + 4 * half),
+                                   _p(None), _stream(g)))
+    return out
+
+
+def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None, want_colsum=False):
     """C[M,N] = a[M,K] @ b[N,K]^T on the hand-written MFMA kernel (csrc/dense_gemm.hip) with a fused tail:
-    mode 0 -> c ; 1 -> (c, gelu(c)) ; 2 -> (c, x + rs*gamma*c) ; 3 -> gelu'(h) * c.  a, b bf16 2-D, K contiguous."""
+    mode 0 -> c ; 1 -> (c, gelu(c)) ; 2 -> (c, x + rs*gamma*c) ; 3 -> gelu'(h) * c (want_colsum: also the f32 column
+    sums of that result).  a, b bf16 2-D, K contiguous."""
     _require_cuda(a)
     M, K = a.shape
     N = b.shape[0]
@@ -610,9 +629,11 @@ def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h
     c2 = torch.empty_like(c) if mode == 1 else None
     out = torch.empty((M, N), dtype=torch.float32, device=a.device) if mode == 2 else None
     ws = _dense_ws(M, N, K, a.device)
+    cs_rows = lib().octic_dense_gemm_colsum_rows(M, N, K) if (mode == 3 and want_colsum) else 0
+    cs = torch.empty((cs_rows, N), dtype=torch.float32, device=a.device) if cs_rows else None
     t = KERNEL_TIMER.start()
     check(lib().octic_dense_gemm_nt(_p(a), _p(b), M, N, K, a.stride(0), b.stride(0), mode, _p(c), _p(c2), N, _p(bias),
-                                    _p(gamma), _p(rs), int(rps), _p(x), _p(out), _p(h), _p(ws), _stream(a)))
+                                    _p(gamma), _p(rs), int(rps), _p(x), _p(out), _p(h), _p(cs), _p(ws), _stream(a)))
     if t is not None:
         nb = 2 * (M * K + N * K + M * N * (2 if mode in (1, 3) else 1)) + (8 * M * N if mode == 2 else 0)
         KERNEL_TIMER.stop(t, name or f"dense_nt_kernel<{mode}>", nb, 2.0 * M * N * K)
@@ -620,4 +641,9 @@ def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h
         return c, c2
     if mode == 2:
         return c, out
+    if cs is not None:
+        colsum = torch.empty(N, dtype=torch.float32, device=a.device)
+        check(lib().octic_dense_finish(_p(cs), cs_rows, N // 2, _p(colsum), ctypes.c_void_p(colsum.data_ptr() + 2 * N),
+                                       _p(None), _stream(a)))
+        return c, colsum
     return c

@@ -96,6 +96,38 @@ def test_dense_nt_dgelu(M, N, K):
     hf = h.double().requires_grad_(True)
     torch.nn.functional.gelu(hf).backward(g.double())
     close(d, hf.grad, 1e-2, "dgelu")
+    # fc1's bias gradient from the same epilogue: the f32 column sums of the bf16 result it stored (fixed order -> the same
+    # bits on every launch), split-K tail tiles included (16448 x 5120 x 1280: 20 tiles cut five ways)
+    d2, cs = o.dense_gemm_nt(a, b, 3, h=h, want_colsum=True)
+    assert torch.equal(d2, d)
+    want = d.double().sum(0)
+    assert float((cs.double() - want).abs().max()) <= 1e-5 * max(1.0, float(d.double().abs().sum(0).max()))
+    assert torch.equal(o.dense_gemm_nt(a, b, 3, h=h, want_colsum=True)[1], cs)
+
+
+@pytest.mark.parametrize("M,N,K", [(16448, 1280, 1280), (16448, 1280, 5120), (16448, 5120, 1280), (3000, 520, 4096),
+                                   (2100, 264, 2048)])
+def test_dense_nt_split_tail_is_bitwise_repeatable(M, N, K):
+    """The last partial round of tiles is cut along K when that pays (long K, or a ragged last row panel); the last
+    arriver sums the partial tiles in slab order, rows past M never travel: ten launches give the same bits."""
+    o = ops()
+    a, b = rnd((M, K), 41), rnd((N, K), 42, K ** -0.5)
+    bias = rnd((N,), 43, dtype=torch.float32)
+    first = o.dense_gemm_nt(a, b, 0, bias=bias)
+    for _ in range(9):
+        assert torch.equal(o.dense_gemm_nt(a, b, 0, bias=bias), first)
+    close(first, a.double() @ b.double().t() + bias.double(), 1e-2, "split tail")
+
+
+@pytest.mark.parametrize("rows,d,ld", [(16448, 3840, 3840), (1000, 264, 264), (257, 1280, 3840), (5, 8, 8)])
+def test_dense_colsum_matches_f32_sum(rows, d, ld):
+    """qkv bias gradient: f32 column sums of the bf16 cotangent (autograd's grad.sum(0), deit/vit.py:33)."""
+    o = ops()
+    g = rnd((rows, ld), 51)[:, :d]
+    got = o.dense_colsum(g)
+    want = g.double().sum(0)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(g.double().abs().sum(0).max()))
+    assert torch.equal(o.dense_colsum(g), got)
 
 
 def test_dense_prep_batch_matches_torch():
