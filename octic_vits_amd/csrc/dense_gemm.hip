@@ -233,8 +233,15 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)((int64_t)a.M * a.lda * 2), 0x27000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)((int64_t)a.N * a.ldb * 2), 0x27000);
   const int r0 = 16 * wid + drow;                                   // unit row of instruction 0
-  const unsigned voA = (unsigned)(((int64_t)(m0 + (r0 >> 6) * 128 + (r0 & 63)) * a.lda + dch * 8) * 2);
-  const unsigned voB = (unsigned)(((int64_t)(n0 + (r0 >> 5) * 64 + (r0 & 31)) * a.ldb + dch * 8) * 2);
+#if DG_ABL & 8    // timing-only ablation: every tile reads the operand panels of tile (0, 0) (all-L2-hit operand stream)
+  const int am0 = 0, an0 = 0;
+#elif DG_ABL & 16  // timing-only ablation: A panels as they are, every tile reads B panel 0
+  const int am0 = m0, an0 = 0;
+#else
+  const int am0 = m0, an0 = n0;
+#endif
+  const unsigned voA = (unsigned)(((int64_t)(am0 + (r0 >> 6) * 128 + (r0 & 63)) * a.lda + dch * 8) * 2);
+  const unsigned voB = (unsigned)(((int64_t)(an0 + (r0 >> 5) * 64 + (r0 & 31)) * a.ldb + dch * 8) * 2);
   const int rowA8 = (int)(a.lda * 16), rowB8 = (int)(a.ldb * 16);   // +8 rows, bytes
   const int halfA = (int)(a.lda * 128), halfB = (int)(a.ldb * 64);  // +64 rows of A, +32 rows of B, bytes
   const int kbase = kt_begin * (DG_BK * 2);

@@ -605,6 +605,10 @@ def track_optimizer(model, optimizer):
 WGRAD_F32_OUT = False      # True: library weight gradients as torch.mm(..., out_dtype=float32) (no bf16 rounding of
                            # dW; measured equal in step time, but outside the shipped TunableOp table)
 DENSE_HIP = {"qkv", "dqkv", "proj", "dproj", "fc1", "dfc1", "fc2", "dfc2"}    # any subset (bench.py --dense-hip)
+# proj / fc2 on the hand-written kernel: x + rs*gamma*y inside the GEMM's epilogue (True) or as the separate row kernel
+# after a plain epilogue (False).  The fused tail reads and writes the f32 residual stream tile by tile at the end of a
+# workgroup with nothing to overlap it (one workgroup per CU): in the step it costs more than the 35 us row pass.
+DENSE_RESID_FUSED = False
 
 
 def dense_hip_ok(x, w, which=None):
@@ -720,8 +724,12 @@ class DenseProjResidFn(torch.autograd.Function):
         wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP)
         a2 = ab.reshape(-1, wb.shape[1])
         g32, rs32 = _f32(gamma), _f32(rs)
-        y, out = ops.dense_gemm_nt(a2, wb, 2, bias=_f32(b), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, wb.shape[0]),
-                                   name="dense_nt_kernel<resid>")
+        if DENSE_RESID_FUSED:
+            y, out = ops.dense_gemm_nt(a2, wb, 2, bias=_f32(b), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, wb.shape[0]),
+                                       name="dense_nt_kernel<resid>")
+        else:
+            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>")
+            out = ops.scale_residual_fwd(x.view(-1, wb.shape[0]), y, g32, rs32, rps)
         ctx.save_for_backward(a2, wb, wt, y, g32, rs32)
         ctx.meta = (rps, b is not None, gamma is not None, a.dtype, a.shape)
         return out.view(x.shape)
@@ -760,9 +768,12 @@ class DenseMlpFn(torch.autograd.Function):
         else:
             h = _linear_lib(y2, w1b, None if b1 is None else c1.b)
             a = torch.nn.functional.gelu(h)
-        if "fc2" in DENSE_HIP:
+        if "fc2" in DENSE_HIP and DENSE_RESID_FUSED:
             br, out = ops.dense_gemm_nt(a, w2b, 2, bias=_f32(b2), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, w2b.shape[0]),
                                         name="dense_nt_kernel<resid>")
+        elif "fc2" in DENSE_HIP:
+            br = ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>")
+            out = ops.scale_residual_fwd(x.view(-1, w2b.shape[0]), br, g32, rs32, rps)
         else:
             br = _linear_lib(a, w2b, None if b2 is None else c2.b)
             out = ops.scale_residual_fwd(x.view(-1, w2b.shape[0]), br, g32, rs32, rps)

@@ -19,7 +19,8 @@ L = _lib.lib()
 L.octic_dbg_dense_trace2.restype = ctypes.c_void_p
 hip = ctypes.CDLL("libamdhip64.so")
 M = 16448
-for (N, K, mode) in ((5120, 1280, 0), (1280, 5120, 0), (1280, 1280, 0)):
+SHAPES = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("SHAPES", "5120x1280x0,1280x5120x0,1280x1280x0").split(",")]
+for (N, K, mode) in SHAPES:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     b = (torch.randn(N, K, device="cuda") / 36).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda")
