@@ -351,9 +351,14 @@ template <typename TS>
 __global__ __launch_bounds__(256) void dense_prep_batch_kernel(const octic_dense_prep_item* __restrict__ items, int n_items) {
   __shared__ float tile[64][65];
   const int b = blockIdx.x;
-  int it = 0;
-  for (int i = 1; i < n_items; ++i)
-    if (b >= items[i].block_begin) it = i;
+  // items are sorted by block_begin: this block's item = (number of items starting at or before it) - 1, counted by the
+  // whole workgroup at once (a per-thread scan of the table was most of a 64 x 64 tile's time)
+  int cnt = 0;
+  for (int i0 = 0; i0 < n_items; i0 += 256) {
+    const int i = i0 + (int)threadIdx.x;
+    cnt += __syncthreads_count(i < n_items && b >= items[i].block_begin);
+  }
+  const int it = cnt > 0 ? cnt - 1 : 0;
   const octic_dense_prep_item& I = items[it];
   const int N = I.N, K = I.K;
   const int lt = b - I.block_begin;
