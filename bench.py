@@ -322,10 +322,14 @@ def main():
             # `roofline` = the kernel with the largest total time in the timed steps.  Library GEMMs are ranked the way a
             # profiler sees them - per operation kind (all weight-gradient shapes run the same hipBLASLt kernel family),
             # not split by shape - so a 10 % library family is not hidden behind a 6 % hand-written kernel.
-            cands = {n: a for n, a in agg.items() if not n.startswith(("library_gemm", "dense_tn_kernel<"))}
+            nt0 = [n for n in agg if n in ("dense_nt_kernel<plain>", "dense_nt_kernel<dgrad>", "dense_nt_kernel<proj>",
+                                           "dense_nt_kernel<fc2>")]
+            cands = {n: a for n, a in agg.items() if not n.startswith(("library_gemm", "dense_tn_kernel<")) and n not in nt0}
             tn = [n for n in agg if n.startswith("dense_tn_kernel<")]
             if tn:    # one kernel symbol (csrc/dense_wgrad.hip) over the four weight-gradient shapes
                 cands["dense_tn_kernel<wgrad, all shapes>"] = merged(tn, "dense_tn_kernel<wgrad, all shapes>")
+            if nt0:   # one kernel symbol too: dense_nt_kernel<0> = qkv / proj / fc2 forward and the four input gradients
+                cands["dense_nt_kernel<0>"] = merged(nt0, "dense_nt_kernel<0>")
             for kind in ("fwd", "dgrad", "wgrad"):
                 names = [n for n in agg if n.startswith(f"library_gemm<{kind} ")]
                 if names:

@@ -20,6 +20,10 @@
 // sets per operand).  Consecutive K-tiles alternate which 32-column half goes first so the prefetch never targets a
 // live register set.
 //
+// (A PERSISTENT variant - one workgroup per CU walking items, the next item's DMA prologue issued before the current
+// epilogue, the epilogue staged 16 rows at a time behind the ring - was built in round 3: per item the prologue + launch
+// gap + store acknowledgement went 2.3 -> 0.7 us and the 16-row epilogue cost 1.1 us more; 142 vs 147 us in isolation on
+// qkv, but 0.2-0.7 ms per step SLOWER in the train step with either tail order, so it is not kept.)
 // Scheduling: tiles are dealt to XCDs in contiguous chunks walked in groups of 8 row-panels (operand panels stay in the
 // XCD's L2).  M = 16 448 gives 65 x {5,15,20} tiles on 256 CUs: the last partial round would idle most of the chip, so
 // the tiles of that round are split along K over `split` workgroups each, placed at the FRONT of the grid (f32 partial

@@ -752,8 +752,8 @@ class DenseMlpFn(torch.autograd.Function):
     """x + rs * gamma * fc2(gelu(fc1(y))) of a standard block (timm Mlp inside deit/vit.py:131-134).  Per GEMM, routed by
     DENSE_HIP: fc1 with bias + exact-erf GELU in the epilogue (pre-activation kept for the backward), fc2 with bias, layer
     scale, stochastic depth and the f32 residual in the epilogue, fc2's input gradient with GELU' in its epilogue, fc1's
-    input gradient; otherwise the BLAS library with the row kernels of csrc/dense.hip around it.  Weight gradients stay
-    on the library."""
+    input gradient; otherwise the BLAS library with the row kernels of csrc/dense.hip around it.  Weight gradients:
+    csrc/dense_wgrad.hip (WGRAD_HIP)."""
 
     @staticmethod
     def forward(ctx, y, x, w1, b1, w2, b2, gamma, rs, rps, c1, c2):
