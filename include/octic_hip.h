@@ -271,6 +271,13 @@ int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const*
  * octic_dense_finish: out0[j] = sum_b slab[b][0][j];  out1[j] = scale1[j] * sum_b slab[b][1][j]
  *   (out0, out1, scale1 may each be NULL).                                                              */
 int octic_dense_blocks(int64_t rows);
+/* octic_dense_resid_layernorm_fwd: xout = x + rs[row / rows_per_scale] * gamma * yb (the tail of one branch of
+ * Layer_scale_init_Block, deit/vit.py:131-134) and y = LayerNorm(xout) (the norm that opens the next branch,
+ * deit/vit.py:132-133) in one row pass; stats[rows,2] = (mean, rstd) of xout.  Same arithmetic as
+ * octic_scale_residual_fwd followed by octic_dense_layernorm_fwd.                                            */
+int octic_dense_resid_layernorm_fwd(const float* x, const void* yb, int yb_dtype, const float* gamma, const float* rs,
+                                    int64_t rows_per_scale, float* xout, void* y, int y_dtype, const float* w,
+                                    const float* b, float* stats, int64_t rows, int d, float eps, void* stream);
 int octic_dense_layernorm_fwd(const float* x, void* y, int y_dtype, const float* w, const float* b, float* stats,
                               int64_t rows, int d, float eps, void* stream);
 int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const float* w, const float* stats,

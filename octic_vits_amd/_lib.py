@@ -49,6 +49,8 @@ _PROTOS = {
     "octic_dense_blocks": (c_int, [c_i64]),
     "octic_dense_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                                           c_float, c_void_p]),
+    "octic_dense_resid_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int,
+                                                c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p]),
     "octic_dense_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_i64, c_int, c_void_p]),
     "octic_dense_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -75,6 +75,67 @@ __global__ __launch_bounds__(256) void dense_ln_fwd_kernel(const float* __restri
   }
 }
 
+// Block tail + the LayerNorm that follows it, one row pass: xout = x + rs[row / rps] * gamma * yb (the residual stream after
+// the branch: same expression as scale_residual_fwd_kernel), y = LayerNorm(xout).  The stream is written once and not read
+// back (the two separate kernels move 210 + 126 MB per launch at ViT-H, this one 252).
+template <typename TY, typename TOUT, int NV>
+__global__ __launch_bounds__(256) void dense_resid_ln_fwd_kernel(const float* __restrict__ x, const TY* __restrict__ yb,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ rs,
+                                                                 long rps, float* __restrict__ xout, TOUT* __restrict__ y,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 float* __restrict__ stats, long rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * 4;
+  f32x4 wv[NV], bv[NV], gm[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    ok[i] = col < d;
+    wv[i] = (ok[i] && w) ? *(const f32x4*)(w + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bv[i] = (ok[i] && b) ? *(const f32x4*)(b + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gm[i] = (ok[i] && gamma) ? *(const f32x4*)(gamma + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+    const float* xr = x + r * d;
+    const TY* yr_in = yb + r * d;
+    float* xo = xout + r * d;
+    f32x4 xv[NV];
+    float s = 0.f;
+    const float rsv = rs ? rs[r / rps] : 1.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok[i]) {
+        const int col = (i * 64 + lane) * 4;
+        f32x4 sc = gm[i];
+        if (rs) sc *= rsv;
+        xv[i] = *(const f32x4*)(xr + col) + sc * Row4<TY>::load(yr_in + col);
+        *(f32x4*)(xo + col) = xv[i];
+      }
+      s += hsum(xv[i]);
+    }
+    const float mean = wave_total(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 c = xv[i] - mean;
+      xv[i] = c;
+      if (ok[i]) q += hsum(c * c);
+    }
+    const float rstd = rsqrtf(wave_total(q) * inv_d + eps);
+    TOUT* yr = y + r * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) Row4<TOUT>::store(yr + (i * 64 + lane) * 4, xv[i] * rstd * wv[i] + bv[i]);
+    if (lane == 0) {
+      stats[2 * r] = mean;
+      stats[2 * r + 1] = rstd;
+    }
+  }
+}
+
 // Fold the kDenseWaves per-wave register partials of a workgroup into its slab [2][d] (deterministic order).
 template <int NV>
 __device__ inline void slab_reduce(float* lds, float* slab, const f32x4 (&p0)[NV], const f32x4 (&p1)[NV],
@@ -438,6 +499,29 @@ int octic_dense_layernorm_fwd(const float* x, void* y, int y_dtype, const float*
   } else {
     DENSE_NV_SWITCH(dense_nv(d), (dense_ln_fwd_kernel<float, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (float*)y, w, b, stats, rows, d, eps)));
   }
+  return launch_status();
+}
+
+int octic_dense_resid_layernorm_fwd(const float* x, const void* yb, int yb_dtype, const float* gamma, const float* rs,
+                                    int64_t rows_per_scale, float* xout, void* y, int y_dtype, const float* w,
+                                    const float* b, float* stats, int64_t rows, int d, float eps, void* stream) {
+  if (rows == 0) return OCTIC_OK;
+  if (!x || !yb || !xout || !y || !stats) return OCTIC_ENULL;
+  if (int e = dense_check(rows, d)) return e;
+  if ((yb_dtype != OCTIC_F32 && yb_dtype != OCTIC_BF16) || (y_dtype != OCTIC_F32 && y_dtype != OCTIC_BF16)) return OCTIC_EDTYPE;
+  if (rs && rows_per_scale <= 0) return OCTIC_ESHAPE;
+  long blocks = (rows + 7) / 8;              // 2 rows per wave (41-42 us at ViT-H against 46 with 4: tools/bench_rln.py)
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  const long rps = rs ? rows_per_scale : 1;
+#define OCTIC_RLN(TYB, TO) \
+  DENSE_NV_SWITCH(dense_nv(d), (dense_resid_ln_fwd_kernel<TYB, TO, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>( \
+      x, (const TYB*)yb, gamma, rs, rps, xout, (TO*)y, w, b, stats, rows, d, eps)))
+  if (yb_dtype == OCTIC_BF16 && y_dtype == OCTIC_BF16) { OCTIC_RLN(bf16, bf16); }
+  else if (yb_dtype == OCTIC_BF16) { OCTIC_RLN(bf16, float); }
+  else if (y_dtype == OCTIC_BF16) { OCTIC_RLN(float, bf16); }
+  else { OCTIC_RLN(float, float); }
+#undef OCTIC_RLN
   return launch_status();
 }
 

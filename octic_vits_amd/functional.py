@@ -609,6 +609,9 @@ DENSE_HIP = {"qkv", "dqkv", "proj", "dproj", "fc1", "dfc1", "fc2", "dfc2"}    # 
 # after a plain epilogue (False).  The fused tail reads and writes the f32 residual stream tile by tile at the end of a
 # workgroup with nothing to overlap it (one workgroup per CU): in the step it costs more than the 35 us row pass.
 DENSE_RESID_FUSED = False
+# The residual add of a branch and the LayerNorm that opens the next one (norm2 of the same block, norm1 of the next
+# block) as ONE row pass (csrc/dense.hip dense_resid_ln_fwd_kernel): the f32 stream is written once and not read back.
+NEXT_NORM_FUSED = True
 
 
 def dense_hip_ok(x, w, which=None):
@@ -718,12 +721,25 @@ class DenseProjResidFn(torch.autograd.Function):
     fused epilogue; backward = one HIP row pass (gy, d gamma, bias gradient) + the input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, a, w, b, gamma, rs, rps, cache):
+    def forward(ctx, x, a, w, b, gamma, rs, rps, cache, nw=None, nb=None, neps=None):
+        """neps is not None: also return LayerNorm(out; nw, nb, neps) in bf16 - the norm that opens the next branch - from
+        the same row pass that adds the residual (NEXT_NORM_FUSED)."""
         x = _c(x)
         ab = _c(a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16))
         wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP)
         a2 = ab.reshape(-1, wb.shape[1])
         g32, rs32 = _f32(gamma), _f32(rs)
+        ctx.norm = neps is not None
+        ctx.x_shape = x.shape
+        if ctx.norm:
+            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>")
+            nw32, nb32 = _f32(nw), _f32(nb)
+            out, yn, stats = ops.dense_resid_layernorm_fwd(x.view(-1, wb.shape[0]), y, g32, rs32, rps, nw32, nb32, neps,
+                                                           torch.bfloat16)
+            ctx.save_for_backward(a2, wb, wt, y, g32, rs32, out, stats, nw32)
+            ctx.meta = (rps, b is not None, gamma is not None, a.dtype, a.shape, nw is not None, nb is not None)
+            ctx.set_materialize_grads(False)
+            return out.view(x.shape), yn.view(x.shape)
         if DENSE_RESID_FUSED:
             y, out = ops.dense_gemm_nt(a2, wb, 2, bias=_f32(b), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, wb.shape[0]),
                                        name="dense_nt_kernel<resid>")
@@ -735,9 +751,19 @@ class DenseProjResidFn(torch.autograd.Function):
         return out.view(x.shape)
 
     @staticmethod
-    def backward(ctx, gout):
-        a2, wb, wt, y, g32, rs32 = ctx.saved_tensors
-        rps, has_b, has_gamma, a_dtype, a_shape = ctx.meta
+    def backward(ctx, gout, gyn=None):
+        dnw = dnb = None
+        if ctx.norm:
+            a2, wb, wt, y, g32, rs32, out, stats, nw32 = ctx.saved_tensors
+            rps, has_b, has_gamma, a_dtype, a_shape, has_nw, has_nb = ctx.meta
+            if gyn is not None:      # LayerNorm backward with the residual cotangent added in the same pass
+                want = has_nw and (ctx.needs_input_grad[8] or ctx.needs_input_grad[9])
+                dres = None if gout is None else _c(gout.float()).view(out.shape)
+                gout, dnw, dnb = ops.dense_layernorm_bwd(_c(gyn).view(out.shape), out, nw32, stats, dres, want_param_grads=want)
+                dnw, dnb = (dnw if has_nw else None), (dnb if has_nb else None)
+        else:
+            a2, wb, wt, y, g32, rs32 = ctx.saved_tensors
+            rps, has_b, has_gamma, a_dtype, a_shape = ctx.meta
         gout = _c(gout.float())
         gy, dgamma, colsum = ops.scale_residual_bwd(gout.view(y.shape), y, g32, rs32, rps, want_gamma=has_gamma,
                                                     want_colsum=has_b)
@@ -745,7 +771,7 @@ class DenseProjResidFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
                   else _mm_lib(gy, wb)).view(a_shape).to(a_dtype)
-        return gout, ga, _wgrad_lib(gy, a2), colsum, dgamma, None, None, None
+        return gout.view(ctx.x_shape), ga, _wgrad_lib(gy, a2), colsum, dgamma, None, None, None, dnw, dnb, None
 
 
 class DenseMlpFn(torch.autograd.Function):
@@ -756,7 +782,9 @@ class DenseMlpFn(torch.autograd.Function):
     csrc/dense_wgrad.hip (WGRAD_HIP)."""
 
     @staticmethod
-    def forward(ctx, y, x, w1, b1, w2, b2, gamma, rs, rps, c1, c2):
+    def forward(ctx, y, x, w1, b1, w2, b2, gamma, rs, rps, c1, c2, nw=None, nb=None, neps=None):
+        """neps is not None: also return LayerNorm(out; nw, nb, neps) in bf16 (the NEXT block's norm1) from the row pass
+        that adds the residual."""
         x = _c(x)
         yb = _c(y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16))
         w1b, w1t = c1.get_nt(w1, b1, "dfc1" in DENSE_HIP)
@@ -768,6 +796,18 @@ class DenseMlpFn(torch.autograd.Function):
         else:
             h = _linear_lib(y2, w1b, None if b1 is None else c1.b)
             a = torch.nn.functional.gelu(h)
+        ctx.norm = neps is not None
+        ctx.x_shape = x.shape
+        if ctx.norm:
+            br = (ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>") if "fc2" in DENSE_HIP
+                  else _linear_lib(a, w2b, None if b2 is None else c2.b))
+            nw32, nb32 = _f32(nw), _f32(nb)
+            out, yn, stats = ops.dense_resid_layernorm_fwd(x.view(-1, w2b.shape[0]), br, g32, rs32, rps, nw32, nb32, neps,
+                                                           torch.bfloat16)
+            ctx.save_for_backward(y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32, out, stats, nw32)
+            ctx.meta = (rps, b1 is not None, b2 is not None, gamma is not None, y.dtype, y.shape, nw is not None, nb is not None)
+            ctx.set_materialize_grads(False)
+            return out.view(x.shape), yn.view(x.shape)
         if "fc2" in DENSE_HIP and DENSE_RESID_FUSED:
             br, out = ops.dense_gemm_nt(a, w2b, 2, bias=_f32(b2), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, w2b.shape[0]),
                                         name="dense_nt_kernel<resid>")
@@ -782,9 +822,19 @@ class DenseMlpFn(torch.autograd.Function):
         return out.view(x.shape)
 
     @staticmethod
-    def backward(ctx, gout):
-        y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32 = ctx.saved_tensors
-        rps, has_b1, has_b2, has_gamma, y_dtype, y_shape = ctx.meta
+    def backward(ctx, gout, gyn=None):
+        dnw = dnb = None
+        if ctx.norm:
+            y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32, out, stats, nw32 = ctx.saved_tensors
+            rps, has_b1, has_b2, has_gamma, y_dtype, y_shape, has_nw, has_nb = ctx.meta
+            if gyn is not None:      # LayerNorm backward with the residual cotangent added in the same pass
+                want = has_nw and (ctx.needs_input_grad[11] or ctx.needs_input_grad[12])
+                dres = None if gout is None else _c(gout.float()).view(out.shape)
+                gout, dnw, dnb = ops.dense_layernorm_bwd(_c(gyn).view(out.shape), out, nw32, stats, dres, want_param_grads=want)
+                dnw, dnb = (dnw if has_nw else None), (dnb if has_nb else None)
+        else:
+            y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32 = ctx.saved_tensors
+            rps, has_b1, has_b2, has_gamma, y_dtype, y_shape = ctx.meta
         gout = _c(gout.float())
         gbr, dgamma, db2 = ops.scale_residual_bwd(gout.view(br.shape), br, g32, rs32, rps, want_gamma=has_gamma,
                                                   want_colsum=has_b2)
@@ -801,7 +851,7 @@ class DenseMlpFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>") if w1t is not None
                   else _mm_lib(dh, w1b)).view(y_shape).to(y_dtype)
-        return gy, gout, gw1, db1, gw2, db2, dgamma, None, None, None, None
+        return gy, gout.view(ctx.x_shape), gw1, db1, gw2, db2, dgamma, None, None, None, None, dnw, dnb, None
 
 
 # -------------------------------------------------------------------------------------- hand-off

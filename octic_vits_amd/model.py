@@ -73,6 +73,8 @@ class OcticVisionTransformer(nn.Module):
             for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        from .vit import link_blocks
+        link_blocks(self.blocks[self.octic_equi_break_layer:])      # residual add + next norm1 as one row pass
 
         std = 8 * .02  # model.py:147
         if self.num_register_tokens > 0:

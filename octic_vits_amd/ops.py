@@ -512,6 +512,21 @@ def dense_layernorm_fwd(x, w, b, eps, out_dtype):
     return y, stats
 
 
+def dense_resid_layernorm_fwd(x, yb, gamma, rs, rps, w, b, eps, out_dtype):
+    """xout = x + rs[row // rps] * gamma * yb ; y = LayerNorm(xout) in one row pass -> (xout f32, y out_dtype, stats)."""
+    _require_cuda(x)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    xout = torch.empty_like(x)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_resid_layernorm_fwd(_p(x), _p(yb), dt_code(yb.dtype), _p(gamma), _p(rs), int(rps), _p(xout), _p(y),
+                                                dt_code(out_dtype), _p(w), _p(b), _p(stats), rows, d, float(eps), _stream(x)))
+    KERNEL_TIMER.stop(t, f"dense_resid_ln_fwd_kernel<{_DTN[out_dtype]}>", rows * d * (8 + yb.element_size() + y.element_size()))
+    return xout, y, stats
+
+
 def dense_layernorm_bwd(gy, x, w, stats, dres, want_param_grads=True):
     """Returns (dx f32 = LN'(gy) + dres, dw, db)."""
     d = x.shape[-1]

@@ -47,12 +47,19 @@ class Mlp(nn.Module):
         return (not drop and isinstance(self.norm, nn.Identity) and type(self.act) is nn.GELU
                 and self.act.approximate == "none" and type(self.fc1) is nn.Linear and type(self.fc2) is nn.Linear)
 
-    def forward_fused(self, y, xres, gamma, rs, dtype):
-        """xres + rs*gamma*fc2(gelu(fc1(y))) with y already normalised and in the compute dtype."""
+    def forward_fused(self, y, xres, gamma, rs, dtype, next_norm=None):
+        """xres + rs*gamma*fc2(gelu(fc1(y))) with y already normalised and in the compute dtype.  next_norm (an
+        nn.LayerNorm): the hand-written path also returns next_norm(result) from the residual row pass -> (x, y_next)."""
         if (dtype == torch.bfloat16 and _OF.dense_hip_ok(y, self.fc1.weight) and _OF.dense_hip_ok(y, self.fc2.weight)
                 and ({"fc1", "fc2", "dfc1", "dfc2"} & _OF.DENSE_HIP)):
+            if next_norm is not None:
+                return _OF.DenseMlpFn.apply(y, xres, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gamma,
+                                            rs, y.shape[1], self._c1, self._c2, next_norm.weight, next_norm.bias,
+                                            next_norm.eps)
             return _OF.DenseMlpFn.apply(y, xres, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gamma,
                                         rs, y.shape[1], self._c1, self._c2)
+        if next_norm is not None:
+            return self.forward_fused(y, xres, gamma, rs, dtype), None
         if dtype == torch.bfloat16 and self.fc1.out_features % 8 == 0:
             h = _OF.DenseLinearGeluFn.apply(y, self.fc1.weight, self.fc1.bias, self._c1)
         else:
@@ -80,8 +87,9 @@ class Attention(nn.Module):
         return (not drop and self.fused_attn and type(self.qkv) is nn.Linear and type(self.proj) is nn.Linear
                 and _ops.attn_supported(N, self.qkv.in_features // self.num_heads, dtype))
 
-    def forward_fused(self, y, xres, gamma, rs, dtype):
-        """xres + rs*gamma*proj(attention(qkv(y))) with y already normalised and in the compute dtype."""
+    def forward_fused(self, y, xres, gamma, rs, dtype, next_norm=None):
+        """xres + rs*gamma*proj(attention(qkv(y))) with y already normalised and in the compute dtype.  next_norm (an
+        nn.LayerNorm): the hand-written path also returns next_norm(result) from the residual row pass -> (x, y_next)."""
         B, N, C = y.shape
         hd = C // self.num_heads
         bf = dtype == torch.bfloat16
@@ -91,8 +99,12 @@ class Attention(nn.Module):
             qkv = _OF.DenseLinearFn.apply(y, self.qkv.weight, self.qkv.bias, dtype, self._c1)
         a = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
         if bf and _OF.dense_hip_ok(y, self.proj.weight, "proj"):
+            if next_norm is not None:
+                return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2,
+                                                  next_norm.weight, next_norm.bias, next_norm.eps)
             return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2)
-        return _OF.LinearScaleResidualFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, dtype, self._c2)
+        out = _OF.LinearScaleResidualFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, dtype, self._c2)
+        return out if next_norm is None else (out, None)
 
     def forward(self, x):
         B, N, C = x.shape
@@ -127,9 +139,13 @@ def _drop_path_scale(dp, x):
     return mask.view(-1)
 
 
-def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2):
-    """bf16-autocast forward of one standard block on the engine's row kernels + library GEMMs, or None when the
-    block is not in that regime (f32 run, CPU, dropout active, exotic sub-modules): the caller then runs eager."""
+def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2, next_norm=None):
+    """bf16-autocast forward of one standard block on the engine's row kernels + GEMMs, or None when the block is not
+    in that regime (f32 run, CPU, dropout active, exotic sub-modules): the caller then runs eager.
+    With functional.NEXT_NORM_FUSED the residual add of a branch and the LayerNorm that opens the next branch are one row
+    pass: norm2 comes out of the attention branch's tail; norm1 of the NEXT block (next_norm, set by link_blocks) out of
+    the MLP's tail and travels as an attribute of the returned stream tensor (`_octic_prenorm`), which that block picks
+    up instead of running its own norm1."""
     if not (x.is_cuda and x.ndim == 3 and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
             and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         return None
@@ -144,10 +160,36 @@ def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2):
         if not isinstance(dp, (DropPath, nn.Identity)):
             return None
     dt = torch.bfloat16
-    y, xres = _OF.DenseLayerNormFn.apply(x, norm1.weight, norm1.bias, norm1.eps, dt)
-    x = attn.forward_fused(y, xres, gamma1, _drop_path_scale(dp1, x), dt)
-    y, xres = _OF.DenseLayerNormFn.apply(x, norm2.weight, norm2.bias, norm2.eps, dt)
+    fuse = _OF.NEXT_NORM_FUSED
+    pre = getattr(x, "_octic_prenorm", None)
+    if pre is not None and pre[0] is norm1 and pre[1] is not None:
+        y, xres = pre[1], x                   # normalised by the previous block's residual pass
+    else:
+        y, xres = _OF.DenseLayerNormFn.apply(x, norm1.weight, norm1.bias, norm1.eps, dt)
+    y2 = None
+    if fuse:
+        x, y2 = attn.forward_fused(y, xres, gamma1, _drop_path_scale(dp1, x), dt, next_norm=norm2)
+    else:
+        x = attn.forward_fused(y, xres, gamma1, _drop_path_scale(dp1, x), dt)
+    if y2 is not None:
+        y, xres = y2, x
+    else:
+        y, xres = _OF.DenseLayerNormFn.apply(x, norm2.weight, norm2.bias, norm2.eps, dt)
+    if fuse and type(next_norm) is nn.LayerNorm and tuple(next_norm.normalized_shape) == (d,):
+        out, yn = mlp.forward_fused(y, xres, gamma2, _drop_path_scale(dp2, x), dt, next_norm=next_norm)
+        if yn is not None:
+            out._octic_prenorm = (next_norm, yn)
+        return out
     return mlp.forward_fused(y, xres, gamma2, _drop_path_scale(dp2, x), dt)
+
+
+def link_blocks(blocks):
+    """Tell every standard block which LayerNorm follows it (norm1 of the next standard block in `blocks`), so that its
+    MLP tail can emit that norm's output (functional.NEXT_NORM_FUSED).  The reference is held in a tuple: it is not a
+    sub-module, state_dict keys do not change."""
+    seq = [b for b in blocks if isinstance(b, (Layer_scale_init_Block, Block))]
+    for cur, nxt in zip(seq[:-1], seq[1:]):
+        cur._next_norm = (nxt.norm1,)
 
 
 class Layer_scale_init_Block(nn.Module):
@@ -165,8 +207,9 @@ class Layer_scale_init_Block(nn.Module):
         self.gamma_2 = nn.Parameter(init_values * torch.ones((dim)), requires_grad=True)
 
     def forward(self, x):
+        nn_ = getattr(self, "_next_norm", None)
         out = _fused_block(x, self.norm1, self.attn, self.gamma_1, self.drop_path, self.norm2, self.mlp, self.gamma_2,
-                           self.drop_path)
+                           self.drop_path, next_norm=nn_[0] if nn_ else None)
         if out is not None:
             return out
         x = x + self.drop_path(self.gamma_1 * self.attn(self.norm1(x)))
@@ -203,8 +246,10 @@ class Block(nn.Module):
         ls_ok = all(isinstance(ls, nn.Identity) or (isinstance(ls, LayerScale) and not ls.inplace)
                     for ls in (self.ls1, self.ls2))
         if ls_ok:
+            nn_ = getattr(self, "_next_norm", None)
             out = _fused_block(x, self.norm1, self.attn, getattr(self.ls1, "gamma", None), self.drop_path1, self.norm2,
-                               self.mlp, getattr(self.ls2, "gamma", None), self.drop_path2)
+                               self.mlp, getattr(self.ls2, "gamma", None), self.drop_path2,
+                               next_norm=nn_[0] if nn_ else None)
             if out is not None:
                 return out
         x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))

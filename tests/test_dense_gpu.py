@@ -198,3 +198,63 @@ def test_new_entry_points_reject_bad_arguments():
     x = torch.zeros(4, 16, device=DEV)
     assert L.octic_scale_residual_fwd(p(x), p(x), 7, None, None, 1, p(x), 4, 16, None) == -3   # OCTIC_EDTYPE
     assert L.octic_linear_d8_prep_batch_blocks(160, 640) == 4 * 3 * 10 + 5 * 20
+
+
+@pytest.mark.parametrize("rows,T,d,ydt", [(150, 50, 132, torch.bfloat16), (16448, 257, 1280, torch.bfloat16),
+                                          (771, 257, 768, torch.float32), (5, 5, 4, torch.bfloat16)])
+def test_resid_layernorm_fwd_equals_the_two_passes(rows, T, d, ydt):
+    """octic_dense_resid_layernorm_fwd = octic_scale_residual_fwd followed by octic_dense_layernorm_fwd, bit for bit
+    (stream, normalised rows and statistics)."""
+    o = ops()
+    x = gen(11, rows, d).to(DEV)
+    yb = gen(12, rows, d).to(DEV).to(ydt)
+    gamma = (gen(13, d) * 0.1).to(DEV)
+    rs = (torch.arange(rows // T) % 3 != 0).float().div(0.66).to(DEV)
+    w, b = (gen(14, d) * 0.3 + 1).to(DEV), (gen(15, d) * 0.2).to(DEV)
+    for g_, r_ in ((gamma, rs), (None, None), (gamma, None)):
+        out = o.scale_residual_fwd(x, yb, g_, r_, T)
+        y, st = o.dense_layernorm_fwd(out, w, b, 1e-6, torch.bfloat16)
+        out2, y2, st2 = o.dense_resid_layernorm_fwd(x, yb, g_, r_, T, w, b, 1e-6, torch.bfloat16)
+        assert torch.equal(out2, out) and torch.equal(y2, y) and torch.equal(st2, st)
+
+
+def test_next_norm_fusion_is_bitwise_the_unfused_block_chain():
+    """Three chained standard blocks (vit.link_blocks): with the residual add + next LayerNorm as one row pass the output
+    and every gradient equal the unfused chain bit for bit; the fused chain runs ONE stand-alone LayerNorm (the first
+    block's norm1), the unfused one six."""
+    from octic_vits_amd import functional as OF, vit
+    dim, heads, B, T = 128, 4, 4, 50
+    blocks = torch.nn.ModuleList([_blocks("layer_scale", dim, heads, 0.0)[0] for _ in range(3)])
+    for i, blk in enumerate(blocks):
+        for j, p in enumerate(blk.parameters()):
+            torch.manual_seed(100 * i + j)
+            p.data.add_(torch.randn_like(p) * 0.05)
+    vit.link_blocks(blocks)
+    x = gen(21, B, T, dim).to(DEV)
+    gout = gen(22, B, T, dim).to(DEV)
+    o = ops()
+    res = {}
+    saved = OF.NEXT_NORM_FUSED
+    try:
+        for mode in (True, False):
+            OF.NEXT_NORM_FUSED = mode
+            for p in blocks.parameters():
+                p.grad = None
+            xg = x.clone().requires_grad_(True)
+            o.KERNEL_TIMER.enable()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h = xg
+                for blk in blocks:
+                    h = blk(h)
+            h.backward(gout)
+            s = o.KERNEL_TIMER.summary()
+            o.KERNEL_TIMER.disable()
+            res[mode] = (h.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in blocks.parameters()],
+                         sum(v["launches"] for n, v in s.items() if n.startswith("dense_ln_fwd")),
+                         sum(v["launches"] for n, v in s.items() if n.startswith("dense_resid_ln_fwd")))
+    finally:
+        OF.NEXT_NORM_FUSED = saved
+    assert res[True][3] == 1 and res[True][4] == 5 and res[False][3] == 6 and res[False][4] == 0
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for (n, _), a, b in zip(blocks.named_parameters(), res[True][2], res[False][2]):
+        assert torch.equal(a, b), n
