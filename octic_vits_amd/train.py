@@ -335,7 +335,8 @@ def synthetic_batch(batch, num_classes, device, seed, img_size=224):
 
 
 def use_tuned_gemms(table=None):
-    """The standard half of the hybrid runs its four projections per block on the library GEMMs (hipBLASLt / rocBLAS).
+    """Library GEMMs (hipBLASLt / rocBLAS) serve the standard half wherever the hand-written kernels are de-selected or
+    refuse a shape (functional.DENSE_HIP / WGRAD_HIP; on the ViT-H bench path none is left since round 3).
     Which library solution is fastest per (layout, m, n, k) was searched once on an MI355X with PyTorch's TunableOp and
     is shipped as a lookup table; this only loads it (tuning itself stays off, so a step never searches).  Shapes that
     are not in the table, or a library build whose validators differ, fall back to the library default."""

@@ -2,7 +2,8 @@
 the reference (deit/vit.py:14-134 ``Attention``/``Layer_scale_init_Block``; timm 1.0.12 ``Block`` for the
 bare default, model.py:21,63).  In f32 / on CPU these are stock PyTorch ops like the reference.  Under bf16 autocast on the
 GPU a block runs on the engine instead (§8f-1, §8f-3): HIP LayerNorm / attention / layer-scale+drop-path+residual
-kernels around the four library GEMMs, with cached bf16 weights — same math, same parameters, same RNG draws."""
+kernels around hand-written GEMMs (csrc/dense_gemm.hip, csrc/dense_wgrad.hip; the BLAS library only for shapes they
+refuse), with cached bf16 weights — same math, same parameters, same RNG draws."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
