@@ -14,14 +14,20 @@ constexpr int kDenseMaxBlocks = 256;    // partial-sum slabs per launch
 
 template <typename T> struct Row4;
 template <> struct Row4<float> {
+  typedef f32x4 vec;
   static __device__ inline f32x4 load(const float* p) { return *(const f32x4*)p; }
+  static __device__ inline f32x4 load_raw(const float* p) { return *(const f32x4*)p; }
+  static __device__ inline f32x4 widen(f32x4 v) { return v; }
   static __device__ inline void store(float* p, f32x4 v) { *(f32x4*)p = v; }
 };
 template <> struct Row4<bf16> {
+  typedef bf16x4 vec;
   static __device__ inline f32x4 load(const bf16* p) {
     bf16x4 h = *(const bf16x4*)p;
     return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
   }
+  static __device__ inline bf16x4 load_raw(const bf16* p) { return *(const bf16x4*)p; }
+  static __device__ inline f32x4 widen(bf16x4 h) { return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
   static __device__ inline void store(bf16* p, f32x4 v) {
     *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
   }
@@ -104,17 +110,33 @@ __global__ __launch_bounds__(256) void dense_resid_ln_fwd_kernel(const float* __
     f32x4 xv[NV];
     float s = 0.f;
     const float rsv = rs ? rs[r / rps] : 1.f;
+    if (NV <= 6 && d == NV * 256) {   // every lane has all chunks: the 2 NV loads of the row go out before the first use
+      typename Row4<TY>::vec yv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok[i]) {
-        const int col = (i * 64 + lane) * 4;
+      for (int i = 0; i < NV; ++i) xv[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) yv[i] = Row4<TY>::load_raw(yr_in + (i * 64 + lane) * 4);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
         f32x4 sc = gm[i];
         if (rs) sc *= rsv;
-        xv[i] = *(const f32x4*)(xr + col) + sc * Row4<TY>::load(yr_in + col);
-        *(f32x4*)(xo + col) = xv[i];
+        xv[i] = xv[i] + sc * Row4<TY>::widen(yv[i]);
+        *(f32x4*)(xo + (i * 64 + lane) * 4) = xv[i];
+        s += hsum(xv[i]);
       }
-      s += hsum(xv[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[i]) {
+          const int col = (i * 64 + lane) * 4;
+          f32x4 sc = gm[i];
+          if (rs) sc *= rsv;
+          xv[i] = *(const f32x4*)(xr + col) + sc * Row4<TY>::load(yr_in + col);
+          *(f32x4*)(xo + col) = xv[i];
+        }
+        s += hsum(xv[i]);
+      }
     }
     const float mean = wave_total(s) * inv_d;
     float q = 0.f;
@@ -140,8 +162,8 @@ __global__ __launch_bounds__(256) void dense_resid_ln_fwd_kernel(const float* __
 template <int NV>
 __device__ inline void slab_reduce(float* lds, float* slab, const f32x4 (&p0)[NV], const f32x4 (&p1)[NV],
                                    const bool (&ok)[NV], int d) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int wv = 0; wv < kDenseWaves; ++wv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int wv = 0; wv < nwaves; ++wv) {
     if (wave == wv) {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
@@ -214,6 +236,64 @@ __global__ __launch_bounds__(kDenseWaves * 64, 4) void dense_ln_bwd_kernel(
   if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, pw, pb, ok, d);
 }
 
+// The same for rows of exactly 256 NV columns (d = 1280 at ViT-H), eight waves per workgroup: every lane has all NV
+// chunks, so nothing is predicated and ALL loads of a row (x, gy, dres: 3 NV wave-instructions = 15 KiB per wave at NV = 5)
+// are requested before the first use.  The predicated kernel above compiles to load / s_waitcnt vmcnt(0) pairs - two
+// loads in flight per wave, ten serial round trips per row, 32 KiB in flight per CU against the ~60 KiB a CU needs to
+// cover the memory latency - and its 128-register budget (16 waves) has no room to hold a row's loads; 8 waves with
+// 256 registers do, and 120 KiB in flight per CU.
+template <typename TG, int NV>
+__global__ __launch_bounds__(512, 2) void dense_ln_bwd_wide_kernel(
+    const TG* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
+    float* __restrict__ partials, long rows, int d) {
+  extern __shared__ float lds[];             // [2][d] slab image | [d] weights
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  const long nw = (long)gridDim.x * nwaves;
+  float* wl = lds + 2 * d;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) wl[j] = w ? w[j] : 1.f;
+  f32x4 pw[NV], pb[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    ok[i] = true;
+    pw[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const float inv_d = 1.0f / (float)d;
+  for (long r = (long)blockIdx.x * nwaves + (threadIdx.x >> 6); r < rows; r += nw) {
+    const long o = r * d + lane * 4;
+    f32x4 xh[NV], g[NV], dr[NV];
+    typename Row4<TG>::vec gr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xh[i] = *(const f32x4*)(x + o + i * 256);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gr[i] = Row4<TG>::load_raw(gy + o + i * 256);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dr[i] = dres ? *(const f32x4*)(dres + o + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xh[i] = (xh[i] - mean) * rstd;
+      const f32x4 gyv = Row4<TG>::widen(gr[i]);
+      pw[i] += gyv * xh[i];
+      pb[i] += gyv;
+      g[i] = gyv * *(const f32x4*)(wl + (i * 64 + lane) * 4);
+      s1 += hsum(g[i]);
+      s2 += hsum(g[i] * xh[i]);
+    }
+    const float m1 = wave_total(s1) * inv_d, m2 = wave_total(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 v = (g[i] - m1 - xh[i] * m2) * rstd;
+      if (dres) v += dr[i];
+      *(f32x4*)(dx + o + i * 256) = v;
+    }
+  }
+  if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, pw, pb, ok, d);
+}
+
 // ------------------------------------------------------------------------------------------ block tail
 // out = x + rs[row / rps] * gamma[col] * y
 template <typename TY>
@@ -249,17 +329,40 @@ __global__ __launch_bounds__(kDenseWaves * 64) void scale_residual_bwd_kernel(
     gm[i] = (ok[i] && gamma) ? *(const f32x4*)(gamma + col) : f32x4{1.f, 1.f, 1.f, 1.f};
     p0[i] = p1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (long r = (long)blockIdx.x * kDenseWaves + (threadIdx.x >> 6); r < rows; r += nw) {
-    const float s = rs ? rs[r / rps] : 1.f;
+  if (NV <= 5 && d == NV * 256 && partials) {      // (wider rows would spill at the 128-register budget of 16 waves)
+    // every lane has all NV chunks (d = 1280 at ViT-H): no per-chunk predicate, so the 2 NV loads of a row are all
+    // requested before the first use (the predicated loop below compiles to load / vmcnt(0) / load / vmcnt(0) / store per
+    // chunk: ten serial round trips per row, hidden only by occupancy)
+    for (long r = (long)blockIdx.x * kDenseWaves + (threadIdx.x >> 6); r < rows; r += nw) {
+      const float s = rs ? rs[r / rps] : 1.f;
+      const long o = r * d + lane * 4;
+      f32x4 g[NV];
+      typename Row4<TY>::vec yv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (ok[i]) {
-        const long o = r * d + (i * 64 + lane) * 4;
-        f32x4 g = *(const f32x4*)(gout + o) * s;
-        p1[i] += g;
-        if (partials) p0[i] += g * Row4<TY>::load(y + o);
-        Row4<TY>::store(gy + o, g * gm[i]);
+      for (int i = 0; i < NV; ++i) g[i] = *(const f32x4*)(gout + o + i * 256);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) yv[i] = Row4<TY>::load_raw(y + o + i * 256);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        g[i] *= s;
+        p1[i] += g[i];
+        p0[i] += g[i] * Row4<TY>::widen(yv[i]);
+        Row4<TY>::store(gy + o + i * 256, g[i] * gm[i]);
       }
+    }
+  } else {
+    for (long r = (long)blockIdx.x * kDenseWaves + (threadIdx.x >> 6); r < rows; r += nw) {
+      const float s = rs ? rs[r / rps] : 1.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (ok[i]) {
+          const long o = r * d + (i * 64 + lane) * 4;
+          f32x4 g = *(const f32x4*)(gout + o) * s;
+          p1[i] += g;
+          if (partials) p0[i] += g * Row4<TY>::load(y + o);
+          Row4<TY>::store(gy + o, g * gm[i]);
+        }
+    }
   }
   if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, p0, p1, ok, d);
 }
@@ -536,6 +639,16 @@ int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const
   const int blocks = dense_blocks(rows);
   const size_t lds = (size_t)3 * d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
+  if (d == dense_nv(d) * 256 && dense_nv(d) <= 6) {      // whole-chunk rows: the unpredicated eight-wave kernel
+    if (g_dtype == OCTIC_BF16) {
+      DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<bf16, NV><<<dim3(blocks), dim3(512), lds, s>>>((const bf16*)gy, x, w, stats, dres, dx,
+                                                            partials, rows, d)));
+    } else {
+      DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<float, NV><<<dim3(blocks), dim3(512), lds, s>>>((const float*)gy, x, w, stats, dres, dx,
+                                                             partials, rows, d)));
+    }
+    return launch_status();
+  }
   if (g_dtype == OCTIC_BF16) {
     DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_kernel<bf16, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>((const bf16*)gy, x, w, stats, dres,
                                                      dx, partials, rows, d)));

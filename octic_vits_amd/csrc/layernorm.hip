@@ -7,6 +7,7 @@
 // is predicated at run time.  Bound: HBM.
 // Reference: octic_vits/d8_layers.py:161-186 (forward), backward derived in SURVEY.md §10.3.
 #include <stdlib.h>
+#include <type_traits>
 #include "octic_common.hpp"
 
 namespace octic {
@@ -401,8 +402,16 @@ __global__ __launch_bounds__(256, 4) void ln_fwd_g8_kernel(const float* __restri
 // Backward.  Register budget (128 for 4 waves/SIMD) goes to the row in flight and the d alpha partials; alpha itself
 // and the d beta partials (A1 lanes only) live in LDS - each lane re-reads / updates only its own addresses.
 // LDS: [2][8c] slab image | [8c] alpha by packed column | [waves][c] d beta partials.
-template <typename TG, int NV>
-__global__ __launch_bounds__(kLnBwdWaves * 64, OCTIC_LNBWD_OCC) void ln_bwd_g8_kernel(
+// WIDE (NV <= 5, bf16 cotangent: the train step): the 3 NV loads of a row (x, g, dres) are requested before the first use
+// and the kernel is built for 2 waves per SIMD (256 registers) instead of 4.  The 128-register build has no room to
+// hold a row's loads: its ISA is load / load / s_waitcnt pairs in the first loop and load / vmcnt(0) / store per chunk
+// in the second - two loads in flight per wave, 16 waves per CU = 32 KiB in flight against the ~60 KiB that cover the
+// memory latency of a CU.  Eight waves holding 15 KiB each do (csrc/dense.hip dense_ln_bwd_wide_kernel: same finding).
+#ifndef OCTIC_LNBWD_WIDE
+#define OCTIC_LNBWD_WIDE 1
+#endif
+template <typename TG, int NV, bool WIDE = false>
+__global__ __launch_bounds__(kLnBwdWaves * 64, WIDE ? 2 : OCTIC_LNBWD_OCC) void ln_bwd_g8_kernel(
     const TG* __restrict__ g, int64_t ldg, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
     const float* a0, const float* a1, const float* a2, const float* a3, const float* a4,
     const float* __restrict__ dres, int64_t ldr, float* __restrict__ dx, int64_t ldd, float* __restrict__ partials,
@@ -435,11 +444,30 @@ __global__ __launch_bounds__(kLnBwdWaves * 64, OCTIC_LNBWD_OCC) void ln_bwd_g8_k
   for (int64_t m = (int64_t)blockIdx.x * kLnBwdWaves + wid; m < M; m += nwaves) {
     const float mu = stats[m * 8 + lg.seg], rstd = stats[m * 8 + 6];
     f32x4 xc[NV], gh[NV];
+    f32x4 dr[WIDE ? NV : 1];
+    typedef typename std::conditional<std::is_same<TG, float>::value, f32x4, bf16x4>::type graw;
+    graw gr[WIDE ? NV : 1];
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) xc[i] = *(const f32x4*)(x + m * ldx + lg.col0 + i * lg.step4);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) gr[i] = *(const graw*)(g + m * ldg + lg.col0 + i * lg.step4);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        dr[i] = dres ? *(const f32x4*)(dres + m * ldr + lg.col0 + i * lg.step4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float dot = 0.f, t = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      xc[i] = *(const f32x4*)(x + m * ldx + lg.col0 + i * lg.step4) - mu;
-      const f32x4 gv = load4<TG>(g + m * ldg + lg.col0 + i * lg.step4);
+      f32x4 gv;
+      if constexpr (WIDE) {
+        xc[i] = xc[i] - mu;
+        if constexpr (std::is_same<TG, float>::value) gv = gr[i];
+        else gv = f32x4{(float)gr[i][0], (float)gr[i][1], (float)gr[i][2], (float)gr[i][3]};
+      } else {
+        xc[i] = *(const f32x4*)(x + m * ldx + lg.col0 + i * lg.step4) - mu;
+        gv = load4<TG>(g + m * ldg + lg.col0 + i * lg.step4);
+      }
       const f32x4 xh = xc[i] * rstd;
       gh[i] = *(const f32x4*)(alds + lg.col0 + i * lg.step4) * gv;
       pa[i] += gv * xh;
@@ -455,7 +483,11 @@ __global__ __launch_bounds__(kLnBwdWaves * 64, OCTIC_LNBWD_OCC) void ln_bwd_g8_k
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       f32x4 o = (gh[i] - mg) * rstd + xc[i] * coef;
-      if (dres) o += *(const f32x4*)(dres + m * ldr + lg.col0 + i * lg.step4);
+      if constexpr (WIDE) {
+        o += dr[i];
+      } else {
+        if (dres) o += *(const f32x4*)(dres + m * ldr + lg.col0 + i * lg.step4);
+      }
       *(f32x4*)(dx + m * ldd + lg.col0 + i * lg.step4) = o;
     }
   }
@@ -483,7 +515,10 @@ __global__ __launch_bounds__(kLnBwdWaves * 64, OCTIC_LNBWD_OCC) void ln_bwd_g8_k
 
 inline int ln_blocks(int64_t M) {   // backward: one partial slab per block, 8 waves each
   int64_t b = (M + kLnBwdWaves - 1) / kLnBwdWaves;
-  const int64_t cap = 256 * 2;
+#ifndef OCTIC_LNBWD_CAP
+#define OCTIC_LNBWD_CAP 256     // one workgroup per CU: the wide kernel (1 per CU by registers) then runs ONE round (56 vs 63 us)
+#endif
+  const int64_t cap = OCTIC_LNBWD_CAP;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 inline int ln_fwd_blocks(int64_t M) {   // forward: 4 waves per block, 4 rows per wave (per-lane constants amortised)
@@ -602,6 +637,13 @@ int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float
 #define LN_BWD_G8(T, N) ln_bwd_g8_kernel<T, N><<<grid, kLnBwdWaves * 64, smem_g8, s>>>((const T*)vg.p[0], vg.ld[0], (const float*)vx.p[0], vx.ld[0], stats, a[0], a[1], a[2], a[3], a[4], rp, vr.ld[0], (float*)vd.p[0], vd.ld[0], partials, M, c)
 #define LN_BWD_G8_NV(T) switch (c / 32) { case 1: LN_BWD_G8(T, 1); break; case 2: LN_BWD_G8(T, 2); break; case 3: LN_BWD_G8(T, 3); break; \
     case 4: LN_BWD_G8(T, 4); break; case 5: LN_BWD_G8(T, 5); break; case 6: LN_BWD_G8(T, 6); break; case 7: LN_BWD_G8(T, 7); break; default: LN_BWD_G8(T, 8); break; }
+    if (OCTIC_LNBWD_WIDE && g_dtype == OCTIC_BF16 && c / 32 <= 5) {
+#define LN_BWD_G8W(N) ln_bwd_g8_kernel<bf16, N, true><<<grid, kLnBwdWaves * 64, smem_g8, s>>>((const bf16*)vg.p[0], vg.ld[0], (const float*)vx.p[0], vx.ld[0], stats, a[0], a[1], a[2], a[3], a[4], rp, vr.ld[0], (float*)vd.p[0], vd.ld[0], partials, M, c)
+      switch (c / 32) { case 1: LN_BWD_G8W(1); break; case 2: LN_BWD_G8W(2); break; case 3: LN_BWD_G8W(3); break;
+                        case 4: LN_BWD_G8W(4); break; default: LN_BWD_G8W(5); break; }
+#undef LN_BWD_G8W
+      return launch_status();
+    }
     if (g_dtype == OCTIC_F32) { LN_BWD_G8_NV(float) } else { LN_BWD_G8_NV(bf16) }
     return launch_status();
   }
