@@ -30,7 +30,9 @@ NAMES = [
     (r"ln_fwd_g8_kernel", "ln_fwd_kernel<bf16>"),
     (r"ln_bwd_g8_kernel", "ln_bwd_kernel<bf16>"),
     (r"dense_ln_fwd_kernel", "dense_ln_fwd_kernel<bf16>"),
-    (r"dense_ln_bwd_kernel", "dense_ln_bwd_kernel<bf16>"),
+    (r"dense_ln_bwd(_wide)?_kernel", "dense_ln_bwd_kernel<bf16>"),
+    (r"dense_resid_ln_fwd_kernel", "dense_resid_ln_fwd_kernel<bf16>"),
+    (r"dense_colsum_kernel", "dense_colsum_kernel"),
     (r"scale_residual_fwd_kernel", "scale_residual_fwd_kernel<bf16>"),
     (r"scale_residual_bwd_kernel", "scale_residual_bwd_kernel<bf16>"),
     (r"dense_gelu_bwd_kernel", "dense_gelu_bwd_kernel"),
