@@ -114,9 +114,26 @@ __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA,
 // (tools/attn_trace.py).  Register cost: 72 VGPRs per pair on plain rows, 80 on packed rows - free in a prologue.
 constexpr int kStageRows = 9;      // rows per thread: Tp / (threads / 16) = 8, or 9 for nine tiles on eight waves
 struct StagePlain { u32x4 a[kStageRows], b[kStageRows]; };
+// Which 16-byte chunk of which rows a thread stages.  A row of the head is kc chunks (10 at head_dim 80); mapping a thread
+// to (row tid / kc, chunk tid % kc) fills 60 of a wave's 64 lanes with work (6 rows per wave-instruction, 6 instructions
+// per thread and tensor at T = 257) where (tid >> 4, tid & 15) filled 40 (4 rows, 9 instructions): the prologues are
+// bound by the CU's vector-memory instruction rate, so lanes that address nothing are time.
+struct StageMap { int c, t0, tstep; };
+__device__ __forceinline__ StageMap stage_map(int tid, int nthr, int kc) {
+  StageMap m;
+  m.tstep = nthr / kc;
+  m.t0 = tid / kc;
+  m.c = tid - m.t0 * kc;
+  if (m.t0 >= m.tstep) {      // the last nthr % kc threads: no rows
+    m.t0 = 1 << 20;
+    m.c = 0;
+  }
+  return m;
+}
 __device__ __forceinline__ void stage_request(StagePlain& R, const bf16* srcA, int64_t stA, int kcA, const bf16* srcB,
                                               int64_t stB, int kcB, int T, int tid, int nthr) {
-  const int c = tid & 15, t0 = tid >> 4, tstep = nthr >> 4;
+  const StageMap sm = stage_map(tid, nthr, kcA > kcB ? kcA : kcB);
+  const int c = sm.c, t0 = sm.t0, tstep = sm.tstep;
 #pragma unroll
   for (int it = 0; it < kStageRows; ++it) {
     const int t = t0 + it * tstep;
@@ -128,7 +145,8 @@ __device__ __forceinline__ void stage_request(StagePlain& R, const bf16* srcA, i
 }
 __device__ __forceinline__ void stage_write(const StagePlain& R, char* imgA, int rsA, int wcA, char* imgB, int rsB, int wcB,
                                             int Tp, int tid, int nthr) {
-  const int c = tid & 15, t0 = tid >> 4, tstep = nthr >> 4;
+  const StageMap sm = stage_map(tid, nthr, wcA > wcB ? wcA : wcB);
+  const int c = sm.c, t0 = sm.t0, tstep = sm.tstep;
 #pragma unroll
   for (int it = 0; it < kStageRows; ++it) {
     const int t = t0 + it * tstep;
@@ -827,7 +845,8 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   if (hm.q.cv == 0) {
     StagePlain qd, kv;
     u32x4 oo[kStageRows];
-    const int c = tid & 15, t0 = tid >> 4, tstep = blockDim.x >> 4;
+    const StageMap sm = stage_map(tid, blockDim.x, kc);
+    const int c = sm.c, t0 = sm.t0, tstep = sm.tstep;
     stage_request(qd, a.q + in_off, a.sT, kc, a.dout + o_off, a.oT, kc, T, tid, blockDim.x);
 #pragma unroll
     for (int it = 0; it < kStageRows; ++it) {

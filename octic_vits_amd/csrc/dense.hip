@@ -243,7 +243,10 @@ __global__ __launch_bounds__(kDenseWaves * 64, 4) void dense_ln_bwd_kernel(
 // cover the memory latency - and its 128-register budget (16 waves) has no room to hold a row's loads; 8 waves with
 // 256 registers do, and 120 KiB in flight per CU.
 template <typename TG, int NV>
-__global__ __launch_bounds__(512, 2) void dense_ln_bwd_wide_kernel(
+#ifndef OCTIC_DLNBWD_WAVES
+#define OCTIC_DLNBWD_WAVES 8
+#endif
+__global__ __launch_bounds__(OCTIC_DLNBWD_WAVES * 64, OCTIC_DLNBWD_WAVES / 4) void dense_ln_bwd_wide_kernel(
     const TG* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
     float* __restrict__ partials, long rows, int d) {
@@ -641,10 +644,10 @@ int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const
   hipStream_t s = (hipStream_t)stream;
   if (d == dense_nv(d) * 256 && dense_nv(d) <= 6) {      // whole-chunk rows: the unpredicated eight-wave kernel
     if (g_dtype == OCTIC_BF16) {
-      DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<bf16, NV><<<dim3(blocks), dim3(512), lds, s>>>((const bf16*)gy, x, w, stats, dres, dx,
+      DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<bf16, NV><<<dim3(blocks), dim3(OCTIC_DLNBWD_WAVES * 64), lds, s>>>((const bf16*)gy, x, w, stats, dres, dx,
                                                             partials, rows, d)));
     } else {
-      DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<float, NV><<<dim3(blocks), dim3(512), lds, s>>>((const float*)gy, x, w, stats, dres, dx,
+      DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<float, NV><<<dim3(blocks), dim3(OCTIC_DLNBWD_WAVES * 64), lds, s>>>((const float*)gy, x, w, stats, dres, dx,
                                                              partials, rows, d)));
     }
     return launch_status();
