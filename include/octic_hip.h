@@ -284,6 +284,14 @@ int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const
                               const float* dres, float* dx, float* partials, int64_t rows, int d, void* stream);
 int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, float* out1, const float* scale1,
                        void* stream);
+/* octic_dense_layernorm_bwd_tail: octic_dense_layernorm_bwd (bf16 gy) followed by octic_scale_residual_bwd on its result,
+ * one row pass for d = 256, 512, ... 1280 (other d: OCTIC_ESHAPE, call the two): dx as above; gyb = rs*gamma*dx in bf16
+ * (cotangent of the bf16 branch output yb whose residual add produced the normalised stream); partials / partials2:
+ * octic_dense_blocks(rows) slabs [2][d] each, as the two kernels leave them (both may be NULL).  The autograd of
+ * `x = x + drop_path(gamma * f(norm(x)))` chained over two branches (deit/vit.py:131-134).                       */
+int octic_dense_layernorm_bwd_tail(const void* gy, const float* x, const float* w, const float* stats, const float* dres,
+                                   float* dx, float* partials, const void* yb, const float* gamma, const float* rs,
+                                   int64_t rows_per_scale, void* gyb, float* partials2, int64_t rows, int d, void* stream);
 /* octic_dense_gelu_bwd: dh = gelu'(h) * g (exact erf GELU, bf16 [rows, d], d % 8 == 0) and, when partials != NULL,
  * octic_dense_gelu_blocks() slabs [d] of column sums of dh (bias gradient of the projection that produced h;
  * reduce with octic_dense_finish(partials, blocks, d/2, out, out + d/2, NULL)).  Replaces GeluBackward + the

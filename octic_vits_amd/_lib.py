@@ -53,6 +53,7 @@ _PROTOS = {
                                                 c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p]),
     "octic_dense_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_i64, c_int, c_void_p]),
+    "octic_dense_layernorm_bwd_tail": (c_int, [c_void_p] * 10 + [c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "octic_dense_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "octic_dense_gelu_blocks": (c_int, []),
     "octic_dense_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),

@@ -297,6 +297,78 @@ __global__ __launch_bounds__(OCTIC_DLNBWD_WAVES * 64, OCTIC_DLNBWD_WAVES / 4) vo
   if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, pw, pb, ok, d);
 }
 
+// LayerNorm backward + the backward of the residual tail in front of it, one row pass (whole-chunk rows, eight waves):
+//   dx  = LN'(gy) + dres                      (cotangent of the stream that entered the norm: f32, written once)
+//   gyb = rs * gamma * dx                     (cotangent of the branch output yb that was added to make that stream)
+//   slabs: dw += gy*xhat, db += gy  |  d gamma += rs*dx*yb, bias gradient / gamma += rs*dx
+// The two separate kernels (dense_ln_bwd_wide + scale_residual_bwd) write dx and read it back: 463 MB per launch at
+// ViT-H, this one 379.  Arithmetic per element is that of the two kernels (dx is used as stored).
+template <typename TG, int NV>
+__global__ __launch_bounds__(512, 2) void dense_ln_bwd_tail_kernel(
+    const TG* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
+    float* __restrict__ partials, const TG* __restrict__ yb, const float* __restrict__ gamma,
+    const float* __restrict__ rs, long rps, TG* __restrict__ gyb, float* __restrict__ partials2, long rows, int d) {
+  extern __shared__ float lds[];             // [2][d] slab image | [d] LayerNorm weights | [d] layer scale
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  const long nw = (long)gridDim.x * nwaves;
+  float* wl = lds + 2 * d;
+  float* gl = lds + 3 * d;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    wl[j] = w ? w[j] : 1.f;
+    gl[j] = gamma ? gamma[j] : 1.f;
+  }
+  f32x4 pw[NV], pb[NV], p0[NV], p1[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    ok[i] = true;
+    pw[i] = pb[i] = p0[i] = p1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const float inv_d = 1.0f / (float)d;
+  for (long r = (long)blockIdx.x * nwaves + (threadIdx.x >> 6); r < rows; r += nw) {
+    const long o = r * d + lane * 4;
+    f32x4 xh[NV], g[NV], dr[NV];
+    typename Row4<TG>::vec gr[NV], yr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xh[i] = *(const f32x4*)(x + o + i * 256);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gr[i] = Row4<TG>::load_raw(gy + o + i * 256);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dr[i] = dres ? *(const f32x4*)(dres + o + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) yr[i] = Row4<TG>::load_raw(yb + o + i * 256);
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    const float sc = rs ? rs[r / rps] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xh[i] = (xh[i] - mean) * rstd;
+      const f32x4 gyv = Row4<TG>::widen(gr[i]);
+      pw[i] += gyv * xh[i];
+      pb[i] += gyv;
+      g[i] = gyv * *(const f32x4*)(wl + (i * 64 + lane) * 4);
+      s1 += hsum(g[i]);
+      s2 += hsum(g[i] * xh[i]);
+    }
+    const float m1 = wave_total(s1) * inv_d, m2 = wave_total(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 v = (g[i] - m1 - xh[i] * m2) * rstd;
+      if (dres) v += dr[i];
+      *(f32x4*)(dx + o + i * 256) = v;
+      const f32x4 t = v * sc;                                  // scale_residual_bwd_kernel: g = gout * s
+      p1[i] += t;
+      p0[i] += t * Row4<TG>::widen(yr[i]);
+      Row4<TG>::store(gyb + o + i * 256, t * *(const f32x4*)(gl + (i * 64 + lane) * 4));
+    }
+  }
+  if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, pw, pb, ok, d);
+  __syncthreads();
+  if (partials2) slab_reduce<NV>(lds, partials2 + (long)blockIdx.x * 2 * d, p0, p1, ok, d);
+}
+
 // ------------------------------------------------------------------------------------------ block tail
 // out = x + rs[row / rps] * gamma[col] * y
 template <typename TY>
@@ -659,6 +731,23 @@ int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const
     DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_kernel<float, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>((const float*)gy, x, w, stats,
                                                      dres, dx, partials, rows, d)));
   }
+  return launch_status();
+}
+
+int octic_dense_layernorm_bwd_tail(const void* gy, const float* x, const float* w, const float* stats, const float* dres,
+                                   float* dx, float* partials, const void* yb, const float* gamma, const float* rs,
+                                   int64_t rows_per_scale, void* gyb, float* partials2, int64_t rows, int d, void* stream) {
+  if (rows == 0) return OCTIC_OK;
+  if (!gy || !x || !stats || !dx || !yb || !gyb) return OCTIC_ENULL;
+  if (int e = dense_check(rows, d)) return e;
+  if (d != dense_nv(d) * 256 || dense_nv(d) > 5) return OCTIC_ESHAPE;     // whole 256-column chunks only (callers fall back)
+  if (rs && rows_per_scale <= 0) return OCTIC_ESHAPE;
+  const int blocks = dense_blocks(rows);
+  const size_t lds = (size_t)4 * d * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  const long rps = rs ? rows_per_scale : 1;
+  DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_tail_kernel<bf16, NV><<<dim3(blocks), dim3(512), lds, s>>>(
+      (const bf16*)gy, x, w, stats, dres, dx, partials, (const bf16*)yb, gamma, rs, rps, (bf16*)gyb, partials2, rows, d)));
   return launch_status();
 }
 

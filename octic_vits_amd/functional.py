@@ -612,6 +612,9 @@ DENSE_RESID_FUSED = False
 # The residual add of a branch and the LayerNorm that opens the next one (norm2 of the same block, norm1 of the next
 # block) as ONE row pass (csrc/dense.hip dense_resid_ln_fwd_kernel): the f32 stream is written once and not read back.
 NEXT_NORM_FUSED = True
+# ... and in the backward of that pair: LayerNorm backward + the backward of the residual tail in front of it as one row
+# pass (dense_ln_bwd_tail_kernel) instead of dense_ln_bwd + scale_residual_bwd (the stream cotangent is not read back).
+LN_TAIL_FUSED = True
 
 
 def dense_hip_ok(x, w, which=None):
@@ -753,20 +756,29 @@ class DenseProjResidFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, gyn=None):
         dnw = dnb = None
+        tail_done = False
         if ctx.norm:
             a2, wb, wt, y, g32, rs32, out, stats, nw32 = ctx.saved_tensors
             rps, has_b, has_gamma, a_dtype, a_shape, has_nw, has_nb = ctx.meta
             if gyn is not None:      # LayerNorm backward with the residual cotangent added in the same pass
                 want = has_nw and (ctx.needs_input_grad[8] or ctx.needs_input_grad[9])
                 dres = None if gout is None else _c(gout.float()).view(out.shape)
-                gout, dnw, dnb = ops.dense_layernorm_bwd(_c(gyn).view(out.shape), out, nw32, stats, dres, want_param_grads=want)
+                g2 = _c(gyn).view(out.shape)
+                if LN_TAIL_FUSED and ops.dense_ln_bwd_tail_ok(g2, y, out.shape[-1]):
+                    gout, dnw, dnb, gy, dgamma, colsum = ops.dense_layernorm_bwd_tail(
+                        g2, out, nw32, stats, dres, y, g32, rs32, rps, want_param_grads=want, want_gamma=has_gamma,
+                        want_colsum=has_b)
+                    tail_done = True
+                else:
+                    gout, dnw, dnb = ops.dense_layernorm_bwd(g2, out, nw32, stats, dres, want_param_grads=want)
                 dnw, dnb = (dnw if has_nw else None), (dnb if has_nb else None)
         else:
             a2, wb, wt, y, g32, rs32 = ctx.saved_tensors
             rps, has_b, has_gamma, a_dtype, a_shape = ctx.meta
-        gout = _c(gout.float())
-        gy, dgamma, colsum = ops.scale_residual_bwd(gout.view(y.shape), y, g32, rs32, rps, want_gamma=has_gamma,
-                                                    want_colsum=has_b)
+        if not tail_done:
+            gout = _c(gout.float())
+            gy, dgamma, colsum = ops.scale_residual_bwd(gout.view(y.shape), y, g32, rs32, rps, want_gamma=has_gamma,
+                                                        want_colsum=has_b)
         ga = None
         if ctx.needs_input_grad[1]:
             ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
@@ -824,20 +836,29 @@ class DenseMlpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, gyn=None):
         dnw = dnb = None
+        tail_done = False
         if ctx.norm:
             y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32, out, stats, nw32 = ctx.saved_tensors
             rps, has_b1, has_b2, has_gamma, y_dtype, y_shape, has_nw, has_nb = ctx.meta
             if gyn is not None:      # LayerNorm backward with the residual cotangent added in the same pass
                 want = has_nw and (ctx.needs_input_grad[11] or ctx.needs_input_grad[12])
                 dres = None if gout is None else _c(gout.float()).view(out.shape)
-                gout, dnw, dnb = ops.dense_layernorm_bwd(_c(gyn).view(out.shape), out, nw32, stats, dres, want_param_grads=want)
+                g2 = _c(gyn).view(out.shape)
+                if LN_TAIL_FUSED and ops.dense_ln_bwd_tail_ok(g2, br, out.shape[-1]):
+                    gout, dnw, dnb, gbr, dgamma, db2 = ops.dense_layernorm_bwd_tail(
+                        g2, out, nw32, stats, dres, br, g32, rs32, rps, want_param_grads=want, want_gamma=has_gamma,
+                        want_colsum=has_b2)
+                    tail_done = True
+                else:
+                    gout, dnw, dnb = ops.dense_layernorm_bwd(g2, out, nw32, stats, dres, want_param_grads=want)
                 dnw, dnb = (dnw if has_nw else None), (dnb if has_nb else None)
         else:
             y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32 = ctx.saved_tensors
             rps, has_b1, has_b2, has_gamma, y_dtype, y_shape = ctx.meta
-        gout = _c(gout.float())
-        gbr, dgamma, db2 = ops.scale_residual_bwd(gout.view(br.shape), br, g32, rs32, rps, want_gamma=has_gamma,
-                                                  want_colsum=has_b2)
+        if not tail_done:
+            gout = _c(gout.float())
+            gbr, dgamma, db2 = ops.scale_residual_bwd(gout.view(br.shape), br, g32, rs32, rps, want_gamma=has_gamma,
+                                                      want_colsum=has_b2)
         if w2t is not None:
             if has_b1:                                                                  # gelu'(h) * (gbr W2), + db1
                 dh, db1 = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>", want_colsum=True)

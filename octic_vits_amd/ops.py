@@ -547,6 +547,39 @@ def dense_layernorm_bwd(gy, x, w, stats, dres, want_param_grads=True):
     return dx, dw, db
 
 
+def dense_ln_bwd_tail_ok(gy, yb, d):
+    """Shapes of octic_dense_layernorm_bwd_tail: bf16 cotangent and branch, rows of 256, 512, ... 1280 columns."""
+    return gy.dtype == torch.bfloat16 and yb.dtype == torch.bfloat16 and d % 256 == 0 and d <= 1280
+
+
+def dense_layernorm_bwd_tail(gy, x, w, stats, dres, yb, gamma, rs, rps, want_param_grads=True, want_gamma=True,
+                             want_colsum=True):
+    """dense_layernorm_bwd followed by scale_residual_bwd on its result, one row pass.
+    Returns (dx f32, dw, db, gyb bf16 = rs*gamma*dx, dgamma, gamma * colsum(rs*dx))."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    gyb = torch.empty(x.shape, dtype=yb.dtype, device=x.device)
+    nblk = lib().octic_dense_blocks(rows)
+    p1 = torch.empty((nblk, 2, d), dtype=torch.float32, device=x.device) if want_param_grads else None
+    want2 = want_gamma or want_colsum
+    p2 = torch.empty((nblk, 2, d), dtype=torch.float32, device=x.device) if want2 else None
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_layernorm_bwd_tail(_p(gy), _p(x), _p(w), _p(stats), _p(dres), _p(dx), _p(p1), _p(yb), _p(gamma),
+                                               _p(rs), int(rps), _p(gyb), _p(p2), rows, d, _stream(x)))
+    KERNEL_TIMER.stop(t, "dense_ln_bwd_tail_kernel<bf16>", rows * d * (2 + 8 + (4 if dres is not None else 0) + 4))
+    dw = db = dgamma = colsum = None
+    if want_param_grads:
+        dw = torch.empty(d, dtype=torch.float32, device=x.device)
+        db = torch.empty(d, dtype=torch.float32, device=x.device)
+        check(lib().octic_dense_finish(_p(p1), nblk, d, _p(dw), _p(db), _p(None), _stream(x)))
+    if want2:
+        dgamma = torch.empty(d, dtype=torch.float32, device=x.device) if want_gamma else None
+        colsum = torch.empty(d, dtype=torch.float32, device=x.device) if want_colsum else None
+        check(lib().octic_dense_finish(_p(p2), nblk, d, _p(dgamma), _p(colsum), _p(gamma), _stream(x)))
+    return dx, dw, db, gyb, dgamma, colsum
+
+
 def scale_residual_fwd(x, y, gamma, rs, rps):
     """out = x + rs[row // rps] * gamma * y   (x f32, y f32/bf16, same shape [..., d])."""
     _require_cuda(x)

@@ -234,7 +234,8 @@ def test_next_norm_fusion_is_bitwise_the_unfused_block_chain():
     gout = gen(22, B, T, dim).to(DEV)
     o = ops()
     res = {}
-    saved = OF.NEXT_NORM_FUSED
+    saved, saved_tail = OF.NEXT_NORM_FUSED, OF.LN_TAIL_FUSED
+    OF.LN_TAIL_FUSED = False          # (its slab sums run in another order: compared separately below)
     try:
         for mode in (True, False):
             OF.NEXT_NORM_FUSED = mode
@@ -253,8 +254,30 @@ def test_next_norm_fusion_is_bitwise_the_unfused_block_chain():
                          sum(v["launches"] for n, v in s.items() if n.startswith("dense_ln_fwd")),
                          sum(v["launches"] for n, v in s.items() if n.startswith("dense_resid_ln_fwd")))
     finally:
-        OF.NEXT_NORM_FUSED = saved
+        OF.NEXT_NORM_FUSED, OF.LN_TAIL_FUSED = saved, saved_tail
     assert res[True][3] == 1 and res[True][4] == 5 and res[False][3] == 6 and res[False][4] == 0
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for (n, _), a, b in zip(blocks.named_parameters(), res[True][2], res[False][2]):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("rows,T,d", [(16448, 257, 1280), (771, 257, 768), (300, 50, 256)])
+def test_layernorm_bwd_tail_equals_the_two_passes(rows, T, d):
+    """octic_dense_layernorm_bwd_tail = octic_dense_layernorm_bwd then octic_scale_residual_bwd: dx and the bf16 branch
+    cotangent bit for bit, the four parameter-gradient sums to 1e-5 of their scale (other slab order)."""
+    o = ops()
+    x = (gen(31, rows, d) * 2 + 0.3).to(DEV)
+    w = (gen(32, d) * 0.3 + 1).to(DEV)
+    gy = gen(33, rows, d).to(DEV).bfloat16()
+    dres = gen(34, rows, d).to(DEV)
+    yb = gen(35, rows, d).to(DEV).bfloat16()
+    gamma = (gen(36, d) * 0.1).to(DEV)
+    rs = (torch.arange(rows // T) % 3 != 0).float().div(0.66).to(DEV)
+    _, stats = o.dense_layernorm_fwd(x, w, None, 1e-6, torch.bfloat16)
+    for dr, g_, r_ in ((dres, gamma, rs), (None, None, None), (dres, gamma, None)):
+        dx, dw, db = o.dense_layernorm_bwd(gy, x, w, stats, dr)
+        gyb, dgamma, colsum = o.scale_residual_bwd(dx, yb, g_, r_, T)
+        dx2, dw2, db2, gyb2, dgamma2, colsum2 = o.dense_layernorm_bwd_tail(gy, x, w, stats, dr, yb, g_, r_, T)
+        assert torch.equal(dx2, dx) and torch.equal(gyb2, gyb)
+        for a, b in ((dw2, dw), (db2, db), (dgamma2, dgamma), (colsum2, colsum)):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
