@@ -30,6 +30,7 @@ NAMES = [
     (r"ln_fwd_g8_kernel", "ln_fwd_kernel<bf16>"),
     (r"ln_bwd_g8_kernel", "ln_bwd_kernel<bf16>"),
     (r"dense_ln_fwd_kernel", "dense_ln_fwd_kernel<bf16>"),
+    (r"dense_ln_bwd_tail_kernel", "dense_ln_bwd_tail_kernel<bf16>"),
     (r"dense_ln_bwd(_wide)?_kernel", "dense_ln_bwd_kernel<bf16>"),
     (r"dense_resid_ln_fwd_kernel", "dense_resid_ln_fwd_kernel<bf16>"),
     (r"dense_colsum_kernel", "dense_colsum_kernel"),
