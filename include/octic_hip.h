@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 5
+#define OCTIC_ABI_VERSION 6
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 

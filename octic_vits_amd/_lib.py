@@ -117,7 +117,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.octic_abi_version() != 5:
+        if L.octic_abi_version() != 6:
             raise RuntimeError("octic_vits_amd: ABI version mismatch between _lib.py and liboctic_hip.so")
         _LIB = L
     return _LIB
