@@ -106,6 +106,8 @@ def main():
                     help="developer A/B: AttentionD8 through the pack / unpack kernels instead of the packed-row attention")
     ap.add_argument("--wgrad-f32-out", action="store_true",
                     help="developer A/B: library weight gradients straight to f32 (default: bf16 result + cast, as autocast does)")
+    ap.add_argument("--no-octic-next-norm", action="store_true",
+                    help="developer A/B: octic proj / fc2 and the following LayerNormD8 as separate autograd nodes (cast pass back)")
     ap.add_argument("--no-ln-tail", action="store_true",
                     help="developer A/B: LayerNorm backward and the residual-tail backward in front of it as two row passes")
     ap.add_argument("--no-next-norm", action="store_true",
@@ -144,6 +146,9 @@ def main():
     if args.resid_fused:
         import octic_vits_amd.functional as _OF2
         _OF2.DENSE_RESID_FUSED = True
+    if args.no_octic_next_norm:
+        import octic_vits_amd.functional as _OF5
+        _OF5.OCTIC_NEXT_NORM = False
     if args.no_ln_tail:
         import octic_vits_amd.functional as _OF4
         _OF4.LN_TAIL_FUSED = False

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 6
+#define OCTIC_ABI_VERSION 7
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -84,6 +84,14 @@ int octic_layernorm_d8_bwd_blocks(int64_t M);
 int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float* stats,
                            const float* const alpha[5], const octic_view* dres, const octic_view* dx,
                            float* partials, int64_t M, int c, int g_dtype, void* stream);
+/* octic_layernorm_d8_bwd_cast: octic_layernorm_d8_bwd for a bf16 cotangent on packed rows with c in {32,...,160}
+ * (other arguments: OCTIC_ESHAPE, call the two kernels), which also stores gcast[row] = bf16(rs[row / rows_per_sample] *
+ * dx[row]) (packed rows of 8c, rs may be NULL): the drop-path-scaled bf16 cotangent that the backward of the
+ * residual-fused LinearD8 in front of this norm needs (d8_layers.py:698-707 chained over two branches) - what
+ * octic_cast_rowscale makes of dx in a pass of its own.                                                          */
+int octic_layernorm_d8_bwd_cast(const octic_view* g, const octic_view* x, const float* stats, const float* const alpha[5],
+                                const octic_view* dres, const octic_view* dx, float* partials, int64_t M, int c,
+                                const float* rs, int64_t rows_per_sample, void* gcast, void* stream);
 int octic_layernorm_d8_bwd_finish(const float* partials, int nblk, int c, float* const dalpha[5], float* dbeta,
                                   void* stream);
 

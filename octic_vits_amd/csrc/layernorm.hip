@@ -415,7 +415,10 @@ __global__ __launch_bounds__(kLnBwdWaves * 64, WIDE ? 2 : OCTIC_LNBWD_OCC) void 
     const TG* __restrict__ g, int64_t ldg, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
     const float* a0, const float* a1, const float* a2, const float* a3, const float* a4,
     const float* __restrict__ dres, int64_t ldr, float* __restrict__ dx, int64_t ldd, float* __restrict__ partials,
-    int64_t M, int c) {
+    int64_t M, int c, const float* __restrict__ crs = nullptr, int64_t crps = 1, bf16* __restrict__ cg = nullptr,
+    int64_t ldc = 0) {
+  // cg (WIDE only): also store bf16(crs[row / crps] * dx) - the drop-path-scaled bf16 cotangent the backward of the
+  // residual-fused LinearD8 in front of this norm needs (what cast_rowscale_kernel makes of dx in a pass of its own)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t nwaves = (int64_t)gridDim.x * kLnBwdWaves;
@@ -485,6 +488,11 @@ __global__ __launch_bounds__(kLnBwdWaves * 64, WIDE ? 2 : OCTIC_LNBWD_OCC) void 
       f32x4 o = (gh[i] - mg) * rstd + xc[i] * coef;
       if constexpr (WIDE) {
         o += dr[i];
+        if (cg) {
+          const float cs_ = crs ? crs[m / crps] : 1.0f;
+          const f32x4 sc = o * cs_;
+          *(bf16x4*)(cg + m * ldc + lg.col0 + i * lg.step4) = bf16x4{(bf16)sc[0], (bf16)sc[1], (bf16)sc[2], (bf16)sc[3]};
+        }
       } else {
         if (dres) o += *(const f32x4*)(dres + m * ldr + lg.col0 + i * lg.step4);
       }
@@ -604,9 +612,9 @@ int octic_layernorm_d8_fwd(const octic_view* x, const octic_view* y, const float
 
 int octic_layernorm_d8_bwd_blocks(int64_t M) { return ln_blocks(M); }
 
-int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float* stats, const float* const alpha[5],
-                           const octic_view* dres, const octic_view* dx, float* partials, int64_t M, int c, int g_dtype,
-                           void* stream) {
+static int ln_bwd_impl(const octic_view* g, const octic_view* x, const float* stats, const float* const alpha[5],
+                       const octic_view* dres, const octic_view* dx, float* partials, int64_t M, int c, int g_dtype,
+                       void* stream, const float* crs, int64_t crps, void* cg) {
   int e;
   if ((e = check_c(c)) || (e = check_view(g, c, g_dtype)) || (e = check_view(x, c, OCTIC_F32)) ||
       (e = check_view(dx, c, OCTIC_F32)))
@@ -638,15 +646,17 @@ int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float
 #define LN_BWD_G8_NV(T) switch (c / 32) { case 1: LN_BWD_G8(T, 1); break; case 2: LN_BWD_G8(T, 2); break; case 3: LN_BWD_G8(T, 3); break; \
     case 4: LN_BWD_G8(T, 4); break; case 5: LN_BWD_G8(T, 5); break; case 6: LN_BWD_G8(T, 6); break; case 7: LN_BWD_G8(T, 7); break; default: LN_BWD_G8(T, 8); break; }
     if (OCTIC_LNBWD_WIDE && g_dtype == OCTIC_BF16 && c / 32 <= 5) {
-#define LN_BWD_G8W(N) ln_bwd_g8_kernel<bf16, N, true><<<grid, kLnBwdWaves * 64, smem_g8, s>>>((const bf16*)vg.p[0], vg.ld[0], (const float*)vx.p[0], vx.ld[0], stats, a[0], a[1], a[2], a[3], a[4], rp, vr.ld[0], (float*)vd.p[0], vd.ld[0], partials, M, c)
+#define LN_BWD_G8W(N) ln_bwd_g8_kernel<bf16, N, true><<<grid, kLnBwdWaves * 64, smem_g8, s>>>((const bf16*)vg.p[0], vg.ld[0], (const float*)vx.p[0], vx.ld[0], stats, a[0], a[1], a[2], a[3], a[4], rp, vr.ld[0], (float*)vd.p[0], vd.ld[0], partials, M, c, crs, crs ? crps : 1, (bf16*)cg, (int64_t)8 * c)
       switch (c / 32) { case 1: LN_BWD_G8W(1); break; case 2: LN_BWD_G8W(2); break; case 3: LN_BWD_G8W(3); break;
                         case 4: LN_BWD_G8W(4); break; default: LN_BWD_G8W(5); break; }
 #undef LN_BWD_G8W
       return launch_status();
     }
+    if (cg) return OCTIC_ESHAPE;          // the scaled bf16 copy exists in the wide kernel only
     if (g_dtype == OCTIC_F32) { LN_BWD_G8_NV(float) } else { LN_BWD_G8_NV(bf16) }
     return launch_status();
   }
+  if (cg) return OCTIC_ESHAPE;
   if (g_dtype == OCTIC_F32) {
     if (pk) launch_ln_bwd<float, true>(nv, grid, smem, s, vg, vx, stats, a, vr, hd, vd, partials, M, c);
     else launch_ln_bwd<float, false>(nv, grid, smem, s, vg, vx, stats, a, vr, hd, vd, partials, M, c);
@@ -655,6 +665,21 @@ int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float
     else launch_ln_bwd<bf16, false>(nv, grid, smem, s, vg, vx, stats, a, vr, hd, vd, partials, M, c);
   }
   return launch_status();
+}
+
+int octic_layernorm_d8_bwd(const octic_view* g, const octic_view* x, const float* stats, const float* const alpha[5],
+                           const octic_view* dres, const octic_view* dx, float* partials, int64_t M, int c, int g_dtype,
+                           void* stream) {
+  return ln_bwd_impl(g, x, stats, alpha, dres, dx, partials, M, c, g_dtype, stream, nullptr, 1, nullptr);
+}
+
+int octic_layernorm_d8_bwd_cast(const octic_view* g, const octic_view* x, const float* stats, const float* const alpha[5],
+                                const octic_view* dres, const octic_view* dx, float* partials, int64_t M, int c,
+                                const float* rs, int64_t rows_per_sample, void* gcast, void* stream) {
+  if (!gcast) return OCTIC_ENULL;
+  if (rs && rows_per_sample <= 0) return OCTIC_ESHAPE;
+  if (((uintptr_t)gcast) & 15) return OCTIC_EALIGN;
+  return ln_bwd_impl(g, x, stats, alpha, dres, dx, partials, M, c, OCTIC_BF16, stream, rs, rows_per_sample, gcast);
 }
 
 int octic_layernorm_d8_bwd_finish(const float* partials, int nblk, int c, float* const dalpha[5], float* dbeta,

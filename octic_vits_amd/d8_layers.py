@@ -134,7 +134,9 @@ class LinearD8(nn.Module):
     def weights(self):
         return tuple(getattr(self, "lin_" + n).weight for n in _IRREPS)
 
-    def forward(self, x_batched, resid=None, rs=None, cs=None):
+    def forward(self, x_batched, resid=None, rs=None, cs=None, next_norm=None):
+        """next_norm (a LayerNormD8, only with resid): also return next_norm(result) -> (Octic, Octic or None); on the
+        bf16 GPU path the two are ONE autograd node whose backward skips the cast pass (OF.LinearD8NormFn)."""
         assert len(x_batched) == 5, "Input should be a 5-tuple"
         xp, cin = as_packed(x_batched)
         if 8 * cin != self.input_channels:
@@ -143,8 +145,14 @@ class LinearD8(nn.Module):
         dtype = compute_dtype(xp)
         rps = xp.shape[-2] if xp.dim() >= 2 else 1
         cs5 = (None,) * 5 if cs is None else tuple(cs)
+        if (next_norm is not None and resid is not None and OF.OCTIC_NEXT_NORM and xp.is_cuda and dtype == torch.bfloat16
+                and resid.dtype == torch.float32 and type(next_norm) is LayerNormD8):
+            a, beta = next_norm.affine()
+            y, yn = OF.LinearD8NormFn.apply(xp, *self.weights(), self.lin_A1.bias, resid, rs, *cs5, cin, cout, rps, dtype,
+                                            self._prep, *a, beta, next_norm.eps)
+            return Octic(y, cout), Octic(yn, cout)
         y = OF.LinearD8Fn.apply(xp, *self.weights(), self.lin_A1.bias, resid, rs, *cs5, cin, cout, rps, dtype, self._prep)
-        return Octic(y, cout)
+        return Octic(y, cout) if next_norm is None else (Octic(y, cout), None)
 
     def extra_repr(self) -> str:
         return f"in_features={self.input_channels}, out_features={self.output_channels}, bias={self.bias is not None}"
@@ -208,13 +216,15 @@ class LayerNormD8(nn.Module):
         self.scaling = AffineD8(channels, bias=bias) if elementwise_affine else nn.Identity()
         self.eps = eps
 
+    def affine(self):
+        if isinstance(self.scaling, AffineD8):
+            return self.scaling.alphas(), self.scaling.beta
+        return (None,) * 5, None
+
     def forward(self, xs, _out_dtype=None, _with_resid=False):
         xp, c = as_packed(xs)
         out_dtype = _out_dtype or xp.dtype
-        if isinstance(self.scaling, AffineD8):
-            a, beta = self.scaling.alphas(), self.scaling.beta
-        else:
-            a, beta = (None,) * 5, None
+        a, beta = self.affine()
         y, xres = OF.LayerNormD8Fn.apply(xp, *a, beta, self.eps, c, out_dtype)
         # _with_resid: also hand back the stream to take the residual from (its cotangent is then folded into this
         # node's backward kernel)
@@ -238,11 +248,12 @@ class MlpD8(nn.Module):
         self.fc2 = LinearD8(hidden_features, out_features, bias=bias[1])
         self.drop2 = DropoutD8(drop_probs[1])
 
-    def forward(self, xs, resid=None, rs=None, cs=None):
+    def forward(self, xs, resid=None, rs=None, cs=None, next_norm=None):
         xs = self.norm(self.drop1(self.act(self.fc1(xs))))
         if self.drop2.active or resid is None:
-            return _tail(self.drop2(self.fc2(xs)), resid, rs, cs)
-        return self.fc2(xs, resid=resid, rs=rs, cs=cs)
+            out = _tail(self.drop2(self.fc2(xs)), resid, rs, cs)
+            return out if next_norm is None else (out, None)
+        return self.fc2(xs, resid=resid, rs=rs, cs=cs, next_norm=next_norm)
 
 
 def _tail(ys, resid, rs, cs):
@@ -498,7 +509,7 @@ class AttentionD8(nn.Module):
         self.rope = rope
         self.att = F.scaled_dot_product_attention
 
-    def forward(self, xs, resid=None, rs=None, cs=None):
+    def forward(self, xs, resid=None, rs=None, cs=None, next_norm=None):
         xp, c = as_packed(xs)
         if xp.dim() != 3:
             raise ValueError("AttentionD8 expects [B, N, C] irreps")
@@ -514,24 +525,35 @@ class AttentionD8(nn.Module):
             o = OF.attention_core(q, k, v, dropout_p=drop)
             on = Octic(OF.UnpackHeadsFn.apply(o, c), c)
         if self.proj_drop.active or resid is None:
-            return _tail(self.proj_drop(self.proj(on)), resid, rs, cs)
-        return self.proj(on, resid=resid, rs=rs, cs=cs)
+            out = _tail(self.proj_drop(self.proj(on)), resid, rs, cs)
+            return out if next_norm is None else (out, None)
+        return self.proj(on, resid=resid, rs=rs, cs=cs, next_norm=next_norm)
 
 
-def _branch(norm, fn, xs_packed, c, rs, cs, out_dtype):
-    """x + drop_path(cs * fn(norm(x))) with the tail fused into fn's last GEMM when fn supports it."""
+def _branch(norm, fn, xs_packed, c, rs, cs, out_dtype, pre=None, next_norm=None):
+    """x + drop_path(cs * fn(norm(x))) with the tail fused into fn's last GEMM when fn supports it.
+    pre: norm(x) already computed by the previous branch's last layer (then x itself is the residual source).
+    next_norm: ask fn's last layer to also return next_norm(result) -> (stream, normalised or None)."""
     x = Octic(xs_packed, c)
-    if type(norm) is LayerNormD8:
+    if pre is not None:
+        xn = pre
+    elif type(norm) is LayerNormD8:
         xn, xs_packed = norm(x, _out_dtype=out_dtype, _with_resid=True)
     else:
         try:
             xn = norm(x, _out_dtype=out_dtype)
         except TypeError:  # foreign norm layer
             xn = norm(x)
+    if next_norm is not None:
+        try:
+            return fn(xn, resid=xs_packed, rs=rs, cs=cs, next_norm=next_norm)
+        except TypeError:  # foreign attention / mlp class
+            pass
     try:
-        return fn(xn, resid=xs_packed, rs=rs, cs=cs)
+        out = fn(xn, resid=xs_packed, rs=rs, cs=cs)
     except TypeError:  # foreign attention / mlp class: compose
-        return _tail(fn(xn), xs_packed, rs, cs)
+        out = _tail(fn(xn), xs_packed, rs, cs)
+    return out if next_norm is None else (out, None)
 
 
 class Layer_scale_init_BlockD8(nn.Module):
@@ -560,9 +582,34 @@ class Layer_scale_init_BlockD8(nn.Module):
     def forward(self, xs):
         xp, c = as_packed(xs)
         dt = compute_dtype(xp)
-        x1 = _branch(self.norm1, self.attn, xp, c, self._mask(xp.shape[0], xp.device), self.gamma_1.alphas(), dt)
-        x2 = _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(), dt)
+        if not (OF.OCTIC_NEXT_NORM and xp.is_cuda and dt == torch.bfloat16 and type(self.norm2) is LayerNormD8):
+            x1 = _branch(self.norm1, self.attn, xp, c, self._mask(xp.shape[0], xp.device), self.gamma_1.alphas(), dt)
+            return _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(), dt)
+        # norm2 comes out of the attention branch's last layer, norm1 of the NEXT block (link_octic_blocks) out of the
+        # MLP's: each pair is one autograd node whose backward needs no cast pass (OF.LinearD8NormFn)
+        pre = getattr(xs, "_prenorm", None)
+        pre1 = pre[1] if (pre is not None and pre[0] is self.norm1 and pre[1] is not None) else None
+        x1, y2 = _branch(self.norm1, self.attn, xp, c, self._mask(xp.shape[0], xp.device), self.gamma_1.alphas(), dt,
+                         pre=pre1, next_norm=self.norm2)
+        nn_ = getattr(self, "_next_norm", None)
+        nxt = nn_[0] if nn_ else None
+        if nxt is None:
+            return _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(),
+                           dt, pre=y2)
+        x2, yn = _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(), dt,
+                         pre=y2, next_norm=nxt)
+        if yn is not None:
+            x2._prenorm = (nxt, yn)
         return x2
+
+
+def link_octic_blocks(blocks):
+    """Tell every Layer_scale_init_BlockD8 which LayerNormD8 follows it (norm1 of the next one in `blocks`); held in a
+    tuple: not a sub-module, state_dict keys do not change."""
+    seq = [b for b in blocks if isinstance(b, Layer_scale_init_BlockD8)]
+    for cur, nxt in zip(seq[:-1], seq[1:]):
+        if type(nxt.norm1) is LayerNormD8:
+            cur._next_norm = (nxt.norm1,)
 
 
 class BlockD8(nn.Module):

@@ -293,6 +293,76 @@ class LinearD8Fn(torch.autograd.Function):
         return (dx, *dw, dbias, dy if fused else None, None, *dcs, None, None, None, None, None)
 
 
+class LinearD8NormFn(torch.autograd.Function):
+    """LinearD8Fn with the fused residual tail (y = resid + rs*cs*(x W^T + b), the new f32 stream) followed by the
+    LayerNormD8 that opens the NEXT branch: returns (y, LayerNorm(y)).  The forward is the two kernels one after the other
+    (the GEMM epilogue owns column slices, not rows); the point is the backward: the norm's backward kernel, which
+    produces the stream cotangent dx anyway, also stores bf16(rs * dx) - the cotangent of this layer's branch - so the
+    cast_rowscale pass over dx disappears (functional.OCTIC_NEXT_NORM)."""
+
+    @staticmethod
+    def forward(ctx, x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps, dtype, prep,
+                a1, a2, b1, b2, ae, beta, eps):
+        w5 = (wA1, wA2, wB1, wB2, wE)
+        cs5 = None if sA1 is None else (sA1, sA2, sB1, sB2, sE)
+        ops._require_cuda(x)
+        x_in_dtype = x.dtype
+        if x.dtype != dtype:
+            x = ops.cast_rowscale(_c(x.float()), None, 1, dtype, cin)
+        x = _c(x)
+        wb, wt = prep.get(w5, cs5, dtype, cin, cout)
+        M = x.numel() // (8 * cin)
+        y = torch.empty(x.shape[:-1] + (8 * cout,), dtype=resid.dtype, device=x.device)
+        b32 = None if bias is None else _c(bias.detach().float())
+        cs32 = None if cs5 is None else [_c(s.detach().float()) for s in cs5]
+        rs32 = None if rs is None else _c(rs.float())
+        ops.linear_fwd(ops.pview(x, cin), wb, b32, ops.pview(y, cout), M, cin, cout, dtype, resid.dtype, x,
+                       resid_v=ops.pview(_c(resid), cout), rs=rs32, rps=rps, cs5=cs32)
+        alpha = None if a1 is None else [_c(t.float()) for t in (a1, a2, b1, b2, ae)]
+        yn, stats = ops.layernorm_fwd(y, alpha, None if beta is None else _c(beta.float()), eps, dtype, cout)
+        ctx.save_for_backward(x, rs32, b32, y, stats, *w5, *(cs32 or []), *(alpha or []))
+        ctx.meta = (cin, cout, rps, dtype, cs5 is not None, bias is not None, x_in_dtype, wt, alpha is not None,
+                    beta is not None)
+        ctx.set_materialize_grads(False)
+        return y, yn
+
+    @staticmethod
+    def backward(ctx, dy, dyn):
+        cin, cout, rps, dtype, has_cs, has_bias, x_in_dtype, wt, has_affine, has_beta = ctx.meta
+        x, rs32, b32, y, stats, *rest = ctx.saved_tensors
+        w5 = rest[:5]
+        cs32 = rest[5:10] if has_cs else None
+        alpha = rest[(10 if has_cs else 5):] if has_affine else None
+        M = x.numel() // (8 * cin)
+        dal, dbeta, g = [None] * 5, None, None
+        if dyn is not None:
+            dres = None if dy is None else _c(dy.float())
+            gn = _c(dyn)
+            if ops.layernorm_bwd_cast_ok(gn, y, cout) and dtype == torch.bfloat16:
+                dy, dal_, dbeta, g = ops.layernorm_bwd_cast(gn, y, stats, alpha, dres, cout, rs32, rps,
+                                                            want_param_grads=has_affine)
+            else:
+                dy, dal_, dbeta = ops.layernorm_bwd(gn, y, stats, alpha, dres, cout, want_param_grads=has_affine)
+            dal = dal_ if dal_ is not None else dal
+        dy = _c(dy)
+        if g is None:
+            g = ops.cast_rowscale(_c(dy.float()), rs32, rps, dtype, cout)  # cotangent of the branch
+        gv, xv = ops.pview(g, cout), ops.pview(x, cin)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=dtype, device=x.device)
+            ops.linear_fwd(gv, wt, None, ops.pview(dx, cin), M, cout, cin, dtype, dtype, x)
+            if dx.dtype != x_in_dtype:
+                dx = dx.to(x_in_dtype)
+        dysum = ops.colsum_a1(gv, M, cout, dtype, x) if (has_bias and not ops.wgrad_has_colsum(cin, cout, dtype)) else None
+        w32 = [_c(w.detach().float()) for w in w5] if has_cs else None
+        dw, dcs, dbias = ops.linear_wgrad(xv, gv, M, cin, cout, dtype, x, w32=w32, cs5=cs32, bias=b32, dysum=dysum,
+                                          want_bias=has_bias)
+        dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
+        dcs = dcs if has_cs else [None] * 5
+        return (dx, *dw, dbias, dy, None, *dcs, None, None, None, None, None, *dal, dbeta if has_beta else None, None)
+
+
 # --------------------------------------------------------------------------------- head packing
 class PackHeadsFn(torch.autograd.Function):
     """packed qkv [B,T,3*8c] -> (q, k, v) each [B,H,T,8c/H].  Three separate outputs so autograd hands the three
@@ -612,6 +682,9 @@ DENSE_RESID_FUSED = False
 # The residual add of a branch and the LayerNorm that opens the next one (norm2 of the same block, norm1 of the next
 # block) as ONE row pass (csrc/dense.hip dense_resid_ln_fwd_kernel): the f32 stream is written once and not read back.
 NEXT_NORM_FUSED = True
+# Octic half: the residual-fused proj / fc2 and the LayerNormD8 that follows as one autograd node (LinearD8NormFn): the
+# norm's backward also emits the drop-path-scaled bf16 cotangent of the branch (no cast_rowscale pass).
+OCTIC_NEXT_NORM = True
 # ... and in the backward of that pair: LayerNorm backward + the backward of the residual tail in front of it as one row
 # pass (dense_ln_bwd_tail_kernel) instead of dense_ln_bwd + scale_residual_bwd (the stream cotangent is not read back).
 LN_TAIL_FUSED = True

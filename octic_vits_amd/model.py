@@ -75,6 +75,8 @@ class OcticVisionTransformer(nn.Module):
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         from .vit import link_blocks
         link_blocks(self.blocks[self.octic_equi_break_layer:])      # residual add + next norm1 as one row pass
+        from .d8_layers import link_octic_blocks
+        link_octic_blocks(self.blocks[:self.octic_equi_break_layer])
 
         std = 8 * .02  # model.py:147
         if self.num_register_tokens > 0:

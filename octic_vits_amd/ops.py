@@ -217,6 +217,33 @@ def layernorm_bwd(g, x, stats, alpha5, dres, c, want_param_grads=True):
     return dx, dal, dbeta
 
 
+def layernorm_bwd_cast_ok(g, x, c):
+    """Shapes of octic_layernorm_d8_bwd_cast: bf16 cotangent, one packed tensor, c = 32 ... 160 in steps of 32."""
+    return g.dtype == torch.bfloat16 and x.dtype == torch.float32 and c % 32 == 0 and c <= 160
+
+
+def layernorm_bwd_cast(g, x, stats, alpha5, dres, c, rs, rps, want_param_grads=True):
+    """layernorm_bwd that also returns bf16(rs[row // rps] * dx): (dx, dalpha5, dbeta, gcast)."""
+    M = x.numel() // (8 * c)
+    dx = torch.empty_like(x)
+    gc = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    nblk = lib().octic_layernorm_d8_bwd_blocks(M)
+    partials = torch.empty((nblk, 2, 8 * c), dtype=torch.float32, device=x.device)
+    gv, xv, dv = pview(g, c), pview(x, c), pview(dx, c)
+    rv = pview(dres, c) if dres is not None else None
+    t = KERNEL_TIMER.start()
+    check(lib().octic_layernorm_d8_bwd_cast(ctypes.byref(gv), ctypes.byref(xv), _p(stats), _arr5(alpha5),
+                                            ctypes.byref(rv) if rv is not None else None, ctypes.byref(dv), _p(partials),
+                                            M, c, _p(rs), int(rps), _p(gc), _stream(x)))
+    KERNEL_TIMER.stop(t, "ln_bwd_kernel<bf16>", M * 8 * c * (2 + 8 + (4 if dres is not None else 0) + 2))
+    if not want_param_grads or alpha5 is None:
+        return dx, None, None, gc
+    dal = [torch.empty_like(a) for a in alpha5]
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib().octic_layernorm_d8_bwd_finish(_p(partials), nblk, c, _arr5(dal), _p(dbeta), _stream(x)))
+    return dx, dal, dbeta, gc
+
+
 _DW_WS = {}
 
 

@@ -120,6 +120,26 @@ def test_layernorm_fwd_bwd(B, T, c, out_dtype):
     close(y2, pack(ln2(tuple(t.double() for t in xs))), rtol, atol, "ln fwd no affine")
 
 
+@pytest.mark.parametrize("B,T,c", [(64, 257, 160), (3, 50, 32), (2, 9, 96)])
+def test_layernorm_bwd_cast_equals_bwd_then_cast(B, T, c):
+    """octic_layernorm_d8_bwd_cast = octic_layernorm_d8_bwd followed by octic_cast_rowscale of its dx, bit for bit."""
+    o = ops()
+    g0 = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randn(B, T, 8 * c, generator=g0, device=DEV) * 2 + 0.3
+    g = torch.randn(B, T, 8 * c, generator=g0, device=DEV).bfloat16()
+    dres = torch.randn(B, T, 8 * c, generator=g0, device=DEV)
+    alpha = [torch.rand(c if i < 4 else 2 * c, generator=g0, device=DEV) + 0.5 for i in range(5)]
+    rs = ((torch.arange(B, device=DEV) % 3 != 0).float() / 0.66)
+    _, stats = o.layernorm_fwd(x, alpha, None, 1e-5, torch.bfloat16, c)
+    for dr, r_ in ((dres, rs), (None, None), (dres, None)):
+        dx, dal, dbeta = o.layernorm_bwd(g, x, stats, alpha, dr, c)
+        want = o.cast_rowscale(dx, r_, T, torch.bfloat16, c)
+        dx2, dal2, dbeta2, gc = o.layernorm_bwd_cast(g, x, stats, alpha, dr, c, r_, T)
+        assert torch.equal(dx2, dx) and torch.equal(gc, want) and torch.equal(dbeta2, dbeta)
+        for a, b in zip(dal2, dal):
+            assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------- Linear
 def _linear_ref(xs, W, bias, resid=None, rs=None, cs=None, T=None):
     """fp64 math of the fused linear (octic_hip.h)."""

@@ -250,3 +250,46 @@ def test_dino_list_forward_and_bf16():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             b16 = m.forward_features(a)["x_norm_patchtokens"].float()
     assert float((b16 - f32).abs().max()) < 5e-2 * max(1.0, float(f32.abs().max()))
+
+
+def test_octic_next_norm_node_is_bitwise_the_separate_nodes():
+    """Three chained Layer_scale_init_BlockD8 (d8_layers.link_octic_blocks) under bf16 autocast: with the residual-fused
+    proj / fc2 and the following LayerNormD8 as one autograd node (its backward emits the scaled bf16 cotangent, no
+    cast_rowscale pass) the output and every gradient equal the separate nodes bit for bit."""
+    import octic_vits_amd.d8_layers as L
+    import octic_vits_amd.functional as OF
+    from octic_vits_amd import ops
+    torch.manual_seed(5)
+    dim, heads, B, T = 8 * 32, 4, 4, 33
+    blocks = torch.nn.ModuleList([L.Layer_scale_init_BlockD8(dim, heads, drop_path=0.3, init_values=0.5) for _ in range(3)]).cuda()
+    for p in blocks.parameters():
+        p.data.add_(torch.randn_like(p) * 0.05)
+    L.link_octic_blocks(blocks)
+    blocks.train()
+    x = torch.randn(B, T, dim, device="cuda")
+    gout = torch.randn(B, T, dim, device="cuda")
+    res = {}
+    saved = OF.OCTIC_NEXT_NORM
+    try:
+        for mode in (True, False):
+            OF.OCTIC_NEXT_NORM = mode
+            for p in blocks.parameters():
+                p.grad = None
+            xg = x.clone().requires_grad_(True)
+            torch.manual_seed(11)
+            ops.KERNEL_TIMER.enable()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h = OF.Octic(xg, dim // 8)
+                for blk in blocks:
+                    h = blk(h)
+            h.packed.backward(gout)
+            summ = ops.KERNEL_TIMER.summary()
+            ops.KERNEL_TIMER.disable()
+            res[mode] = (h.packed.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in blocks.parameters()],
+                         sum(v["launches"] for n, v in summ.items() if n.startswith("cast_rowscale")))
+    finally:
+        OF.OCTIC_NEXT_NORM = saved
+    assert res[False][3] - res[True][3] == 5          # every residual-fused layer but the last one lost its cast pass
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for (n, _), a, b in zip(blocks.named_parameters(), res[True][2], res[False][2]):
+        assert torch.equal(a, b), n
