@@ -281,3 +281,44 @@ def test_layernorm_bwd_tail_equals_the_two_passes(rows, T, d):
         assert torch.equal(dx2, dx) and torch.equal(gyb2, gyb)
         for a, b in ((dw2, dw), (db2, db), (dgamma2, dgamma), (colsum2, colsum)):
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_ln_tail_fusion_in_a_block_chain_matches_the_unfused_chain():
+    """Three chained standard blocks of width 256 (whole-chunk rows: the fused LayerNorm-backward + residual-tail-backward
+    pass and the unpredicated row paths are live): output and x-gradient bit for bit, parameter gradients to 1e-5 of
+    their scale against the chain with the two backward passes separate (their slab sums run in another order)."""
+    from octic_vits_amd import functional as OF, vit
+    dim, heads, B, T = 256, 4, 4, 50
+    blocks = torch.nn.ModuleList([_blocks("layer_scale", dim, heads, 0.0)[0] for _ in range(3)])
+    for i, blk in enumerate(blocks):
+        for j, p in enumerate(blk.parameters()):
+            torch.manual_seed(100 * i + j)
+            p.data.add_(torch.randn_like(p) * 0.05)
+    vit.link_blocks(blocks)
+    x = gen(41, B, T, dim).to(DEV)
+    gout = gen(42, B, T, dim).to(DEV)
+    o = ops()
+    res = {}
+    saved = OF.LN_TAIL_FUSED
+    try:
+        for mode in (True, False):
+            OF.LN_TAIL_FUSED = mode
+            for p in blocks.parameters():
+                p.grad = None
+            xg = x.clone().requires_grad_(True)
+            o.KERNEL_TIMER.enable()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h = xg
+                for blk in blocks:
+                    h = blk(h)
+            h.backward(gout)
+            s = o.KERNEL_TIMER.summary()
+            o.KERNEL_TIMER.disable()
+            res[mode] = (h.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in blocks.parameters()],
+                         sum(v["launches"] for n, v in s.items() if n.startswith("dense_ln_bwd_tail")))
+    finally:
+        OF.LN_TAIL_FUSED = saved
+    assert res[True][3] == 5 and res[False][3] == 0
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for (n, _), a, b in zip(blocks.named_parameters(), res[True][2], res[False][2]):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-5 * max(1.0, float(b.float().abs().max())), n
