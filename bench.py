@@ -212,25 +212,24 @@ def main():
             raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"]).returncode)
     sync()
     log("warm-up done, timing")
-    if not args.no_kernel_timing:
-        ops.KERNEL_TIMER.enable()
-    # per-kernel HIP events are recorded in one timed step out of ten (a step with ~1800 event records between its
-    # kernels runs ~20 % slower); every kernel still gets >= 16 timed launches per sampled step, all inside the
-    # timed region
-    timing = ops.KERNEL_TIMER.on
-    sampled = [i for i in range(args.steps) if i % 10 == 5] or [args.steps // 2]
+    # The timed region is `steps` full iterations and nothing else: graph replays at one GPU (eager DDP steps otherwise),
+    # no host read of the loss inside it (train._LossWatch checks two steps late on a pinned copy).  The per-kernel HIP
+    # events (~1800 records per step, which slow a step by ~20 %) are taken AFTER it, in the same process on the same
+    # weights: see `step_breakdown.note`.
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if timing:
-            ops.KERNEL_TIMER.on = i in sampled
-        if graphed is not None and not (timing and i in sampled):
-            loss = graphed.replay()
-        else:
-            loss = trainer.step(samples, targets)
-    issued = time.perf_counter() - t0          # host time to enqueue the steps (no sync): launch-bound if ~ elapsed
+        loss = graphed.replay() if graphed is not None else trainer.step(samples, targets)
+    issued = time.perf_counter() - t0          # host time to enqueue the steps (no sync inside): launch-bound if ~ elapsed
     sync()
     elapsed = time.perf_counter() - t0
-    ops.KERNEL_TIMER.disable()
+    sampled = []
+    if not args.no_kernel_timing:
+        ops.KERNEL_TIMER.enable()
+        sampled = [0, 1]
+        for _ in sampled:
+            trainer.step(samples, targets)
+        sync()
+        ops.KERNEL_TIMER.disable()
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -283,7 +282,7 @@ def main():
                        "global_batch": world * args.batch * args.accum, "per_gpu_batch": args.batch,
                        "accum_steps": args.accum, "parallelism": f"dp{world}",
                        "library_gemm_table": bool(trainer.tuned_gemms),
-                       "launch": "hipGraph replay (kernel-timing steps eager)" if graphed is not None else "eager"},
+                       "launch": "hipGraph replay" if graphed is not None else "eager"},
             "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),
             "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4),
         }
@@ -389,8 +388,10 @@ def main():
             # individually; the rest is ATen glue (casts, reductions, RNG, copies) and the fused optimizer
             line["step_breakdown"] = {"timed_kernels_ms": round(timed_us / 1e3, 2),
                                       "other_ms": round(ms - timed_us / 1e3, 2),
-                                      "note": "timed = engine kernels + BLAS-library GEMMs of the standard half, HIP events in "
-                                              "sampled steps (which run slower than the average step); other = ATen glue + optimizer"}
+                                      "note": "per-kernel HIP events are recorded in 2 eager steps run right AFTER the timed region "
+                                              "(same process, same weights; such a step runs ~20 % slower than a replayed one, so "
+                                              "the kernel times are upper bounds); the timed region itself is `steps` full "
+                                              "iterations with no event records and no host read; other = ATen glue + optimizer"}
         if fwd_only is not None:
             line["extra"] = {"forward_only": fwd_only}
         if world == 1 and not args.no_cpu_baseline:

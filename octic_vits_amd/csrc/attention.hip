@@ -501,8 +501,9 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
       const int i = wid + j * W;
       if (i < ninstr) {
         const unsigned vo = voff[j] == 0x7FFFFFF0u ? voff[j] : voff[j] + (unsigned)(bs * (((emask >> j) & 1) ? 4 : 2));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 1\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                     :: "s"(lds_dst + i * 1024), "v"(vo), "s"(rs) : "memory");
+        unsigned keep;   // M0 saved / restored inside the statement (octic_common.hpp: dma16_to_lds)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 1\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_dst + i * 1024), "v"(vo), "s"(rs) : "memory");
       }
     }
   };
@@ -704,11 +705,9 @@ static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
     const bool fits = nt <= 9 && nrows <= 2 && need <= 160 * 1024 && kimg / 1024 <= 8 * W &&
                       (a.T * 2 * KS + W * 64 - 1) / (W * 64) <= 6 && (a.T - 1) * a.sT * 2 + a.hd * 2 < 0x7FFFFFF0ll;
     if (fits) {
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      static DeviceOnce once;
+      const int cus = device_cus();
+      if (once.first()) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_persist_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
       }
@@ -722,12 +721,11 @@ static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
   const size_t comb = ((size_t)W * 32 * (DT * 32 + kPartPad) + (2 * W + 1) * 32) * sizeof(float);
   if (nt != W && comb > smem) smem = comb;
   if (smem > 160 * 1024) return OCTIC_ESHAPE;
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, DT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, DT, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
-    done = true;
   }
   if (W <= 8) attn_fwd_kernel<KS, DT, 512><<<(int)(B * a.H), W * 64, smem, s>>>(a, rsk, rsv, nt);
   else attn_fwd_kernel<KS, DT, 640><<<(int)(B * a.H), W * 64, smem, s>>>(a, rsk, rsv, nt);
@@ -1115,14 +1113,13 @@ static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream
   if (nt != W && comb > smem_dq) smem_dq = comb;
   if (nt != W && comb > smem_kv) smem_kv = comb;
   if (smem_kv > 160 * 1024 || smem_dq > 160 * 1024) return OCTIC_ESHAPE;
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<KS, DT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KS, DT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<KS, DT, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KS, DT, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
-    done = true;
   }
   if (phase & 1) {
     if (Wq <= 8) attn_bwd_dq_kernel<KS, DT, 512><<<(int)(B * a.H), Wq * 64, smem_dq, s>>>(a, rs, nt);

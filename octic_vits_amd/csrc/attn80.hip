@@ -59,10 +59,14 @@ __device__ __forceinline__ int swz(int r) { const int t = (r >> 1) & 7; return (
 #define A80_DMA_POLICY ""          // cache policy of the LDS-DMA loads (developer A/B: " sc1", " nt", " sc0 sc1")
 #endif
 __device__ __forceinline__ void dma16(unsigned lds_dst, unsigned vo, const i32x4 rs) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen" A80_DMA_POLICY " lds" :: "s"(lds_dst), "v"(vo), "s"(rs) : "memory");
+  unsigned keep;   // M0 saved / restored inside the statement (octic_common.hpp: dma16_to_lds)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen" A80_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(vo), "s"(rs) : "memory");
 }
 __device__ __forceinline__ void dma4(unsigned lds_dst, unsigned vo, const i32x4 rs) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, 0 offen" A80_DMA_POLICY " lds" :: "s"(lds_dst), "v"(vo), "s"(rs) : "memory");
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dword %2, %3, 0 offen" A80_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(vo), "s"(rs) : "memory");
 }
 
 // descriptor of one (batch element, head) of a tensor: rows 0..T-1, everything past the last row reads as zero
@@ -843,14 +847,7 @@ inline bool shape_ok(int T, int hd, int64_t sT, int64_t oT) {
 }
 
 static int cu_count() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    (void)hipGetLastError();
-  }
-  return cus;
+  return device_cus();
 }
 
 }  // namespace a80
@@ -867,12 +864,11 @@ int attn80_fwd_launch(const AttnArgs& a_, int64_t B, hipStream_t s) {
   a.dbg = g_a80_variant >> 4;
   const int nt = (a.T + 31) / 32, W = nt < 8 ? nt : 8;
   const int units = (int)(B * a.H), cus = cu_count();
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)fwd_os_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
-    done = true;
   }
   if ((g_a80_variant & 15) == 0 && nt == MAXNT) fwd_os_kernel<<<units < cus ? units : cus, 512, fwd_os_lds(nt), s>>>(a, units);
   else fwd_kernel<<<units < cus ? units : cus, W * 64, fwd_lds(nt), s>>>(a, nt, units);

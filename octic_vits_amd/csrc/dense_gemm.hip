@@ -720,17 +720,7 @@ extern "C" {
 
 // CUs of the current device (the split-K parts of a tile wait for each other: the plan must not assume more workgroup
 // slots than the device has); 256 when no device is visible (host-only callers sizing a workspace)
-static int dense_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    (void)hipGetLastError();
-    cus = n;
-  }
-  return cus;
-}
+static int dense_cus() { return device_cus(); }
 
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K) {
   const DgPlan p = dense_plan(M, N, K, dense_cus());
@@ -770,14 +760,13 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
     a.slabs = (float*)((char*)workspace + (((int64_t)p.rem * 4 + 255) & ~(int64_t)255));
   }
   const int smem = DG_LDS;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipGetLastError();
-    attr_done = true;
   }
   switch (mode) {
     case DG_PLAIN: dense_nt_kernel<DG_PLAIN><<<p.grid, 512, smem, s>>>(a); break;

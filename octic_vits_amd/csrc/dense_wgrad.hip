@@ -103,7 +103,9 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
   // round 3's first attempt; see dma16_to_lds in octic_common.hpp)
   auto dma16 = [](unsigned lds_dst, unsigned voff, int soff, const i32x4 rs) {
     lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    unsigned keep;   // M0 saved / restored inside the statement (octic_common.hpp: dma16_to_lds)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
   };
   const unsigned lds0 = lds_offset(lds);
 
@@ -408,13 +410,7 @@ extern "C" {
 static int g_tn_slabs_override = 0;
 static int dw_slabs(int tiles, int steps) {
   if (g_tn_slabs_override > 0) return g_tn_slabs_override <= steps / 2 ? g_tn_slabs_override : (steps / 2 > 0 ? steps / 2 : 1);
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    (void)hipGetLastError();
-  }
+  const int cus = device_cus();
   const int tiles8 = (tiles + 7) / 8 * 8;
   const int per_slab = DW_MAP == 1 ? tiles : tiles8;
   // One round of workgroups whenever the tiles fit: the most slabs that still give every item its own CU (measured on
@@ -468,11 +464,10 @@ int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int
   a.slabs = (float*)p;
   hipStream_t s = (hipStream_t)stream;
   const int smem = DW_SLOTS * DW_UNIT;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)dense_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipGetLastError();
-    attr_done = true;
   }
 #if DW_MAP == 1
   dense_tn_kernel<<<(a.tiles * a.S + 255) / 256 * 256, 512, smem, s>>>(a);

@@ -620,12 +620,11 @@ int launch_ring_nt(GemmArgs& a, hipStream_t s) {
   }
   a.total_tiles = t;
   const size_t smem = (size_t)S * (BM + BN) * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 0, NT, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 1, NT, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipGetLastError();
-    attr_done = true;
   }
   if (fused) linear_d8_ring_kernel<TIN, TOUT, 1, NT, S, BM><<<t, BM * 2, smem, s>>>(a);
   else linear_d8_ring_kernel<TIN, TOUT, 0, NT, S, BM><<<t, BM * 2, smem, s>>>(a);
@@ -690,14 +689,13 @@ int launch_gemm(GemmArgs& a, hipStream_t s) {
   a.total_tiles = t;
   const size_t smem = (size_t)2 * (kBM + bn) * 128;
   // gfx950 has 160 KiB of LDS per CU; anything above the 64 KiB default must be opted into once.
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce once;
+  if (once.first()) {
     hipFuncSetAttribute((const void*)linear_d8_kernel<TIN, TOUT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kBM + 64) * 128);
     hipFuncSetAttribute((const void*)linear_d8_kernel<TIN, TOUT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kBM + 96) * 128);
     hipFuncSetAttribute((const void*)linear_d8_kernel<TIN, TOUT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kBM + 128) * 128);
     hipFuncSetAttribute((const void*)linear_d8_kernel<TIN, TOUT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kBM + 160) * 128);
     (void)hipGetLastError();
-    attr_done = true;
   }
   switch (nt) {
     case 2: linear_d8_kernel<TIN, TOUT, 2><<<t, 256, smem, s>>>(a); break;

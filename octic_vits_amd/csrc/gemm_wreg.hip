@@ -417,13 +417,7 @@ __global__ __launch_bounds__(256, 2) void linear_d8_wreg_kernel(GemmArgs args) {
 }
 
 static int cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
+  return device_cus();
 }
 
 template <typename TOUT>
@@ -495,12 +489,11 @@ int launch_t(GemmArgs& a, hipStream_t s) {
   }
   a.total_tiles = t;
   const size_t smem = (size_t)S * TM * Kc * 2 + 4 * TM * (NTW_MAX * 16 * ES + 16) + 2 * 4 * NTW_MAX * 16 * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce once;
+  if (once.first()) {
     hipFuncSetAttribute((const void*)linear_d8_wreg_kernel<TOUT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     hipFuncSetAttribute((const void*)linear_d8_wreg_kernel<TOUT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipGetLastError();
-    attr_done = true;
   }
   if (fused) linear_d8_wreg_kernel<TOUT, 1><<<t, 256, smem, s>>>(a);
   else linear_d8_wreg_kernel<TOUT, 0><<<t, 256, smem, s>>>(a);

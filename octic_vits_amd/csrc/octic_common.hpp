@@ -130,7 +130,41 @@ __device__ inline float wave_sum(float v) { return wave_total(v); }
 __device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 __device__ __forceinline__ void dma16_to_lds(unsigned lds_dst, const void* src) {
   lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(src) : "memory");
+  // M0 is compiler-reserved (movrel indexing, its own *_load_lds builtins) and a clobber entry for it is only a warning:
+  // every statement that writes M0 saves and restores it itself (two scalar moves)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(src) : "memory");
+}
+
+// ---- per-device one-time setup ---------------------------------------------------------------
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) applies to the CURRENT device only and the CU count is a
+// property of a device: both are keyed on hipGetDevice(), so a process that drives a second GPU gets its own opt-in
+// and its own grid sizes (round-3 advisor finding: process-wide `static bool done`).
+inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+  return (d < 0 || d >= 64) ? 0 : d;
+}
+struct DeviceOnce {               // `static DeviceOnce once; if (once.first()) { ...setup for this device... }`
+  unsigned long long mask = 0;
+  bool first() {
+    const unsigned long long bit = 1ull << current_device();
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+  }
+};
+inline int device_cus() {         // CUs of the current device (256 when no device is visible)
+  static int cus[64] = {};
+  const int d = current_device();
+  if (!cus[d]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    (void)hipGetLastError();
+    cus[d] = n;
+  }
+  return cus[d];
 }
 
 // ---- host-side argument checks -------------------------------------------------------------

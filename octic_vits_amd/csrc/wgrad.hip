@@ -463,11 +463,10 @@ int launch_wgrad_tt(WgArgs& a, hipStream_t s) {
   }
   a.wgs = t;
   constexpr size_t smem = (size_t)2 * 2 * WElem<TIN>::BMR * (BW * sizeof(TIN) + 16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<TIN, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipGetLastError();
-    attr_done = true;
   }
   wgrad_kernel<TIN, TT><<<t, 256, smem, s>>>(a);
   return launch_status();
@@ -491,12 +490,11 @@ inline int launch_wgrad_ring(WgArgs& a, hipStream_t s) {
     t += a.g[i].k_tiles * a.g[i].n_tiles * a.g[i].splits;
   }
   a.wgs = t;
-  static bool attr_done = false;
-  if (!attr_done && kWgS * kWgStage > 64 * 1024) {
+  static DeviceOnce once;
+  if (kWgS * kWgStage > 64 * 1024 && once.first()) {
     (void)hipFuncSetAttribute((const void*)wgrad_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgS * kWgStage);
     (void)hipGetLastError();
   }
-  attr_done = true;
   wgrad_ring_kernel<<<t, 256, kWgS * kWgStage, s>>>(a);
   return launch_status();
 }

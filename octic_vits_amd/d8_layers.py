@@ -40,6 +40,11 @@ drop_path_mask_source = None
 # the reference's per-call draws (the parity tests inject masks through drop_path_mask_source).  The pool is re-drawn at
 # the start of every forward, so a seeded forward is reproducible and a captured step contains its own draw.  Blocks
 # called on their own (pool not armed) draw per call as before.
+# Activation checkpointing: a recompute runs outside the armed window and must see the SAME masks as the forward.  The
+# pooled draw is therefore used only when nothing can replay the block later - gradients enabled (a re-entrant
+# checkpoint runs its forward under no_grad) and no saved-tensor hooks installed (the non-re-entrant checkpoint and the
+# offloading contexts install them).  Otherwise masks are drawn per call from torch's generator, whose state
+# torch.utils.checkpoint saves and restores, so forward and recompute agree exactly as they do in the reference.
 DROP_PATH_POOL = 64
 _mask_pool = {}
 _pool_armed = False
@@ -54,9 +59,18 @@ def arm_drop_path_pool(on=True):
             pool[1] = DROP_PATH_POOL
 
 
+def _pool_usable():
+    if not _pool_armed or not torch.is_grad_enabled():
+        return False
+    try:
+        return torch._C._autograd._top_saved_tensors_default_hooks(False) is None
+    except AttributeError:      # private API moved: be safe, draw per call
+        return False
+
+
 def _drop_path_mask(B, drop_prob, device, scale_by_keep=True):
     keep = 1.0 - drop_prob
-    if drop_path_mask_source is not None or not _pool_armed:
+    if drop_path_mask_source is not None or not _pool_usable():
         if drop_path_mask_source is not None:
             m = drop_path_mask_source(B, keep, device)
         else:
@@ -588,7 +602,9 @@ class Layer_scale_init_BlockD8(nn.Module):
         # norm2 comes out of the attention branch's last layer, norm1 of the NEXT block (link_octic_blocks) out of the
         # MLP's: each pair is one autograd node whose backward needs no cast pass (OF.LinearD8NormFn)
         pre = getattr(xs, "_prenorm", None)
-        pre1 = pre[1] if (pre is not None and pre[0] is self.norm1 and pre[1] is not None) else None
+        # valid only for the packed stream exactly as the previous block returned it (version counter: in-place edits)
+        pre1 = pre[1] if (pre is not None and pre[0] is self.norm1 and pre[1] is not None
+                          and pre[2] == xp._version and pre[3] == xp.data_ptr()) else None
         x1, y2 = _branch(self.norm1, self.attn, xp, c, self._mask(xp.shape[0], xp.device), self.gamma_1.alphas(), dt,
                          pre=pre1, next_norm=self.norm2)
         nn_ = getattr(self, "_next_norm", None)
@@ -599,7 +615,7 @@ class Layer_scale_init_BlockD8(nn.Module):
         x2, yn = _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(), dt,
                          pre=y2, next_norm=nxt)
         if yn is not None:
-            x2._prenorm = (nxt, yn)
+            x2._prenorm = (nxt, yn, x2.packed._version, x2.packed.data_ptr())
         return x2
 
 

@@ -267,18 +267,18 @@ def _lift_tables_on(O: int, Cin: int, h: int, device: str, dtype):
         i1, s1, i2, s2 = [], [], [], []
         for conv, kind, r in _LIFT_BLOCKS:
             ia, sa, ib, sb = _unfold_tables(h, kind)
-            scale = 0.5 if kind == "E" else SQRT2_OVER_4
-            if r:
+            scale = 0.5 if kind == "E" else SQRT2_OVER_4      # factors are built in float64 and cast to `dtype` at the end:
+            if r:                                                # an f32 table would cost a float64 caller 1e-9 (advisor, r3)
                 ia, sa = ia[rot], sa[rot]
             off = conv * O * Cin * Q
             i1.append((off + base + ia.view(1, 1, P2)).reshape(-1))
-            s1.append((scale * sa).view(1, 1, P2).expand(O, Cin, P2).reshape(-1))
+            s1.append((scale * sa.double()).view(1, 1, P2).expand(O, Cin, P2).reshape(-1))
             if ib is None:
                 i2.append(torch.zeros(O * Cin * P2, dtype=torch.long))
-                s2.append(torch.zeros(O * Cin * P2))
+                s2.append(torch.zeros(O * Cin * P2, dtype=torch.float64))
             else:
                 i2.append((off + base + ib.view(1, 1, P2)).reshape(-1))
-                s2.append((scale * sb).view(1, 1, P2).expand(O, Cin, P2).reshape(-1))
+                s2.append((scale * sb.double()).view(1, 1, P2).expand(O, Cin, P2).reshape(-1))
         i1, s1, i2, s2 = torch.cat(i1), torch.cat(s1), torch.cat(i2), torch.cat(s2)
         # inverse: for every parameter entry the output positions that read it (either term), with their factors
         used2 = s2 != 0

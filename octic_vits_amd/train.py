@@ -5,8 +5,9 @@ recipe of experiments/train_deit.py:31-51): model.train -> bf16 autocast forward
 targets -> backward (gradients all-reduced over RCCL by DDP bucket hooks, overlapped with backward) -> LAMB step
 (lr 3e-3, wd 0.02) -> EMA update -> gradient norm.  Differences, all stated in DESIGN.md:
   * autocast dtype is bf16 (BASELINE.json) instead of the reference's fp16 + loss scaler;
-  * the non-finite-loss check (engine.py:67-71) reads the PREVIOUS step's loss so the host never blocks on
-    the current step (the reference calls loss.item() and torch.cuda.synchronize() every iteration);
+  * the non-finite-loss check (engine.py:67-71) runs TWO steps late on a pinned host copy of the loss (`_LossWatch`):
+    the host never waits for work the GPU has not finished long ago, so it can enqueue step k+1 while step k runs
+    (the reference calls loss.item() and torch.cuda.synchronize() every iteration);
   * the logged gradient norm is the one LAMB computes anyway (the reference makes a second pass,
     engine.py:84).
 """
@@ -368,6 +369,60 @@ def octic_weight_preps(model):
     return [m._prep for m in model.modules() if isinstance(m, LinearD8)]
 
 
+class _LossWatch:
+    """The non-finite-loss check of deit/engine.py:67-71 without a per-step stream drain.
+
+    `loss.item()` on the previous step's loss waits for everything queued before it - in graph mode the whole previous
+    replay - so the host could never enqueue step k+1 while step k runs (round-3 review: `host_issue_ms_per_step` read
+    65 ms for a 0.5 ms graph launch).  Here every step ends with an asynchronous copy of its loss into one of `lag + 1`
+    pinned host slots plus an event; the check of step k happens when step k + lag is about to be issued (lag 2): step k
+    finished a whole step ago and step k+1 is keeping the GPU busy, so waiting on k's event costs nothing.  The optimizer
+    kernels refuse a non-finite step on their own, so the weights are intact when this raises.  On the CPU the loss is
+    read directly (nothing is asynchronous there)."""
+
+    def __init__(self, device_type, lag=2):
+        self.cuda = device_type == "cuda"
+        self.lag = lag
+        self.n = 0
+        if self.cuda:
+            self.host = torch.zeros(lag + 1, dtype=torch.float32).pin_memory()
+            self.events = [torch.cuda.Event() for _ in range(lag + 1)]
+        else:
+            self.host = torch.zeros(lag + 1, dtype=torch.float32)
+
+    def push(self, loss):
+        """Call after a step has been issued; `loss` is its (device-resident) scalar loss."""
+        slot = self.n % (self.lag + 1)
+        if self.cuda:
+            self.host[slot:slot + 1].copy_(loss.detach().reshape(1).float(), non_blocking=True)
+            self.events[slot].record()
+        else:
+            self.host[slot] = float(loss.detach())
+        self.n += 1
+
+    def check(self, block=True):
+        """Call before issuing a step: raises if the loss of the step `lag` steps back was not finite."""
+        k = self.n - self.lag
+        if k < 0:
+            return
+        slot = k % (self.lag + 1)
+        if self.cuda:
+            if block:
+                self.events[slot].synchronize()
+            elif not self.events[slot].query():
+                return
+        if not math.isfinite(float(self.host[slot])):
+            raise FloatingPointError("Loss is not finite, stopping training")
+
+    def drain(self):
+        """Check every loss that has not been looked at yet (end of an epoch / before a checkpoint)."""
+        if self.cuda:
+            torch.cuda.current_stream().synchronize()
+        for k in range(max(0, self.n - self.lag), self.n):
+            if not math.isfinite(float(self.host[k % (self.lag + 1)])):
+                raise FloatingPointError("Loss is not finite, stopping training")
+
+
 class Trainer:
     """One DeiT-III iteration (deit/engine.py:43-87).  ``accum_steps`` micro-batches per optimizer step express the
     reference's global batch on fewer GPUs (configs[2]: 2048 = 8 GPUs x 64 x 4 micro-batches; the reference ran
@@ -407,7 +462,7 @@ class Trainer:
             self.optimizer = Lamb(groups, lr=lr, eps=opt_eps, weight_decay=weight_decay)
             self.ema = ModelEma(model, ema_decay) if ema_decay else None
         self.criterion = nn.BCEWithLogitsLoss()
-        self._pending_loss = None
+        self._watch = _LossWatch(self.device_type)
 
     def _forward_loss(self, samples, targets):
         if self.autocast:
@@ -418,12 +473,10 @@ class Trainer:
 
     def step(self, samples, targets):
         self.model.train()
-        # engine.py:67-71 one step late (the host never blocks on the step in flight); the optimizer kernels refuse a
-        # non-finite step on their own, so the weights are still intact when this raises
+        # engine.py:67-71 two steps late on a pinned host copy (_LossWatch): no stream drain per step
         self._steps += 1
-        if self._pending_loss is not None and self._steps % self.check_every == 0 \
-                and not math.isfinite(self._pending_loss.item()):
-            raise FloatingPointError("Loss is not finite, stopping training")
+        if self._steps % self.check_every == 0:
+            self._watch.check()
         self.optimizer.zero_grad(set_to_none=True)
         k = self.accum_steps
         if k == 1:
@@ -442,7 +495,7 @@ class Trainer:
         self.optimizer.step()
         if self.ema is not None:
             self.ema.update(self.raw_model)
-        self._pending_loss = loss.detach()
+        self._watch.push(loss)
         return loss
 
     # ---- the whole iteration as one hipGraph -----------------------------------------------------------------------
@@ -488,16 +541,17 @@ class GraphedStep:
     def replay(self, samples=None, targets=None):
         t = self.trainer
         t._steps += 1
-        # the same one-step-late check as Trainer.step; self.loss is overwritten by the replay, so look first
-        if t._pending_loss is not None and t._steps % t.check_every == 0 and not math.isfinite(t._pending_loss.item()):
-            raise FloatingPointError("Loss is not finite, stopping training")
+        # the same late check as Trainer.step (the graph's loss buffer is overwritten by every replay: _LossWatch
+        # keeps a pinned host copy per step, taken by a stream-ordered copy behind the replay)
+        if t._steps % t.check_every == 0:
+            t._watch.check()
         if samples is not None and samples.data_ptr() != self.samples.data_ptr():
             self.samples.copy_(samples, non_blocking=True)
         if targets is not None and targets.data_ptr() != self.targets.data_ptr():
             self.targets.copy_(targets, non_blocking=True)
         self.graph.replay()
         t.optimizer.step_count += 1
-        t._pending_loss = self.loss
+        t._watch.push(self.loss)
         return self.loss
 
 

@@ -3,7 +3,9 @@ the reference (deit/vit.py:14-134 ``Attention``/``Layer_scale_init_Block``; timm
 bare default, model.py:21,63).  In f32 / on CPU these are stock PyTorch ops like the reference.  Under bf16 autocast on the
 GPU a block runs on the engine instead (§8f-1, §8f-3): HIP LayerNorm / attention / layer-scale+drop-path+residual
 kernels around hand-written GEMMs (csrc/dense_gemm.hip, csrc/dense_wgrad.hip; the BLAS library only for shapes they
-refuse), with cached bf16 weights — same math, same parameters, same RNG draws."""
+refuse), with cached bf16 weights — same math, same parameters.  Drop-path masks have the reference's distribution;
+inside a model forward they are drawn 64 at a time (d8_layers.DROP_PATH_POOL), so torch's generator is consumed in a
+different order than by the reference's per-call draws (parity tests inject the reference's masks)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -163,7 +165,9 @@ def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2, next_norm
     dt = torch.bfloat16
     fuse = _OF.NEXT_NORM_FUSED
     pre = getattr(x, "_octic_prenorm", None)
-    if pre is not None and pre[0] is norm1 and pre[1] is not None:
+    # the carried norm is only valid for the stream exactly as the previous block returned it: an in-place edit in between
+    # (a forward hook doing x.mul_(), a token edit) bumps the version counter and the block normalises again
+    if pre is not None and pre[0] is norm1 and pre[1] is not None and pre[2] == x._version:
         y, xres = pre[1], x                   # normalised by the previous block's residual pass
     else:
         y, xres = _OF.DenseLayerNormFn.apply(x, norm1.weight, norm1.bias, norm1.eps, dt)
@@ -179,7 +183,7 @@ def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2, next_norm
     if fuse and type(next_norm) is nn.LayerNorm and tuple(next_norm.normalized_shape) == (d,):
         out, yn = mlp.forward_fused(y, xres, gamma2, _drop_path_scale(dp2, x), dt, next_norm=next_norm)
         if yn is not None:
-            out._octic_prenorm = (next_norm, yn)
+            out._octic_prenorm = (next_norm, yn, out._version)
         return out
     return mlp.forward_fused(y, xres, gamma2, _drop_path_scale(dp2, x), dt)
 

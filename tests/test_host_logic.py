@@ -179,3 +179,69 @@ def test_packed_pos_embed_equals_the_composed_construction():
         g = torch.randn_like(fused)
         for a, b in zip(torch.autograd.grad(U.packed_pos_embed(ps), ps, g), torch.autograd.grad(U.packed_pos_embed_composed(ps), ps, g)):
             assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
+def test_drop_path_pool_is_bypassed_where_a_recompute_could_replay_the_block():
+    """Round-3 advisor finding: a checkpoint recompute runs outside the armed window, so the forward must not have used
+    the pooled draw.  Under torch.utils.checkpoint (both flavours) masks are drawn per call from torch's generator - whose
+    state checkpoint saves and restores - so the recompute sees exactly the forward's mask."""
+    import torch
+    from torch.utils.checkpoint import checkpoint
+    from octic_vits_amd import d8_layers as L
+    seen = []
+
+    def branch(x):
+        m = L._drop_path_mask(x.shape[0], 0.5, x.device)
+        seen.append(m.clone())
+        return x * m.view(-1, 1)
+
+    for reentrant in (False, True):
+        seen.clear()
+        x = torch.ones(16, 4, requires_grad=True)
+        torch.manual_seed(21)
+        L.arm_drop_path_pool(True)
+        try:
+            y = checkpoint(branch, x, use_reentrant=reentrant)
+        finally:
+            L.arm_drop_path_pool(False)
+        y.sum().backward()                                    # recompute happens here, pool disarmed
+        assert len(seen) == 2 and torch.equal(seen[0], seen[1]), reentrant
+        assert torch.equal(x.grad, seen[0].view(-1, 1).expand(16, 4))
+    # and without a checkpoint the armed pool is used (one [64, B] draw)
+    L.arm_drop_path_pool(True)
+    try:
+        L._drop_path_mask(16, 0.5, torch.device("cpu"))
+        assert any(k[1] == 16 for k in L._mask_pool)
+    finally:
+        L.arm_drop_path_pool(False)
+
+
+def test_lift_weight_gather_is_exact_in_float64():
+    """The gather factors of d8_utils._lift_tables_on are built in float64 (an f32 table cost a float64 caller 1e-9 in
+    the forward, advisor r3): in float64 the fused weight equals the composed construction to the last bit."""
+    import torch
+    from octic_vits_amd.d8_layers import LiftD8
+    torch.manual_seed(6)
+    m = LiftD8(3, 16, 4, 4, bias=True).double()
+    assert torch.equal(m.packed_weight(), m.packed_weight_composed())
+
+
+def test_loss_watch_raises_two_steps_late_and_never_on_finite_losses():
+    """train._LossWatch (deit/engine.py:67-71 without a per-step stream drain): the loss of step k is examined when step
+    k + 2 is about to be issued; drain() looks at everything that is left."""
+    import torch
+    from octic_vits_amd.train import _LossWatch
+    w = _LossWatch("cpu")
+    for v in (0.7, 0.6, 0.5):
+        w.check()
+        w.push(torch.tensor(v))
+    w.check()
+    w.push(torch.tensor(float("nan")))       # step 3
+    w.check()                                # looks at step 2: fine
+    w.push(torch.tensor(0.4))                # step 4
+    with pytest.raises(FloatingPointError):
+        w.check()                            # looks at step 3
+    w2 = _LossWatch("cpu")
+    w2.push(torch.tensor(float("inf")))
+    with pytest.raises(FloatingPointError):
+        w2.drain()
