@@ -28,6 +28,15 @@
 // XCD's L2).  M = 16 448 gives 65 x {5,15,20} tiles on 256 CUs: the last partial round would idle most of the chip, so
 // the tiles of that round are split along K over `split` workgroups each, placed at the FRONT of the grid (f32 partial
 // slabs + a ticket; the last arriver of a tile reduces and runs the epilogue) where that pays - see dense_plan().
+//
+// Round 4: the tile WIDTH is a template parameter (NT = MFMA n-tiles per wave).  NT = 4 is the 256 x 256 tile above.
+// NT = 5 is a 256 x 320 tile for the N = 1280 problems (proj, fc2, the input gradients of proj and fc1): 65 x 5 = 325
+// tiles of 256 x 256 are 1.27 rounds on 256 CUs, 64 x 4 = 256 tiles of 256 x 320 are exactly ONE (plus the 64-row last
+// panel, whose 4 tiles go through the split-K front of the grid with the MFMAs of empty row halves skipped).  A wave then
+// owns 128 x 80 (160 accumulator registers, 242 VGPRs in all); the column sets of a wave are 3 + 2 n-tiles, so the four
+// units of a K-tile are 16 / 24 / 16 / 16 KiB (2 / 3 / 2 / 2 DMA instructions per wave; the four units in flight behind
+// every landed-wait are always one of each kind: vmcnt(9)), two K-tiles of 72 KiB fill the ring, and the epilogue stages
+// the tile in two 64-row passes.
 #include <type_traits>
 #ifndef DG_DMA_IN_MMA
 #define DG_DMA_IN_MMA 0      // 0: DMA issued in the R interval (beside the partner's MFMAs); 1: mid-MFMA; 2: M start
@@ -36,11 +45,8 @@
 
 namespace octic {
 
-constexpr int DG_BM = 256, DG_BN = 256, DG_BK = 64;
-constexpr int DG_UNIT = 128 * 128;            // bytes per unit
-#ifndef DG_NSLOT
-#define DG_NSLOT 8
-#endif
+constexpr int DG_BM = 256, DG_BK = 64;
+constexpr int DG_UNIT = 128 * 128;            // bytes per 128-row unit
 #ifndef DG_DIST
 #define DG_DIST 6
 #endif
@@ -56,9 +62,29 @@ constexpr int DG_UNIT = 128 * 128;            // bytes per unit
 #ifndef DG_BALANCED
 #define DG_BALANCED 0    // 1: first row half of the next K-tile is read in phase 3 (reads 4/4/8/8 instead of 12/4/8/0)
 #endif
-constexpr int DG_SLOTS = DG_NSLOT;            // ring slots (10 x 16 KiB = all 160 KiB of the CU's LDS)
+constexpr int DG_SLOTS = 8;                   // ring = two K-tiles of four units
 constexpr int DG_D = DG_DIST;                 // prefetch distance in units: unit g+D is issued in R_g (D <= slots - 2)
-constexpr int DG_LDS = DG_SLOTS * DG_UNIT > 8 * 128 * 144 ? DG_SLOTS * DG_UNIT : 8 * 128 * 144;   // ring | 8 x 18 KiB epilogue tiles
+static_assert(DG_D >= 4 && DG_D <= DG_SLOTS - 2, "prefetch distance");
+// Per tile width (NT = n-tiles of 16 columns per wave; 4 waves along N):
+//   column sets of a wave: NA = NT - 2 tiles first, 2 tiles second; unit kinds 0 / 3 = A row halves (16 KiB),
+//   kind 1 = first column sets (NA x 8 KiB), kind 2 = second column sets (16 KiB)
+template <int NT> struct DgGeom {
+  static constexpr int NA = NT - 2;
+  static constexpr int BN = 64 * NT;
+  static constexpr int WCOLS = 16 * NT;                       // columns per wave
+  static constexpr int U1 = NA * 8192;                        // bytes of the kind-1 unit
+  static constexpr int KT = 3 * DG_UNIT + U1;                 // bytes of a K-tile in the ring (64 / 72 KiB)
+  static constexpr int RING = 2 * KT;
+  static constexpr int SRS = WCOLS * 2 + 16;                  // staged epilogue row stride (data + 16 B bank spread)
+  static constexpr int EPI_PASSES = NT == 4 ? 1 : 2;          // the staged tile must fit the LDS: 8 x (128 / passes) rows
+  static constexpr int EPI_ROWS = 128 / EPI_PASSES;
+  static constexpr int EPI = 8 * EPI_ROWS * SRS;
+  static constexpr int LDS = RING > EPI ? RING : EPI;
+  static constexpr int INFLIGHT = 2 * (DG_D - 2) + (NA - 2);  // DMA instructions of the D - 2 youngest units (one of each kind when D = 6)
+  static_assert(DG_D == 6 || NT == 4, "unequal units: the steady vmcnt assumes the 4 youngest units are one of each kind");
+  __host__ __device__ static constexpr int unit_off(int kind) { return kind == 0 ? 0 : kind == 1 ? DG_UNIT : kind == 2 ? DG_UNIT + U1 : 2 * DG_UNIT + U1; }
+  __host__ __device__ static constexpr int unit_instr(int kind) { return kind == 1 ? NA : 2; }
+};
 
 struct DgArgs {
   const bf16* A;      // [M, K], row stride lda
@@ -98,6 +124,10 @@ __device__ inline void dg_wait_vmcnt(int n) {      // n even, wave-uniform; anyt
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
     case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -160,12 +190,16 @@ __device__ inline void dg_wait_imm() {
   else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int MODE>
+template <int MODE, int NT>
 __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];   // DG_SLOTS x 16 KiB ring; re-used as 8 x 18 KiB epilogue tiles
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // two K-tiles of four units; re-used as 8 staged epilogue tiles
+  using GE = DgGeom<NT>;
+  constexpr int NA = GE::NA, DG_BN = GE::BN;
+  static_assert(NT == 4 || MODE == DG_PLAIN, "the fused tails exist for the 256-wide tile only");
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -245,9 +279,13 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const int am0 = m0, an0 = n0;
 #endif
   const unsigned voA = (unsigned)(((int64_t)(am0 + (r0 >> 6) * 128 + (r0 & 63)) * a.lda + dch * 8) * 2);
-  const unsigned voB = (unsigned)(((int64_t)(an0 + (r0 >> 5) * 64 + (r0 & 31)) * a.ldb + dch * 8) * 2);
+  // B: a wave's DMA rows of the first column sets are unit rows 8 NA wid + 8 j + drow (j < NA), of the second sets
+  // 16 wid + 8 j + drow; unit row blocks of 16 NA (32) rows belong to column wave wc = block index
+  const int rb1 = 8 * NA * wid + drow;                              // kind 1: unit row of instruction 0
+  const unsigned voB1 = (unsigned)(((int64_t)(an0 + (rb1 / (16 * NA)) * GE::WCOLS + (rb1 % (16 * NA))) * a.ldb + dch * 8) * 2);
+  const unsigned voB2 = (unsigned)(((int64_t)(an0 + (r0 >> 5) * GE::WCOLS + 16 * NA + (r0 & 31)) * a.ldb + dch * 8) * 2);
   const int rowA8 = (int)(a.lda * 16), rowB8 = (int)(a.ldb * 16);   // +8 rows, bytes
-  const int halfA = (int)(a.lda * 128), halfB = (int)(a.ldb * 64);  // +64 rows of A, +32 rows of B, bytes
+  const int halfA = (int)(a.lda * 128);                             // +64 rows of A, bytes
   const int kbase = kt_begin * (DG_BK * 2);
 
   int u_issue = 0;                      // next unit to issue
@@ -255,17 +293,26 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   auto issue_unit = [&](auto kind_c) {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr bool isA = KIND == 0 || KIND == 3;
-    constexpr bool second = KIND >= 2;
-    char* dst = lds + (u_issue % DG_SLOTS) * DG_UNIT + wid * 2048;
-    const int so = kbase + (u_issue >> 2) * (DG_BK * 2) + (second ? (isA ? halfA : halfB) : 0);
+    char* dst = lds + ((u_issue >> 2) & 1) * GE::KT + GE::unit_off(KIND) + wid * (GE::unit_instr(KIND) * 1024);
+    const int so = kbase + (u_issue >> 2) * (DG_BK * 2) + (KIND == 3 ? halfA : 0);
     if constexpr (isA) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA, so, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voA, so + rowA8, 0, 0);
+    } else if constexpr (KIND == 1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, voB1, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voB1, so + rowB8, 0, 0);
+      if constexpr (NA == 3)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst + 2048), 16, voB1, so + 2 * rowB8, 0, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, voB, so, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voB, so + rowB8, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, voB2, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voB2, so + rowB8, 0, 0);
     }
     ++u_issue;
+  };
+  // DMA instructions of this wave that belong to the `n` youngest issued units (kind-1 units count NA, the others 2)
+  auto young_instr = [&](int n) {
+    const int k1 = ((u_issue + 2) >> 2) - ((u_issue - n + 2) >> 2);   // units u in [u_issue - n, u_issue) with u % 4 == 1
+    return 2 * n + (NA - 2) * k1;
   };
 #define DG_IC(v) std::integral_constant<int, v>()
 
@@ -274,25 +321,30 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const int rdo0 = fr * 128 + ((kg ^ sw) << 4);
   const int rdo1 = fr * 128 + (((4 + kg) ^ sw) << 4);
   const int a_row0 = wr * 64;          // unit rows of this wave inside units 0 / 3
-  const int b_row0 = wc * 32;          // inside units 1 / 2
 
   bf16x8 Af[1 + DG_BALANCED][2][4];    // [row half (one set unless DG_BALANCED)][kstep][m-tile]
-  bf16x8 Bf[2][2][2];                  // [n-half][kstep][n-tile]
-  f32x4 acc[2][2][4][2];               // [m-half][n-half][m-tile][n-tile]
+  bf16x8 Bf0[2][NA], Bf1[2][2];        // first / second column set: [kstep][n-tile]
+  f32x4 acc0[2][4][NA], acc1[2][4][2]; // first / second column set: [m-half][m-tile][n-tile]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int p = 0; p < 4; ++p) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int q = 0; q < NA; ++q) acc0[i][p][q] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) acc[i][j][p][q] = f32x4{0, 0, 0, 0};
+      for (int q = 0; q < 2; ++q) acc1[i][p][q] = f32x4{0, 0, 0, 0};
+    }
+  // row tiles (mh * 4 + mi) of this wave with rows below M: the MFMAs of a row half without real rows are skipped (the
+  // 64-row last panel of M = 16 448 keeps one half of one wave row busy - its tiles cost a third of a full one)
+  int rt_hi = (a.M - m0 - wr * 128 + 15) >> 4;
+  rt_hi = rt_hi < 0 ? 0 : (rt_hi > 8 ? 8 : rt_hi);
+  const int live_mask = __builtin_amdgcn_readfirstlane((rt_hi > 0 ? 1 : 0) | (rt_hi > 4 ? 2 : 0));   // scalar: s_bitcmp + s_cbranch
 
   auto readA = [&](int mh, int unit) {
 #if DG_ABL & 2
     if (unit > 3) return;
 #endif
-    const char* base = lds + (unit % DG_SLOTS) * DG_UNIT + a_row0 * 128;
+    const char* base = lds + ((unit >> 2) & 1) * GE::KT + GE::unit_off(mh ? 3 : 0) + a_row0 * 128;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       Af[mh * DG_BALANCED][0][mi] = *(const bf16x8*)(base + mi * 2048 + rdo0);
@@ -303,11 +355,20 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #if DG_ABL & 2
     if (unit > 3) return;
 #endif
-    const char* base = lds + (unit % DG_SLOTS) * DG_UNIT + b_row0 * 128;
+    if (nh == 0) {
+      const char* base = lds + ((unit >> 2) & 1) * GE::KT + GE::unit_off(1) + wc * (16 * NA) * 128;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      Bf[nh][0][ni] = *(const bf16x8*)(base + ni * 2048 + rdo0);
-      Bf[nh][1][ni] = *(const bf16x8*)(base + ni * 2048 + rdo1);
+      for (int ni = 0; ni < NA; ++ni) {
+        Bf0[0][ni] = *(const bf16x8*)(base + ni * 2048 + rdo0);
+        Bf0[1][ni] = *(const bf16x8*)(base + ni * 2048 + rdo1);
+      }
+    } else {
+      const char* base = lds + ((unit >> 2) & 1) * GE::KT + GE::unit_off(2) + wc * 32 * 128;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        Bf1[0][ni] = *(const bf16x8*)(base + ni * 2048 + rdo0);
+        Bf1[1][ni] = *(const bf16x8*)(base + ni * 2048 + rdo1);
+      }
     }
   };
   // 16 MFMAs of one quadrant; the DMA of the next unit is issued from inside the block (the matrix pipe is busy for 16
@@ -321,14 +382,21 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #if DG_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
+    if (live_mask & (mh ? 2 : 1)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi) {
+        if (nh == 0) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mh][nh][mi][ni] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[nh][ks][ni], Af[mh * DG_BALANCED][ks][mi], acc[mh][nh][mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NA; ++ni)
+            acc0[mh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf0[ks][ni], Af[mh * DG_BALANCED][ks][mi], acc0[mh][mi][ni], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc1[mh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf1[ks][ni], Af[mh * DG_BALANCED][ks][mi], acc1[mh][mi][ni], 0, 0, 0);
+        }
+      }
 #if DG_DMA_IN_MMA
       if (ks == 0) {
         __builtin_amdgcn_sched_barrier(0);
@@ -336,6 +404,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
+    }
     }
 #if DG_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
@@ -358,8 +427,8 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     int need = g + 2;
     need = need < nunits - 1 ? need : nunits - 1;
     const int ok = (u_issue - 1) - need;
-    if (ok == DG_D - 2) dg_wait_imm<2 * (DG_D - 2)>();       // steady state: one compare
-    else dg_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+    if (ok == DG_D - 2) dg_wait_imm<GE::INFLIGHT>();         // steady state: one compare
+    else dg_wait_vmcnt(ok > 0 ? young_instr(ok) : 0);
   };
 
   // ---- prologue: the whole ring in flight
@@ -372,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     // row half" units are read in phase 3 of the previous K-tile): with the ring completely in flight (D = slots) the
     // slot of unit v is refilled in M_v, which is only safe because every unit is read in a phase < v.
     const int ok = (u_issue - 1) - 1;
-    dg_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+    dg_wait_vmcnt(ok > 0 ? young_instr(ok) : 0);
 #if DG_BALANCED
     __builtin_amdgcn_s_barrier();
     readA(0, 0);
@@ -398,7 +467,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #if DG_ABL & 5   // bit 2: DMA is issued but never waited for (timing-only: separates issue cost from memory waits)
       return;
 #endif
-      if constexpr (STEADY) dg_wait_imm<2 * (DG_D - 2)>();
+      if constexpr (STEADY) dg_wait_imm<GE::INFLIGHT>();
       else wait_landed();
     };
 #if DG_PRIO == 2    // the R interval (DMA issue + LDS reads) is the long one: give IT the issue priority
@@ -491,21 +560,19 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   // with the parts at the front of the grid: the wait replaces the reducer's reads, the fences and the 53 MB stay; and
   // it would forbid two of these GEMMs on two streams.)
   const int rt_lo = 0;
-  int rt_hi = (a.M - m0 - wr * 128 + 15) >> 4;           // row tiles (mh * 4 + mi) of this wave with rows below M
-  rt_hi = rt_hi < 0 ? 0 : (rt_hi > 8 ? 8 : rt_hi);
+  // accumulator tile (mh, mi, n-tile j of the wave's NT) as ONE indexable thing for the slab / epilogue code
+  auto ACC = [&](int mh, int mi, int j) -> f32x4& { return j < NA ? acc0[mh][mi][j] : acc1[mh][mi][j - NA]; };
   if (rem_idx >= 0 && a.split > 1) {
     float* slab = a.slabs + ((int64_t)rem_idx * a.split + part) * (DG_BM * DG_BN);
     // slab layout: [wave][acc register index][lane] float4 -> fully coalesced 16-byte stores and loads
-    f32x4* sw4 = (f32x4*)slab + (int64_t)wid * 32 * 64 + lane;
+    f32x4* sw4 = (f32x4*)slab + (int64_t)wid * (8 * NT) * 64 + lane;
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         if (mh * 4 + mi >= rt_hi) continue;
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) sw4[(((mh * 2 + nh) * 4 + mi) * 2 + ni) * 64] = acc[mh][nh][mi][ni];
+        for (int j = 0; j < NT; ++j) sw4[((mh * 4 + mi) * NT + j) * 64] = ACC(mh, mi, j);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -533,33 +600,66 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     // slab): the result does not depend on the arrival order, so identical launches give identical bits
     for (int p = 0; p < a.split; ++p) {
       const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)rem_idx * a.split + p) * (DG_BM * DG_BN)) +
-                        (int64_t)wid * 32 * 64 + lane;
+                        (int64_t)wid * (8 * NT) * 64 + lane;
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           if (mh * 4 + mi >= rt_hi) continue;
 #pragma unroll
-          for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              const f32x4 o = o4[(((mh * 2 + nh) * 4 + mi) * 2 + ni) * 64];
-              acc[mh][nh][mi][ni] = p == 0 ? o : acc[mh][nh][mi][ni] + o;
-            }
+          for (int j = 0; j < NT; ++j) {
+            const f32x4 o = o4[((mh * 4 + mi) * NT + j) * 64];
+            ACC(mh, mi, j) = p == 0 ? o : ACC(mh, mi, j) + o;
+          }
         }
     }
   }
 
-  // ---- epilogue.  Each wave stages its 128 x 64 block (+ bias, rounded to bf16) in its own LDS tile in the MFMA layout
+  // ---- epilogue.  Each wave stages its 128 x 16 NT block (+ bias, rounded to bf16) in its own LDS tile in the MFMA layout
   // (lane (fr, kg) of tile (m-tile, n-tile): token row fr, output columns 4 kg .. 4 kg + 3) and reads it back row-wise:
-  // a global instruction then moves 8 rows x 128 contiguous bytes (16 B per lane) instead of 16 rows x 32 bytes.
-  constexpr int SRS = 144;                   // staged row stride: 128 B of data + 16 B (bank spread of the 8-byte writes)
+  // a global instruction then moves whole row pieces (16 B per lane) instead of 16 rows x 32 bytes.
+  if constexpr (NT != 4) {
+    // 320-wide tile, plain epilogue: two passes of 64 rows (the staged 128 x 80 blocks of 8 waves exceed the LDS);
+    // read-back: a row piece is 160 B = 10 chunks, an instruction moves 6 rows (lanes 60..63 idle)
+    constexpr int SRS = GE::SRS;
+    char* const stg = lds + wid * (GE::EPI_ROWS * SRS);
+    const int er = lane / 10, ech = lane - er * 10;
+    const int n = n0 + wc * GE::WCOLS + ech * 8;
+    const bool nok = n < a.N && lane < 60;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      if (mh * 4 >= rt_hi) break;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nl = j * 16 + kg * 4;
+        const int nb = n0 + wc * GE::WCOLS + nl;
+        f32x4 bv = {0, 0, 0, 0};
+        if (a.bias && nb < a.N) bv = *(const f32x4*)(a.bias + nb);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          if (mh * 4 + mi >= rt_hi) continue;
+          const f32x4 v = ACC(mh, mi, j) + bv;
+          const bf16x4 cb = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4*)(stg + (mi * 16 + fr) * SRS + nl * 2) = cb;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS operations complete in order; the tile is private
+#pragma unroll
+      for (int it = 0; it < 11; ++it) {
+        const int row = it * 6 + er;
+        const int m = m0 + wr * 128 + mh * 64 + row;
+        if (row >= 64 || m >= a.M || !nok || mh * 4 + (row >> 4) >= rt_hi) continue;
+        const u32x4 raw = *(const u32x4*)(stg + row * SRS + ech * 16);
+        *(u32x4*)(a.C + (int64_t)m * a.ldc + n) = raw;
+      }
+      // the next pass re-uses the staging tile: its ds_writes follow these ds_reads in program order (in-order LDS)
+    }
+  } else {
+  constexpr int SRS = GE::SRS;               // staged row stride: 128 B of data + 16 B (bank spread of the 8-byte writes)
   char* const stg = lds + wid * (128 * SRS);
 #pragma unroll
-  for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int nl = nh * 32 + ni * 16 + kg * 4;
+  for (int j = 0; j < NT; ++j) {
+      const int nl = j * 16 + kg * 4;
       const int n = n0 + wc * 64 + nl;
       f32x4 bv = {0, 0, 0, 0};
       if (a.bias && n < a.N) bv = *(const f32x4*)(a.bias + n);
@@ -568,7 +668,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           if (mh * 4 + mi < rt_lo || mh * 4 + mi >= rt_hi) continue;
-          const f32x4 v = acc[mh][nh][mi][ni] + bv;
+          const f32x4 v = ACC(mh, mi, j) + bv;
           const bf16x4 cb = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
           *(bf16x4*)(stg + (mh * 64 + mi * 16 + fr) * SRS + nl * 2) = cb;
         }
@@ -657,6 +757,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
       *(f32x4*)(base + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
     }
   }
+  }   // NT == 4
 #ifdef DG_TRACE2
   DGT2(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -667,19 +768,25 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // Schedule: `full` tiles get one workgroup each; the remaining r = tiles - full tiles (the partial last round on the
 // `cus` workgroup slots) are split along K over `split` workgroups each, so the last round also fills the chip.
-struct DgPlan { int tiles_m, tiles_n, full, rem, split, tail_pad, grid; };
+struct DgPlan { int nt, tiles_m, tiles_n, full, rem, split, tail_pad, grid; double cost; };
 
-inline DgPlan dense_plan(int M, int N, int K, int cus) {
+// `cost` = launch length in units of one K-tile of the 256-wide tile (a model, used only to choose the tile width):
+// whole rounds of full tiles + the split parts in front of the grid.
+inline DgPlan dense_plan_nt(int M, int N, int K, int cus, int nt, int force_split = 0, bool front_unsplit = false) {
   DgPlan p;
+  const int bn = 64 * nt;
+  const double wf = nt / 4.0;                              // K-tile cost and slab size relative to the 256-wide tile
+  p.nt = nt;
   p.tiles_m = (M + DG_BM - 1) / DG_BM;
-  p.tiles_n = (N + DG_BN - 1) / DG_BN;
+  p.tiles_n = (N + bn - 1) / bn;
   const int tiles = p.tiles_m * p.tiles_n;
   const int rounds = tiles / cus;
+  const int nkt = K / DG_BK;
   p.full = rounds * cus;
   p.rem = tiles - p.full;
   p.split = 1;
+  double f = 1.0;                                          // share of real rows in the remaining tiles
   if (p.rem > 0) {
-    const int nkt = K / DG_BK;
     int s = cus / p.rem;                                   // workgroup slots per remaining tile
     const int smax = nkt / 4 > 0 ? nkt / 4 : 1;            // keep >= 4 K-tiles per part
     s = s < 1 ? 1 : (s > smax ? smax : s);
@@ -689,7 +796,7 @@ inline DgPlan dense_plan(int M, int N, int K, int cus) {
     // ... and so is a short K: a split tile pays the slab round trip (f32 partial out, `s` partials back through the
     // reducer's CU: ~26 us = 17 K-tiles of this kernel for a tile of 256 real rows, tools/dense_phases.py), in proportion
     // to the rows that exist (the tail of M = 16 448 is mostly the 64-row last panel).  Split only if K/s + that < K.
-    if (s > 1) {
+    {
       int64_t rows = 0;
       for (int tile = p.full; tile < tiles; ++tile) {
         const int G = 8, per_group = G * p.tiles_n, gidx = tile / per_group, first_m = gidx * G;
@@ -698,18 +805,47 @@ inline DgPlan dense_plan(int M, int N, int K, int cus) {
         const int left = M - tm * DG_BM;
         rows += left < DG_BM ? left : DG_BM;
       }
-      const double f = (double)rows / ((double)p.rem * DG_BM);
-      if ((double)nkt / s + 17.0 * f + 1.0 >= (double)nkt) s = 1;
+      f = (double)rows / ((double)p.rem * DG_BM);
     }
+    if (s > 1 && (double)nkt / s + 17.0 * f * wf + 1.0 >= (double)nkt) s = 1;
+    if (force_split > 0) s = force_split > smax ? smax : force_split;
     p.split = s;
-    if (s == 1) {            // an unsplit tail is just more full tiles
+    // an unsplit tail is just more full tiles - unless it is a thin (mostly empty) panel: those tiles are short and stay
+    // in FRONT of the grid, where they run beside the first round instead of after it
+    if (s == 1 && !(front_unsplit && f < 0.5 && rounds >= 1)) {
       p.full = tiles;
       p.rem = 0;
     }
   }
   p.tail_pad = (p.rem * p.split + 7) & ~7;
   p.grid = p.tail_pad + p.full;
+  const double tile_cost = nkt * wf + 3.0;                 // + prologue / epilogue / launch gap (~5 us)
+  p.cost = (double)((p.full + cus - 1) / cus) * tile_cost;
+  if (p.rem > 0) {
+    // rows that do not exist cost no MFMAs (row halves without real rows are skipped): a part of a mostly empty tile
+    // is bounded by its DMA / barrier skeleton, about half a full K-tile
+    const double kt = (f < 0.5 ? 0.5 : 1.0) * wf;
+    p.cost += (double)nkt / p.split * kt + 17.0 * f * wf + 3.0;
+  }
   return p;
+}
+
+// The workspace of one (M, N, K) is shared by every mode and tile width of that problem: the ticket words (zero between
+// launches: the last arriver re-arms its ticket) live in a region of FIXED size in front of the slabs, so no plan's slabs
+// can land on another plan's tickets.
+constexpr int DG_TICKET_BYTES = 8192;
+
+static int g_dense_force_nt = 0;
+static int g_dense_force_split = 0;   // developer switch (octic_dbg_dense_split): 0 = plan's choice, n = split of the remaining tiles (1 = unsplit, kept in front)      // developer switch (octic_dbg_dense_tile): 0 = choose by the cost model, 4 / 5 = force
+
+// The 320-wide tile serves plain-epilogue problems whose N is a multiple of 320 when the model says its launch is shorter
+// (ViT-H: N = 1280 - one round of 256 tiles instead of 1.27 rounds of 325).
+inline DgPlan dense_plan(int M, int N, int K, int cus, int mode) {
+  const DgPlan p4 = dense_plan_nt(M, N, K, cus, 4, g_dense_force_split, g_dense_force_split == 1);
+  if (mode != DG_PLAIN || (N % 320) != 0 || g_dense_force_nt == 4) return p4;
+  const DgPlan p5 = dense_plan_nt(M, N, K, cus, 5, g_dense_force_split, g_dense_force_split == 1);
+  if (g_dense_force_nt == 5) return p5;
+  return p5.cost < p4.cost ? p5 : p4;
 }
 
 }  // namespace octic
@@ -722,11 +858,23 @@ extern "C" {
 // slots than the device has); 256 when no device is visible (host-only callers sizing a workspace)
 static int dense_cus() { return device_cus(); }
 
+// enough for either tile width (the plain mode may pick the 320-wide tile, the fused tails use the 256-wide one)
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K) {
-  const DgPlan p = dense_plan(M, N, K, dense_cus());
-  if (p.split <= 1) return 256;
-  return (int64_t)p.rem * p.split * DG_BM * DG_BN * 4 + (int64_t)p.rem * 4 + 256;
+  int64_t need = 256;
+  for (int nt = 4; nt <= 5; ++nt) {
+    if (nt == 5 && (N % 320) != 0) continue;
+    DgPlan p = dense_plan_nt(M, N, K, dense_cus(), nt);
+    if (g_dense_force_split > 1) p = dense_plan_nt(M, N, K, dense_cus(), nt, 8);     // developer switch: room for any split
+    if (p.split <= 1) continue;
+    const int64_t b = (int64_t)p.rem * p.split * DG_BM * (64 * nt) * 4 + DG_TICKET_BYTES + 256;
+    need = b > need ? b : need;
+  }
+  return need;
 }
+
+// developer switch: force the tile width of the plain mode (0 = cost model, 4 = 256-wide, 5 = 320-wide where N % 320 == 0)
+void octic_dbg_dense_tile(int nt) { g_dense_force_nt = (nt == 4 || nt == 5) ? nt : 0; }
+void octic_dbg_dense_split(int s) { g_dense_force_split = s > 0 ? s : 0; }
 
 int octic_dense_gemm_colsum_rows(int M, int N, int K) {
   (void)N; (void)K;
@@ -751,28 +899,33 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.lda = lda; a.ldb = ldb; a.M = M; a.N = N; a.K = K;
   a.C = (bf16*)C; a.C2 = (bf16*)C2; a.ldc = ldc; a.bias = bias; a.gamma = gamma; a.rs = rs; a.rps = rs ? rps : 1;
   a.X = X; a.OUT = OUT; a.H = (const bf16*)H; a.colsum = mode == DG_DGELU ? colsum : nullptr;
-  const DgPlan p = dense_plan(M, N, K, dense_cus());
+  const DgPlan p = dense_plan(M, N, K, dense_cus(), mode);
   a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.full_tiles = p.full; a.split = p.split; a.tail_pad = p.tail_pad;
   hipStream_t s = (hipStream_t)stream;
   if (p.split > 1) {
     if (!workspace) return OCTIC_ENULL;
+    if (p.rem * 4 > DG_TICKET_BYTES) return OCTIC_ESHAPE;
     a.tickets = (int*)workspace;
-    a.slabs = (float*)((char*)workspace + (((int64_t)p.rem * 4 + 255) & ~(int64_t)255));
+    a.slabs = (float*)((char*)workspace + DG_TICKET_BYTES);
   }
-  const int smem = DG_LDS;
+  const int smem = DgGeom<4>::LDS, smem5 = DgGeom<5>::LDS;
   static DeviceOnce once;
   if (once.first()) {
-    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_PLAIN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_PLAIN, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem5);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_DGELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipGetLastError();
   }
   switch (mode) {
-    case DG_PLAIN: dense_nt_kernel<DG_PLAIN><<<p.grid, 512, smem, s>>>(a); break;
-    case DG_GELU: dense_nt_kernel<DG_GELU><<<p.grid, 512, smem, s>>>(a); break;
-    case DG_RESID: dense_nt_kernel<DG_RESID><<<p.grid, 512, smem, s>>>(a); break;
-    case DG_DGELU: dense_nt_kernel<DG_DGELU><<<p.grid, 512, smem, s>>>(a); break;
+    case DG_PLAIN:
+      if (p.nt == 5) dense_nt_kernel<DG_PLAIN, 5><<<p.grid, 512, smem5, s>>>(a);
+      else dense_nt_kernel<DG_PLAIN, 4><<<p.grid, 512, smem, s>>>(a);
+      break;
+    case DG_GELU: dense_nt_kernel<DG_GELU, 4><<<p.grid, 512, smem, s>>>(a); break;
+    case DG_RESID: dense_nt_kernel<DG_RESID, 4><<<p.grid, 512, smem, s>>>(a); break;
+    case DG_DGELU: dense_nt_kernel<DG_DGELU, 4><<<p.grid, 512, smem, s>>>(a); break;
     default: return OCTIC_ESHAPE;
   }
   return launch_status();

@@ -56,6 +56,71 @@ def test_dense_nt_integer_operands_bit_exact(M, N, K):
     assert torch.equal(c, want), f"{int((c != want).sum())} wrong elements"
 
 
+def _force_tile(nt):
+    """developer switch of csrc/dense_gemm.hip: tile width of the plain mode (0 = cost model, 4 = 256-wide, 5 = 320-wide)"""
+    import ctypes
+    from octic_vits_amd import _lib
+    _lib.lib()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.octic_dbg_dense_tile.argtypes = [ctypes.c_int]
+    raw.octic_dbg_dense_tile.restype = None
+    raw.octic_dbg_dense_tile(nt)
+
+
+# round 4: the 256 x 320 tile (one round of workgroups for the N = 1280 problems).  Shapes with N % 320 == 0: ViT-H's four
+# N = 1280 uses, ragged M (1 .. 255 rows in the last panel, a panel of exactly 64 rows, fewer rows than one wave row),
+# short K (ring never steady), more tiles than CUs (several rounds), a K-split tail that is not the 64-row panel
+W320 = [(16448, 1280, 1280), (16448, 1280, 5120), (300, 320, 256), (77, 640, 128), (1000, 960, 384), (4112, 1280, 1024),
+        (513, 320, 192), (66000, 1280, 256), (16448, 3840, 1280)]
+
+
+@pytest.mark.parametrize("M,N,K", W320)
+def test_dense_nt_320_wide_tile_integer_exact_and_equal_to_the_256_wide_tile(M, N, K):
+    """Both tile widths forced in turn on the same operands.  Integer-valued operands make every product and partial sum
+    exact: any dropped / doubled K-slice, swapped column set or mis-addressed DMA row of the 3 + 2 n-tile layout is a wrong
+    integer.  On random operands the two widths differ only where the split-K tail sums slabs in another grouping, so they
+    are held to the bf16 output tolerance against fp64 and to 2 ulp of each other."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = torch.randint(-3, 4, (M, K), generator=g, device=DEV).to(torch.bfloat16)
+    b = torch.randint(-2, 3, (N, K), generator=g, device=DEV).to(torch.bfloat16)
+    bias = torch.randint(-4, 5, (N,), generator=g, device=DEV).float()
+    want = (a.float() @ b.float().t() + bias).to(torch.bfloat16)
+    try:
+        for nt in (5, 4):
+            _force_tile(nt)
+            c = o.dense_gemm_nt(a, b, 0, bias=bias)
+            assert torch.equal(c, want), f"tile {nt}: {int((c != want).sum())} wrong elements of {c.numel()}"
+        ar, br = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+        ref = ar.double() @ br.double().t()
+        outs = []
+        for nt in (5, 4):
+            _force_tile(nt)
+            c = o.dense_gemm_nt(ar, br, 0)
+            close(c, ref, 1e-2, f"tile {nt} {M}x{N}x{K}")
+            outs.append(c.float())
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((outs[0] - outs[1]).abs().max()) <= 2 ** -6 * scale
+    finally:
+        _force_tile(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(16448, 1280, 1280), (16448, 1280, 5120), (66000, 1280, 256)])
+def test_dense_nt_320_wide_tile_is_bitwise_repeatable(M, N, K):
+    """The 64-row last panel goes through the split-K front of the grid (f32 slabs, ticket, last arriver sums in slab
+    order): identical launches give identical bits, also right after a launch of another shape used the workspace."""
+    o = ops()
+    a, b = rnd((M, K), 3), rnd((N, K), 4, K ** -0.5)
+    try:
+        _force_tile(5)
+        first = o.dense_gemm_nt(a, b, 0)
+        o.dense_gemm_nt(rnd((3000, 1280), 5), rnd((1280, 1280), 6), 0)
+        for _ in range(3):
+            assert torch.equal(o.dense_gemm_nt(a, b, 0), first)
+    finally:
+        _force_tile(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 264, 256), (16448, 5120, 1280)])
 def test_dense_nt_gelu(M, N, K):
     o = ops()
