@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liboctic_hip.so")
-SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_wreg.hip", "wgrad.hip", "lamb.hip", "attention.hip", "attn80.hip", "dense.hip", "dense_gemm.hip", "dense_wgrad.hip"]
+SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_wreg.hip", "wgrad.hip", "lamb.hip", "attention.hip", "attn80.hip", "attn80_bwd.hip", "dense.hip", "dense_gemm.hip", "dense_wgrad.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
@@ -24,7 +24,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
-    headers = [os.path.join(CSRC, "octic_common.hpp"), os.path.join(CSRC, "attn_common.hpp"), os.path.join(CSRC, "gemm_args.hpp"),
+    headers = [os.path.join(CSRC, "octic_common.hpp"), os.path.join(CSRC, "attn_common.hpp"), os.path.join(CSRC, "attn80_common.hpp"), os.path.join(CSRC, "gemm_args.hpp"),
                os.path.join(HERE, "..", "include", "octic_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:

@@ -1100,6 +1100,8 @@ template <int KS, int DT>
 static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream_t s) {
   // dkv (two accumulator sets) needs the 256-register budget of the eight-wave split (105 vs 156 us with spills);
   // dq runs the same either way (~106 us) and follows it
+  // both gradients asked for at once: the single-pass kernel (csrc/attn80_bwd.hip) where its shape applies
+  if (phase == 3 && KS == 5 && !g_attn_legacy && attn80_bwd_ok(a)) return attn80_bwd_launch(a, B, s);
   const int nt = (a.T + 31) / 32, W = attn_waves(nt), Wq = W;
   // the row images are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16); rows are padded so the
   // b128 reads are conflict-free, the transposed reads then see at most 2-way conflicts.  The tr fragments reach

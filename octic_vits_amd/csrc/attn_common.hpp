@@ -193,5 +193,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[DT]) {
 // csrc/attn80.hip: persistent head_dim-80 kernels (all operands by LDS-DMA, one head ahead)
 int attn80_fwd_ok(const AttnArgs& a);
 int attn80_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s);
+// csrc/attn80_bwd.hip: single-pass backward (dq, dk, dv from ONE recomputation of P) for head_dim 80, T = 257
+int attn80_bwd_ok(const AttnBwdArgs& a);
+int attn80_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s);
 
 }  // namespace octic

@@ -420,6 +420,18 @@ def attn_supported(T, hd, dtype):
     return 2 * tp * (cols * 2 + 16) + 2 * tp * 4 <= 160 * 1024
 
 
+# Single-pass attention backward (csrc/attn80_bwd.hip: P and dS computed once, 10 T^2 hd FLOP) for head_dim 80, T = 257;
+# False = the dq + dkv pair (14 T^2 hd) for every shape (bench --no-fused-attn-bwd)
+ATTN_BWD_FUSED = True
+
+
+def _attn_bwd_phases(T, hd):
+    """(phase, timer name, algorithmic bytes per element of q, flops per B H T^2 hd) of the backward launches."""
+    if ATTN_BWD_FUSED and hd == 80 and T == 257:
+        return ((3, "attn_bwd_kernel", 8, 10.0),)         # reads q k v o dO, writes dq dk dv
+    return ((1, "attn_bwd_dq_kernel", 6, 6.0), (2, "attn_bwd_dkv_kernel", 6, 8.0))
+
+
 def attn_bwd(q, k, v, o, dout, lse, scale, dq, dk, dv):
     """All tensors are [B,H,T,hd] views; q/k/v share strides, o/dout share strides, dq/dk/dv share strides."""
     B, H, T, hd = q.shape
@@ -427,7 +439,7 @@ def attn_bwd(q, k, v, o, dout, lse, scale, dq, dk, dv):
     if k.stride() != st or v.stride() != st or dout.stride() != so or dk.stride() != sg or dv.stride() != sg:
         raise ValueError("attn_bwd: stride sets differ")
     delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
-    for phase, name, nbytes, flops in ((1, "attn_bwd_dq_kernel", 6, 6.0), (2, "attn_bwd_dkv_kernel", 6, 8.0)):
+    for phase, name, nbytes, flops in _attn_bwd_phases(T, hd):
         t = KERNEL_TIMER.start()
         check(lib().octic_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H,
                                    T, hd, st[0], st[1], st[2], so[0], so[1], so[2], sg[0], sg[1], sg[2], float(scale),
@@ -457,7 +469,7 @@ def attn_bwd_packed(qkv, o, dout, lse, H, c, scale):
     B, T = qkv.shape[0], qkv.shape[1]
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
-    for phase, name, nbytes, flops in ((1, "attn_bwd_dq_kernel", 6, 6.0), (2, "attn_bwd_dkv_kernel", 6, 8.0)):
+    for phase, name, nbytes, flops in _attn_bwd_phases(T, 80):
         t = KERNEL_TIMER.start()
         check(lib().octic_attn_bwd_packed(_p(qkv), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, H, T, c, qkv.stride(1),
                                           o.stride(1), dqkv.stride(1), float(scale), phase, _stream(qkv)))

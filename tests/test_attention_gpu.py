@@ -148,3 +148,73 @@ def test_packed_attention_matches_fp64_reference():
         err = (got - want).abs().max().item()
         assert err <= 2e-2 * want.abs().max().item(), (name, err)
         assert ((got - want).norm() / want.norm()).item() < 1e-2, name
+
+
+def _bwd_raw(q, k, v, o, do, lse, scale, fused):
+    from octic_vits_amd import ops
+    dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+    old = ops.ATTN_BWD_FUSED
+    ops.ATTN_BWD_FUSED = fused
+    try:
+        ops.attn_bwd(q, k, v, o, do, lse, scale, dq, dk, dv)
+    finally:
+        ops.ATTN_BWD_FUSED = old
+    return dq, dk, dv
+
+
+@pytest.mark.parametrize("B,H", [(2, 3), (5, 16)])
+def test_single_pass_backward_matches_fp64_and_the_two_kernel_path(B, H):
+    """csrc/attn80_bwd.hip (round 4: P and dS once per tile pair, dQ as a fixed-order sum of eight per-wave partials,
+    key 256 on the vector unit) against (a) float64 autograd of softmax attention on the same bf16 inputs - 3e-2 of the
+    gradient scale, the bound of the two-kernel path - with the error of every gradient ALSO required to be no worse than
+    1.5 x the two-kernel path's own error; (b) bitwise repeatability; (c) the rows that take special paths: token 256 as
+    key (dk / dv row 256) and as query (dq row 256) are checked separately at the same tolerance."""
+    from octic_vits_amd import ops
+    T, hd = 257, 80
+    g = torch.Generator().manual_seed(31 + B)
+    q, k, v = (torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    do = torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda()
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, scale)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ro = torch.softmax((qd @ kd.transpose(-1, -2)) * scale, dim=-1) @ vd
+    ro.backward(do.double())
+    fused = _bwd_raw(q, k, v, o, do, lse, scale, True)
+    pair = _bwd_raw(q, k, v, o, do, lse, scale, False)
+    again = _bwd_raw(q, k, v, o, do, lse, scale, True)
+    for name, f, p, a, want in zip(("dq", "dk", "dv"), fused, pair, again, (qd.grad, kd.grad, vd.grad)):
+        assert torch.equal(f, a), f"{name}: two launches differ"
+        sc = max(1.0, float(want.abs().max()))
+        ef, ep = float((f.double() - want).abs().max()), float((p.double() - want).abs().max())
+        assert ef <= 3e-2 * sc, f"{name}: max err {ef:.3e} (scale {sc:.3g})"
+        assert ef <= 1.5 * ep + 1e-3 * sc, f"{name}: single-pass err {ef:.3e} vs two-kernel {ep:.3e}"
+        e256 = float((f.double()[:, :, 256] - want[:, :, 256]).abs().max())
+        assert e256 <= 3e-2 * sc, f"{name}[256]: {e256:.3e}"
+        rel = float((f.double() - want).norm() / want.norm())
+        assert rel < 1.2e-2, (name, rel)
+
+
+def test_single_pass_backward_on_strided_fused_qkv_rows_and_spiky_scores():
+    """The standard half's layout (q, k, v = strided views of one [B,T,3,H,hd] tensor; gradients into one tensor of the same
+    layout) and scores with a wide range (|x| up to ~25 after scaling): exp2(x - lse) spans the whole bf16 range of P."""
+    from octic_vits_amd import ops
+    B, H, T, hd = 3, 16, 257, 80
+    g = torch.Generator().manual_seed(77)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g)
+    qkv[:, :, 0] *= 3.0
+    qkv[:, :, 1] *= 3.0
+    qkv = qkv.to(torch.bfloat16).cuda()
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    do = torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda()
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, scale)
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ops.attn_bwd(q, k, v, o, do, lse, scale, dq, dk, dv)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ro = torch.softmax((qd @ kd.transpose(-1, -2)) * scale, dim=-1) @ vd
+    ro.backward(do.double())
+    for name, got, want in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        sc = max(1.0, float(want.abs().max()))
+        err = float((got.double() - want).abs().max())
+        assert err <= 3e-2 * sc, f"{name}: max err {err:.3e} (scale {sc:.3g})"

@@ -27,4 +27,9 @@ qkv = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16().requires_gr
 dop = torch.randn(B, T, 8 * c, device="cuda").bfloat16()
 op = OF.AttnPackedFn.apply(qkv, H, c, hd ** -0.5)
 t_packed = timeit(lambda: torch.autograd.grad(op, qkv, dop, retain_graph=True))
-print(f"attn bwd (dq + dkv): plain {t_plain:6.1f} us   packed {t_packed:6.1f} us")
+print(f"attn bwd single pass: plain {t_plain:6.1f} us   packed {t_packed:6.1f} us")
+from octic_vits_amd import ops
+ops.ATTN_BWD_FUSED = False
+t_plain2 = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True))
+t_packed2 = timeit(lambda: torch.autograd.grad(op, qkv, dop, retain_graph=True))
+print(f"attn bwd (dq + dkv): plain {t_plain2:6.1f} us   packed {t_packed2:6.1f} us")
