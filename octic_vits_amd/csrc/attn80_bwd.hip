@@ -9,31 +9,30 @@
 //   * one workgroup (8 waves) per (batch, head); wave w OWNS key tile w (keys 32 w .. 32 w + 31): its K and V rows sit in
 //     registers as B operands (key on the lane) for the whole head, its dK^T and dV^T accumulate lane-locally
 //     (2 x 48 registers) - no cross-wave reduction for dK / dV;
-//   * the query side STREAMS: Q and dO arrive tile by tile (32 queries) through a two-stage LDS ring filled by LDS-DMA
-//     (a80 tile format: the same swizzled 5 KiB images as the forward), tile t + 1 in flight while tile t is multiplied;
-//     there is no whole-head staging prologue;
-//   * per query tile a wave computes  S' = Q K_w^T, dP = dO V_w^T  (10 MFMAs, un-swapped: query on the accumulator row,
-//     key on the lane),  P = exp2(S' scale - lse), dS = P (dP - delta)  in registers,  dV^T += dO^T P, dK^T += Q^T dS
-//     (12 MFMAs, P / dS straight from the accumulator registers), and its share of dQ:  dQp^T = K_w^T dS^T  (6 MFMAs) -
-//     dS crosses LDS once (2 KiB per wave, written as packed accumulator chunks, read back with transposing reads), the
-//     K^T operand comes from the resident K image by transposing reads;
-//   * dQ of the tile is the sum of the eight waves' partials: each wave parks its 32 x 80 f32 partial in its own LDS
-//     slot, one barrier, then 320 threads add the eight slots in slot order (bitwise reproducible), scale, round and
-//     store 16-byte pieces of the dq rows (the store itself is issued one tile later, so the next tile's landed-wait
-//     never waits for it);
-//   * the 257th KEY (one row that fits no wave) is worked on by the vector unit inside the reduce step, in the same
-//     (query, 16-byte chunk) thread layout: two dot products per query, p and dS of that key, the rank-1 terms of dQ,
-//     and running sums of dK[256] / dV[256] that are combined through LDS after the sweep;
+//   * the query side STREAMS: Q, dO and O arrive tile by tile (32 queries) through a three-stage LDS ring filled by
+//     LDS-DMA (a80 tile format: the same swizzled 5 KiB images as the forward), two tiles ahead of the one being
+//     multiplied; the whole-head images are K (every wave reads all of it for dQ) and V (a wave re-reads its own tile);
+//   * per query tile a wave computes  S' = Q K_w^T, dP = dO V_w^T  (10 MFMAs 32x32x16, un-swapped: query on the
+//     accumulator row, key on the lane),  P = exp2(S' scale - lse), dS = P (dP - delta)  in registers,
+//     dV^T += dO^T P, dK^T += Q^T dS  (12 MFMAs, P / dS straight from the accumulator registers);
+//   * dQ needs the contraction over ALL keys: every wave writes its 32 x 32 dS tile to LDS (2 KiB, packed accumulator
+//     chunks, bf16 - the same rounding dK sees), one barrier, and the 80 x 32 tile dQ^T = K^T dS^T is cut into ten
+//     16 x 16 blocks, each owned by ONE wave which runs the whole key range (8 MFMAs 16x16x32, K^T from the resident K
+//     image and dS^T from the eight dS tiles by transposing reads): no partial sums, no f32 traffic, fixed summation order
+//     (bitwise reproducible).  (First version of this kernel: 32 x 80 f32 partials per wave parked in LDS and summed by
+//     320 threads - 84 KiB of LDS and 19 % of the cycles; tools/a80_bwd_trace.py.)
+//   * the 257th KEY (one row that fits no wave) is worked on by the vector unit, 16 lanes per query / one 16-byte chunk
+//     per lane: two dot products per query, p and dS of that key, the rank-1 term of dQ (added when a block is stored) and
+//     running sums of dK[256] / dV[256] that are combined through LDS after the sweep;
 //   * the 257th QUERY is the only real row of the ninth query tile (an ordinary iteration on a mostly empty tile);
-//   * delta = <dO, O> of all queries is computed in the prologue from global rows (one memory round trip, shared with
-//     the K / V images and the first ring tiles).
-// LDS: ring 20 KiB + K image 40 KiB + dQ slots 84 KiB + statistics = 147 KiB, 8 waves at <= 256 registers.
+//   * delta = <dO, O> is computed one tile ahead from the ring's dO and O tiles (same thread layout, DPP row sums).
+// LDS: ring 45 KiB + K image 40 KiB + V image 40 KiB + dS tiles 16 KiB + statistics = 144 KiB.
 #include "attn80_common.hpp"
 
 #ifdef A80_TRACE
 // developer-only (tools/a80_bwd_trace.py builds with -DA80_TRACE): per workgroup and wave, cycles summed per phase over the
 // nine iterations: [0] prologue, [1] landed-wait + barrier a, [2] S' / dP, [3] softmax terms + dS tile, [4] dV / dK,
-// [5] dQ partial MFMAs, [6] parking, [7] barrier b, [8] reduce + key 256, [9] epilogue, [10] total
+// [5] dQ blocks, [6] -, [7] barrier b, [8] stores + DMA issue + delta + key 256, [9] epilogue, [10] total
 __device__ unsigned long long g_a80_bwd_trace[1024 * 8 * 16];
 extern "C" void* octic_dbg_a80_bwd_trace(void) {
   void* p = nullptr;
@@ -56,17 +55,19 @@ namespace octic {
 namespace a80 {
 
 constexpr int BW_T = 257, BW_NT = 9;
-constexpr int QROW = 84;                          // f32 row stride of a dQ partial (80 + 4: 16-byte aligned rows, bank spread)
-constexpr int SLOT_B = 32 * QROW * 4;             // 10 752 B per wave
-constexpr int BW_RING = 2 * 2 * TILE_B;           // two stages of (Q tile | dO tile)
+constexpr int BW_STG = 3 * TILE_B;                // one ring stage: Q | dO | O tile
+constexpr int BW_RING = 3 * BW_STG;
 constexpr int BW_KIMG = 8 * TILE_B;
-constexpr int BW_SLOTS = WAVES * SLOT_B;
+constexpr int BW_VIMG = 8 * TILE_B;               // V rows of all key tiles (a wave re-reads its own tile as the B operand of dP)
+constexpr int BW_DST = 2048;                      // a wave's dS tile: [key 32][64 B]
+constexpr int BW_DS = WAVES * BW_DST;
 constexpr int BW_STAT = 2 * 288 * 4;              // lse_s, del_s
 constexpr int BW_XK = 384;                        // K row 256 | V row 256 (160 B each)
-constexpr int BW_X = 2 * 32 * 4;                  // p and dS of key 256 for the queries of the current tile
-constexpr int BW_LDS = BW_RING + BW_KIMG + BW_SLOTS + BW_STAT + BW_XK + BW_X;
+constexpr int BW_PX = 2 * 32 * 4;                 // p and dS of key 256 for the queries of the current tile
+constexpr int BW_PQ = 2 * 4 * 64 * 16;            // f32 key quarters of dQ blocks 8 and 9
+constexpr int BW_ACC = 160 * 4;                   // dK[256] | dV[256] running sums
+constexpr int BW_LDS = BW_RING + BW_KIMG + BW_VIMG + BW_DS + BW_STAT + BW_XK + BW_PX + BW_PQ + BW_ACC;
 static_assert(BW_LDS <= 160 * 1024, "LDS budget");
-static_assert(8 * TILE_B <= BW_SLOTS, "the V image borrows the slot region during the prologue");
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
@@ -80,6 +81,20 @@ __device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b, float a
   }
   return acc;
 }
+// four consecutive head elements (half `sub` of group g) at `base[row_off + ...]`: the base stays a uniform pointer and
+// everything per-lane is a 32-bit element offset (a per-lane 64-bit row pointer kept live across the tile loop was
+// spilled, and every scratch reload drains the DMA queue)
+__device__ __forceinline__ void hm_store8_at(bf16* base, int row_off, int g, int sub, const u32x2 v, const HeadMap m) {
+  if (m.cv == 0) { *(u32x2*)(base + (row_off + g * 8 + sub * 4)) = v; return; }
+  if (g < 8) { *(u32x2_u*)(base + (row_off + hm_off8(m, g) + sub * 4)) = u32x2_u{v[0], v[1]}; return; }
+  if (g == 8) {
+    const int o = row_off + 2 * sub * m.cv + m.bs + 8;
+    *(unsigned*)(base + o) = v[0];
+    *(unsigned*)(base + (o + m.cv)) = v[1];
+    return;
+  }
+  *(u32x2_u*)(base + (row_off + (4 + 2 * sub) * m.cv + 2 * m.bs + 16)) = u32x2_u{v[0], v[1]};
+}
 // chunk j (16 bytes = elements 8 j .. 8 j + 7) of row `row` of a tile image
 __device__ __forceinline__ const char* tile_chunk(const char* tile, int row, int j) {
   return j < 8 ? tile + row * 128 + ((j ^ swz(row)) << 4) : tile + TAIL_OFF + row * 32 + (j - 8) * 16;
@@ -90,13 +105,17 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
   char* const kimg = smem + BW_RING;
-  char* const slots = kimg + BW_KIMG;
-  float* const lse_s = (float*)(slots + BW_SLOTS);
+  char* const vimg = kimg + BW_KIMG;
+  char* const dst = vimg + BW_VIMG;
+  float* const lse_s = (float*)(dst + BW_DS);
   float* const del_s = lse_s + 288;
   char* const xk = (char*)(del_s + 288);
-  float* const px = (float*)(xk + BW_XK);          // [0..31] p of key 256, [32..63] dS of key 256
+  float* const pxp = (float*)(xk + BW_XK);
+  float* const pxs = pxp + 32;
+  char* const pq = (char*)(pxs + 32);
+  float* const acc256 = (float*)(pq + BW_PQ);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned ldsK = lds0 + BW_RING, ldsS = ldsK + BW_KIMG;
+  const unsigned ldsK = lds0 + BW_RING, ldsV = ldsK + BW_KIMG;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
@@ -112,107 +131,199 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
 #endif
   FragAddr fa;
   fa.setup(lane);
-  LeanStager stq, sto;                               // rows of q / k / v (stride sT, block width cv_in) and of dO (oT, cv_out)
+  LeanStager stq, sto;                               // rows of q / k / v (stride sT, block width cv_in) and of dO / O (oT, cv_out)
   stq.setup(wid, W, lane, a.sT, a.cv_in, nt, T);
   sto.setup(wid, W, lane, a.oT, a.cv_out, nt, T);
   const i32x4 rq = make_rs(a.q, in_off, a.sT, T, a.cv_in), rk = make_rs(a.k, in_off, a.sT, T, a.cv_in);
   const i32x4 rv = make_rs(a.v, in_off, a.sT, T, a.cv_in), rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
+  const i32x4 ro = make_rs(a.o, o_off, a.oT, T, a.cv_out);
+  auto issue_tile = [&](int t) {                     // Q, dO, O rows of query tile t -> ring stage t % 3
+    const int s3 = 3 * (t % 3);
+    stq.issue(t, lds0, rq, hm.q.bs, s3);
+    sto.issue(t, lds0, rdo, hm.o.bs, s3 + 1);
+    sto.issue(t, lds0, ro, hm.o.bs, s3 + 2);
+  };
 
-  // thread layout of the row-wise passes (delta, reduce, key 256): 16 lanes per query, lane j < 10 owns 16-byte chunk j
+  // thread layout of the row-wise delta: 16 lanes per query, lane j < 10 owns 16-byte chunk j
   const int qq = 4 * wid + (lane >> 4), j16 = lane & 15;
   const bool jon = j16 < 10;
   const int jc = jon ? j16 : 9;
+  float* const dl = a.delta + stat_off;              // uniform base, 32-bit per-lane index
+  // delta of tile t for query qq from the ring's dO and O tiles (every lane of the row gets the sum)
+  auto delta_of = [&](int t) {
+    const char* st_ = ring + (t % 3) * BW_STG;
+    const u32x4 dc = *(const u32x4*)tile_chunk(st_ + TILE_B, qq, jc), oc = *(const u32x4*)tile_chunk(st_ + 2 * TILE_B, qq, jc);
+    const float d = sum16_from8(sum8(jon ? dot8_bf16(dc, oc, 0.f) : 0.f));
+    const int q = 32 * t + qq;
+    if (j16 == 0) {
+      del_s[q] = d;                                  // rows past T are zero rows: d = 0
+      if (q < T) dl[q] = d;
+    }
+  };
 
   // ---------------------------------------------------------------------------------------------------- prologue
-  // K image (tiles 0..7), V image (borrowing the slot region), the first two ring tiles: all by LDS-DMA.  Meanwhile
-  // delta = <dO, O> of the 257 queries from global rows, and rows 256 of K and V.
 #pragma unroll
   for (int jt = 0; jt < 8; ++jt) {
     stq.issue(jt, ldsK, rk, hm.k.bs);
-    stq.issue(jt, ldsS, rv, hm.v.bs);
+    stq.issue(jt, ldsV, rv, hm.v.bs);
   }
-  stq.issue(0, lds0, rq, hm.q.bs, 0);
-  sto.issue(0, lds0, rdo, hm.o.bs, 1);
-  stq.issue(1, lds0, rq, hm.q.bs, 2);
-  sto.issue(1, lds0, rdo, hm.o.bs, 3);
+  issue_tile(0);
+  issue_tile(1);
   {
-    u32x4 dd[nt], oo[nt];
-#pragma unroll
-    for (int p = 0; p < nt; ++p) {
-      const int q = 32 * p + qq;
-      dd[p] = u32x4{0, 0, 0, 0};
-      oo[p] = u32x4{0, 0, 0, 0};
-      if (q < T && jon) {
-        dd[p] = hm_load16(a.dout + o_off + (int64_t)q * a.oT, jc, hm.o);
-        oo[p] = hm_load16(a.o + o_off + (int64_t)q * a.oT, jc, hm.o);
-      }
-    }
     u32x4 xrow = {0, 0, 0, 0};
     if (wid == 1 && lane < 10) xrow = hm_load16(a.k + in_off + (int64_t)256 * a.sT, lane, hm.k);
     if (wid == 2 && lane < 10) xrow = hm_load16(a.v + in_off + (int64_t)256 * a.sT, lane, hm.v);
     for (int t = tid; t < 288; t += 512) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
-#pragma unroll
-    for (int p = 0; p < nt; ++p) {
-      float d = dot8_bf16(dd[p], oo[p], 0.f);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
-      d += __shfl_xor(d, 8, 64);
-      const int q = 32 * p + qq;
-      if (j16 == 0) {
-        del_s[q] = q < T ? d : 0.f;
-        if (q < T) a.delta[stat_off + q] = d;
-      }
-    }
+    if (tid < 160) acc256[tid] = 0.f;
     if ((wid == 1 || wid == 2) && lane < 10) *(u32x4*)(xk + (wid - 1) * 160 + lane * 16) = xrow;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  bf16x8 kf[KS], vf[KS];
-  {
-    const char* kt_ = kimg + wid * TILE_B;
-    const char* vt_ = slots + wid * TILE_B;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      kf[ks] = rowfrag(kt_, fa, ks);
-      vf[ks] = rowfrag(vt_, fa, ks);
-    }
-  }
+  // The K and V rows of the own key tile (B operands of S' and dP) are re-read from the resident images every tile:
+  // 40 registers that the accumulators need more (with them in registers the build spilled 13-96 VGPRs, and every scratch
+  // reload inside the tile loop is an `s_waitcnt vmcnt(0)`, i.e. a drain of the DMA queue)
+  const char* const kt_ = kimg + wid * TILE_B;
+  const char* const vt_ = vimg + wid * TILE_B;
+  delta_of(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                      // the V image is dead: the slot region is free
+  __builtin_amdgcn_s_barrier();
 
   BWT(0);
   f32x16 dkt[DT], dvt[DT];
   zero_acc<DT>(dkt);
   zero_acc<DT>(dvt);
-  float dk256[8], dv256[8];                          // running sums of dK[256] / dV[256], chunk jc, over this thread's queries
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { dk256[e] = 0.f; dv256[e] = 0.f; }
-  u32x4 pend = {0, 0, 0, 0};                         // dq piece of the previous tile, stored one tile late
-  int pend_q = T;
-  char* const myslot = slots + wid * SLOT_B;
-  const char* const ktile = kimg + wid * TILE_B;
+  char* const mydst = dst + wid * BW_DST;
   bf16* const dqb = a.dq + g_off;
+  const int gT = (int)a.gT;
 
-  // transposing read addresses of the dS tile ([key][permuted q], 64-byte rows): lane group g = (khalf, nh)
-  const int tg = lane >> 4, ti = lane & 15;
-  const int ds_rd = (4 * (tg >> 1) + (ti >> 2)) * 64 + (tg & 1) * 32 + (ti & 3) * 8;
-  // accumulator lane n (= lane & 31) of dQp^T holds query qperm(n) of the tile
-  const int qperm = 16 * (r >> 4) + 4 * ((r >> 3) & 1) + (r & 3) + 8 * ((r & 7) >> 2);
+  // ---- transposing-read geometry of the 16x16x32 products (natural k order: lane group kq holds k = 8 kq + e).
+  // A 16 x 32 operand block read out of a 32-row tile image: rows 8 kq + q4 (+ 4), columns 16 db + 4 p .. + 3.
+  const int kq = lane >> 4, ti = lane & 15, q4 = ti >> 2, pp = ti & 3;
+  const int trow = 8 * kq + q4;
+  auto blk_lo = [&](int db) { return db < 4 ? trow * 128 + (((2 * db + (pp >> 1)) ^ swz(trow)) << 4) + (pp & 1) * 8 : TAIL_OFF + trow * 32 + pp * 8; };
+  auto blk_hi = [&](int db) { return db < 4 ? (trow + 4) * 128 + (((2 * db + (pp >> 1)) ^ swz(trow + 4)) << 4) + (pp & 1) * 8 : TAIL_OFF + (trow + 4) * 32 + pp * 8; };
+  auto tr8 = [&](const char* lo, const char* hi) {
+    const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lo);
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)hi);
+    const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+    return __builtin_bit_cast(bf16x8, w);
+  };
+  // ---- dQ^T = K^T dS^T in ten blocks of 16 d x 16 queries (block bi: d-block bi % 5, query block bi / 5).  Wave w owns
+  // block w over the whole key range (8 k-steps); blocks 8 and 9 are cut into four key quarters of 2 k-steps, wave w takes
+  // quarter w >> 1 of block 8 + (w & 1): ten k-steps per wave.  The quarters meet in LDS (f32, 1 KiB each) and are
+  // summed in quarter order by waves 0 / 1 at the start of the next tile.
+  //   A = K^T block out of K tile kt; B = dS^T block out of wave kt's dS tile: rows 8 kq + q4 (+ 4), 32-byte half
+  //   qb ^ (row >> 3 & 1), bytes 8 p ..
+  const int bi0 = wid, bi1 = 8 + (wid & 1);
+  const int ka_lo0 = blk_lo(bi0 % 5), ka_hi0 = blk_hi(bi0 % 5), kb0 = trow * 64 + (((bi0 / 5) ^ (kq & 1)) * 32) + pp * 8;
+  const int ka_lo1 = blk_lo(bi1 % 5), ka_hi1 = blk_hi(bi1 % 5), kb1 = trow * 64 + ((1 ^ (kq & 1)) * 32) + pp * 8;
+  // a block's accumulator: lane (n = ti, rq = kq) holds elements 16 db + 4 rq .. + 3 of query position 16 qb + n of the tile
+  const int qpos16 = 4 * (ti >> 3) + (ti & 3) + 8 * ((ti & 7) >> 2);       // + 16 qb
+  u32x2 pend = {0, 0};                               // dq piece of the previous tile (own block), stored one tile late
+  int pend_off = -1, pend2_off = -1;                 // element offsets of the rows in dq (-1: nothing pending)
+  auto dq_block = [&](int t, int ka_lo, int ka_hi, int kb, int kt0, int nk, int db, int qb, bool rank1) {
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int k = 0; k < nk; ++k) {
+      const char* kp = kimg + (kt0 + k) * TILE_B;
+      const char* sp = dst + (kt0 + k) * BW_DST + kb;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + ka_lo, kp + ka_hi), tr8(sp, sp + 256), acc, 0, 0, 0);
+    }
+    if (rank1) {                                     // dS of key 256 for this query: rank-1 term of dQ
+      const float sk = pxs[16 * qb + qpos16];
+      const u32x2 k2 = *(const u32x2*)(xk + (16 * db + 4 * kq) * 2);
+      acc[0] += sk * bf_lo(k2[0]); acc[1] += sk * bf_hi(k2[0]); acc[2] += sk * bf_lo(k2[1]); acc[3] += sk * bf_hi(k2[1]);
+    }
+    (void)t;
+    return acc;
+  };
+  auto pack_scaled = [&](const f32x4 v) {
+    const bf16x4 o = {(bf16)(v[0] * a.scale), (bf16)(v[1] * a.scale), (bf16)(v[2] * a.scale), (bf16)(v[3] * a.scale)};
+    return __builtin_bit_cast(u32x2, o);
+  };
+  auto store_pending = [&]() {
+    if (pend_off >= 0) {
+      const int d0 = 16 * (bi0 % 5) + 4 * kq;
+      hm_store8_at(dqb, pend_off, d0 >> 3, (d0 >> 2) & 1, pend, hm.q);
+    }
+    if (wid < 2 && pend2_off >= 0) {                 // blocks 8 / 9 of the previous tile: the four key quarters, in order
+      const f32x4* q4p = (const f32x4*)pq + wid * 256 + lane;
+      const f32x4 sum = ((q4p[0] + q4p[64]) + q4p[128]) + q4p[192];
+      const int d0 = 16 * (3 + wid) + 4 * kq;
+      hm_store8_at(dqb, pend2_off, d0 >> 3, (d0 >> 2) & 1, pack_scaled(sum), hm.q);
+    }
+  };
+
+  // ---- key 256 (the row that fits no wave) by ONE wave per tile, on the matrix pipe with 16x16x32 products:
+  //   s'[q] = <Q[q], K[256]>, dp[q] = <dO[q], V[256]>   (two query blocks x three k-steps, B = the key row in every column)
+  //   p, dS of that key for the 32 queries -> LDS (pxp, pxs; pxs is also the rank-1 term of dQ)
+  //   dV[256] += dO^T p, dK[256] += Q^T dS               (five d-blocks each, B = p / dS in every column) -> acc256 in LDS
+  auto key256 = [&](int t, const char* qt_, const char* dt_) {
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      f32x4 aS = {0, 0, 0, 0}, aD = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks3 = 0; ks3 < 3; ++ks3) {
+        const int c = 4 * ks3 + kq;                  // 16-byte chunk of the head vector (10, 11: beyond head_dim)
+        u32x4 fq = {0, 0, 0, 0}, fd = {0, 0, 0, 0}, fk = {0, 0, 0, 0}, fv = {0, 0, 0, 0};
+        if (c < 10) {
+          fq = *(const u32x4*)tile_chunk(qt_, 16 * qb2 + ti, c);
+          fd = *(const u32x4*)tile_chunk(dt_, 16 * qb2 + ti, c);
+          fk = *(const u32x4*)(xk + c * 16);
+          fv = *(const u32x4*)(xk + 160 + c * 16);
+        }
+        aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq), __builtin_bit_cast(bf16x8, fk), aS, 0, 0, 0);
+        aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fv), aD, 0, 0, 0);
+      }
+      const int q0 = 16 * qb2 + 4 * kq;              // lane (n, rq = kq): queries q0 .. q0 + 3 of the tile (every n alike)
+      const f32x4 l4 = *(const f32x4*)(lse_s + 32 * t + q0), d4 = *(const f32x4*)(del_s + 32 * t + q0);
+      f32x4 p4, s4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p4[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(aS[e], a.scale_log2, -l4[e]));
+        s4[e] = p4[e] * (aD[e] - d4[e]);
+      }
+      if (ti == 0) {
+        *(f32x4*)(pxp + q0) = p4;
+        *(f32x4*)(pxs + q0) = s4;
+      }
+    }
+    // B operands: lane (n, kq) holds queries 8 kq + e, the same in every column n
+    float pb[8], sb[8];
+    {
+      const f32x4 a0 = *(const f32x4*)(pxp + 8 * kq), a1 = *(const f32x4*)(pxp + 8 * kq + 4);
+      const f32x4 b0 = *(const f32x4*)(pxs + 8 * kq), b1 = *(const f32x4*)(pxs + 8 * kq + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pb[e] = a0[e]; pb[4 + e] = a1[e]; sb[e] = b0[e]; sb[4 + e] = b1[e]; }
+    }
+    const bf16x8 bp = pack8(pb), bs = pack8(sb);
+#pragma unroll
+    for (int db = 0; db < 5; ++db) {
+      const int lo = blk_lo(db), hi = blk_hi(db);
+      const f32x4 z = {0, 0, 0, 0};
+      const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(dt_ + lo, dt_ + hi), bp, z, 0, 0, 0);
+      const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(qt_ + lo, qt_ + hi), bs, z, 0, 0, 0);
+      if (ti == 0) {                                 // column 0 of the block: elements 16 db + 4 kq .. + 3
+        float* pk = acc256 + 16 * db + 4 * kq;
+        *(f32x4*)pk = *(const f32x4*)pk + dk;
+        *(f32x4*)(pk + 80) = *(const f32x4*)(pk + 80) + dv;
+      }
+    }
+  };
 
   for (int t = 0; t < nt; ++t) {
-    // ---- [a_t] tile t has landed (issued a whole iteration ago); every wave is done with tile t - 1 and with the slots
+    // ---- [a_t] tiles t and t + 1 have landed; every wave is done with tile t - 1, the dS tiles and the dQ quarters
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     BWT(1);
-    if (pend_q < T && jon) hm_store16(dqb + (int64_t)pend_q * a.gT, jc, pend, hm.q);
-    if (t >= 1 && t + 1 < nt) {                      // tile t + 1 -> the stage tile t - 1 occupied (tiles 0, 1: prologue)
-      stq.issue(t + 1, lds0, rq, hm.q.bs, 2 * ((t + 1) & 1));
-      sto.issue(t + 1, lds0, rdo, hm.o.bs, 2 * ((t + 1) & 1) + 1);
-    }
-    const char* qt_ = ring + (2 * (t & 1)) * TILE_B;
+    store_pending();
+    if (t + 2 < nt) issue_tile(t + 2);
+    const char* qt_ = ring + (t % 3) * BW_STG;
     const char* dt_ = qt_ + TILE_B;
+    if (t + 1 < nt) delta_of(t + 1);                 // one tile ahead: visible after this tile's barriers
+    if (wid == 2 + t % 6) key256(t, qt_, dt_);
+    BWT(8);
 
     // ---- S' and dP (query on the accumulator row, key on the lane)
     f32x16 x, dp;
@@ -220,8 +331,8 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
     for (int i = 0; i < 16; ++i) { x[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_, fa, ks), kf[ks], x, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(dt_, fa, ks), vf[ks], dp, 0, 0, 0);
+      x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_, fa, ks), rowfrag(kt_, fa, ks), x, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(dt_, fa, ks), rowfrag(vt_, fa, ks), dp, 0, 0, 0);
     }
     BWT(2);
     float ps[16], ds[16];
@@ -238,10 +349,17 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
       }
     }
     const bf16x8 p0 = pack8(ps), p1 = pack8(ps + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
-    // dS tile of this wave: row = key (lane r), 16-byte chunk 2 s + half = queries 16 s + 4 half + {0..3, 8..11}
-    *(bf16x8*)(myslot + r * 64 + half * 16) = s0;
-    *(bf16x8*)(myslot + r * 64 + 32 + half * 16) = s1;
+    // dS tile of this wave: row = key (lane r); its 32-byte half s (queries 16 s + {4 half + 0..3, + 8}) sits at half
+    // s ^ (r >> 3 & 1), so that the transposing reads of rows 0-3 and 8-11 hit disjoint banks
+    {
+      const int sw = (r >> 3) & 1;
+      *(bf16x8*)(mydst + r * 64 + (sw * 32) + half * 16) = s0;
+      *(bf16x8*)(mydst + r * 64 + ((sw ^ 1) * 32) + half * 16) = s1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     BWT(3);
+    __builtin_amdgcn_s_barrier();                    // ---- [b_t] the eight dS tiles, pxs and delta of the next tile are in LDS
+    BWT(7);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dt_, fa, d, 0), p0, dvt[d], 0, 0, 0);
@@ -250,76 +368,21 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
       dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_, fa, d, 1), s1, dkt[d], 0, 0, 0);
     }
     BWT(4);
-    // ---- this wave's share of dQ: dQp^T[d][q'] = sum_key K^T[d][key] dS^T[key][q'] (k order of trfrag: 4 half + {0..3}, + 8)
-    f32x16 dqp[DT];
-    zero_acc<DT>(dqp);
+    // ---- dQ^T: the own block over all keys, a key quarter of block 8 / 9
     {
-      bf16x8 bq[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const char* lo = myslot + s * 1024 + ds_rd;
-        const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lo);
-        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lo + 512));
-        const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-        bq[s] = __builtin_bit_cast(bf16x8, w);
-      }
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        dqp[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(ktile, fa, d, 0), bq[0], dqp[d], 0, 0, 0);
-        dqp[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(ktile, fa, d, 1), bq[1], dqp[d], 0, 0, 0);
-      }
+      const f32x4 own = dq_block(t, ka_lo0, ka_hi0, kb0, 0, 8, bi0 % 5, bi0 / 5, true);
+      const int qloc = 16 * (bi0 / 5) + qpos16;
+      pend = pack_scaled(own);
+      pend_off = 32 * t + qloc < T ? (32 * t + qloc) * gT : -1;
+      const f32x4 part = dq_block(t, ka_lo1, ka_hi1, kb1, 2 * (wid >> 1), 2, bi1 % 5, 1, wid < 2);
+      ((f32x4*)pq)[(wid & 1) * 256 + (wid >> 1) * 64 + lane] = part;
+      pend2_off = 32 * t + 16 + qpos16 < T ? (32 * t + 16 + qpos16) * gT : -1;
     }
     BWT(5);
-    // park the partial: row = query qperm, elements 32 d + 8 k4 + 4 half .. + 3 (the dS tile underneath is consumed)
-    {
-      float* row = (float*)myslot + qperm * QROW + 4 * half;
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
-          if (d * 32 + k4 * 8 < HD)
-            *(f32x4*)(row + d * 32 + 8 * k4) = f32x4{dqp[d][4 * k4], dqp[d][4 * k4 + 1], dqp[d][4 * k4 + 2], dqp[d][4 * k4 + 3]};
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    BWT(6);
-    __builtin_amdgcn_s_barrier();                    // ---- [b_t] all eight partials are in LDS
-    BWT(7);
-
-    // ---- reduce + key 256, thread (query qq of the tile, chunk jc)
-    {
-      const int q = 32 * t + qq;
-      const u32x4 qc = *(const u32x4*)tile_chunk(qt_, qq, jc), dc = *(const u32x4*)tile_chunk(dt_, qq, jc);
-      const u32x4 kc = *(const u32x4*)(xk + jc * 16), vc = *(const u32x4*)(xk + 160 + jc * 16);
-      float sx = jon ? dot8_bf16(qc, kc, 0.f) : 0.f, dx = jon ? dot8_bf16(dc, vc, 0.f) : 0.f;
-      sx += __shfl_xor(sx, 1, 64); dx += __shfl_xor(dx, 1, 64);
-      sx += __shfl_xor(sx, 2, 64); dx += __shfl_xor(dx, 2, 64);
-      sx += __shfl_xor(sx, 4, 64); dx += __shfl_xor(dx, 4, 64);
-      sx += __shfl_xor(sx, 8, 64); dx += __shfl_xor(dx, 8, 64);
-      const float p256 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx, a.scale_log2, -lse_s[q]));
-      const float s256 = p256 * (dx - del_s[q]);
-      f32x4 s0v = {0, 0, 0, 0}, s1v = {0, 0, 0, 0};
-      const float* src = (const float*)slots + qq * QROW + jc * 8;
-#pragma unroll
-      for (int w = 0; w < W; ++w) {                   // fixed slot order: identical launches give identical bits
-        s0v += *(const f32x4*)(src + w * (SLOT_B / 4));
-        s1v += *(const f32x4*)(src + w * (SLOT_B / 4) + 4);
-      }
-      float o8[8] = {s0v[0], s0v[1], s0v[2], s0v[3], s1v[0], s1v[1], s1v[2], s1v[3]};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o8[2 * e] = (o8[2 * e] + s256 * bf_lo(kc[e])) * a.scale;
-        o8[2 * e + 1] = (o8[2 * e + 1] + s256 * bf_hi(kc[e])) * a.scale;
-        dv256[2 * e] += p256 * bf_lo(dc[e]);
-        dv256[2 * e + 1] += p256 * bf_hi(dc[e]);
-        dk256[2 * e] += s256 * bf_lo(qc[e]);
-        dk256[2 * e + 1] += s256 * bf_hi(qc[e]);
-      }
-      pend = __builtin_bit_cast(u32x4, pack8(o8));
-      pend_q = q;
-    }
-    BWT(8);
   }
-  if (pend_q < T && jon) hm_store16(dqb + (int64_t)pend_q * a.gT, jc, pend, hm.q);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // the last tile's dQ quarters; every wave is past its ring / image reads
+  store_pending();
 
   // ---------------------------------------------------------------------------------------------------- epilogue
   {
@@ -327,27 +390,11 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
     store_rows16(a.dk + g_off + (int64_t)ki * a.gT, dkt, a.scale, half, hm.k);
     store_rows16(a.dv + g_off + (int64_t)ki * a.gT, dvt, 1.0f, half, hm.v);
   }
-  // dK[256], dV[256]: 32 query groups x 10 chunks x 8 elements each, summed in group order through LDS
-  __builtin_amdgcn_s_barrier();                      // every wave is past its last reduce: the slot region is free
-  {
-    float* part = (float*)slots;                     // [32 groups][2][80]
-    if (jon) {
-      float* pr = part + (size_t)qq * 160 + jc * 8;
-      *(f32x4*)pr = f32x4{dk256[0], dk256[1], dk256[2], dk256[3]};
-      *(f32x4*)(pr + 4) = f32x4{dk256[4], dk256[5], dk256[6], dk256[7]};
-      *(f32x4*)(pr + 80) = f32x4{dv256[0], dv256[1], dv256[2], dv256[3]};
-      *(f32x4*)(pr + 84) = f32x4{dv256[4], dv256[5], dv256[6], dv256[7]};
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (tid < 160) {
-      float s = 0.f;
-      for (int g = 0; g < 32; ++g) s += part[g * 160 + tid];
-      const bool isv = tid >= 80;
-      const int e = isv ? tid - 80 : tid;
-      bf16* row = (isv ? a.dv : a.dk) + g_off + (int64_t)256 * a.gT;
-      row[hm_elem(e, isv ? hm.v : hm.k)] = (bf16)(isv ? s : s * a.scale);
-    }
+  if (tid < 160) {                                   // dK[256] | dV[256] (acc256: written by one wave per tile, in tile order)
+    const bool isv = tid >= 80;
+    const int e = isv ? tid - 80 : tid;
+    bf16* row = (isv ? a.dv : a.dk) + g_off + (int64_t)256 * a.gT;
+    row[hm_elem(e, isv ? hm.v : hm.k)] = (bf16)(isv ? acc256[tid] : acc256[tid] * a.scale);
   }
 #ifdef A80_TRACE
   BWT(9);
