@@ -31,8 +31,8 @@
 
 #ifdef A80_TRACE
 // developer-only (tools/a80_bwd_trace.py builds with -DA80_TRACE): per workgroup and wave, cycles summed per phase over the
-// nine iterations: [0] prologue, [1] landed-wait + barrier a, [2] S' / dP, [3] softmax terms + dS tile, [4] dV / dK,
-// [5] dQ blocks, [6] -, [7] barrier b, [8] stores + DMA issue + delta + key 256, [9] epilogue, [10] total
+// nine iterations: [0] prologue, [2] S' / dP, [3] softmax terms + dS tile, [7] landed-wait + the barrier, [8] dq stores + DMA
+// issue, [4] dV / dK, [5] dQ blocks, [6] delta + key 256, [9] epilogue, [10] total
 __device__ unsigned long long g_a80_bwd_trace[1024 * 8 * 16];
 extern "C" void* octic_dbg_a80_bwd_trace(void) {
   void* p = nullptr;
@@ -55,19 +55,20 @@ namespace octic {
 namespace a80 {
 
 constexpr int BW_T = 257, BW_NT = 9;
+constexpr int BW_NSTG = 4;                        // ring stages: tile t is multiplied while t + 1, t + 2 have landed and t + 3 flies
 constexpr int BW_STG = 3 * TILE_B;                // one ring stage: Q | dO | O tile
-constexpr int BW_RING = 3 * BW_STG;
+constexpr int BW_RING = BW_NSTG * BW_STG;
 constexpr int BW_KIMG = 8 * TILE_B;
-constexpr int BW_VIMG = 8 * TILE_B;               // V rows of all key tiles (a wave re-reads its own tile as the B operand of dP)
 constexpr int BW_DST = 2048;                      // a wave's dS tile: [key 32][64 B]
-constexpr int BW_DS = WAVES * BW_DST;
+constexpr int BW_DS = 2 * WAVES * BW_DST;         // double-buffered (one barrier per tile)
+constexpr int BW_PQ = 2 * 2 * 4 * 64 * 16;        // f32 key quarters of dQ blocks 8 and 9, double-buffered
 constexpr int BW_STAT = 2 * 288 * 4;              // lse_s, del_s
 constexpr int BW_XK = 384;                        // K row 256 | V row 256 (160 B each)
-constexpr int BW_PX = 2 * 32 * 4;                 // p and dS of key 256 for the queries of the current tile
-constexpr int BW_PQ = 2 * 4 * 64 * 16;            // f32 key quarters of dQ blocks 8 and 9
+constexpr int BW_PX = 2 * 2 * 32 * 4;             // p and dS of key 256 for the queries of a tile, double-buffered
 constexpr int BW_ACC = 160 * 4;                   // dK[256] | dV[256] running sums
-constexpr int BW_LDS = BW_RING + BW_KIMG + BW_VIMG + BW_DS + BW_STAT + BW_XK + BW_PX + BW_PQ + BW_ACC;
+constexpr int BW_LDS = BW_RING + BW_KIMG + BW_DS + BW_PQ + BW_STAT + BW_XK + BW_PX + BW_ACC;
 static_assert(BW_LDS <= 160 * 1024, "LDS budget");
+static_assert(8 * TILE_B <= BW_DS + BW_PQ, "the V image borrows the dS / quarter buffers during the prologue");
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
@@ -105,15 +106,13 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
   char* const kimg = smem + BW_RING;
-  char* const vimg = kimg + BW_KIMG;
-  char* const dst = vimg + BW_VIMG;
-  float* const lse_s = (float*)(dst + BW_DS);
+  char* const dsb = kimg + BW_KIMG;                  // [2][8 waves][2 KiB] dS tiles (prologue: the V image, with pq)
+  char* const pq = dsb + BW_DS;                      // [2][2 blocks][4 quarters][64 lanes] f32x4
+  float* const lse_s = (float*)(pq + BW_PQ);
   float* const del_s = lse_s + 288;
   char* const xk = (char*)(del_s + 288);
-  float* const pxp = (float*)(xk + BW_XK);
-  float* const pxs = pxp + 32;
-  char* const pq = (char*)(pxs + 32);
-  float* const acc256 = (float*)(pq + BW_PQ);
+  float* const px = (float*)(xk + BW_XK);            // [2][p 32 | dS 32]
+  float* const acc256 = px + 128;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned ldsK = lds0 + BW_RING, ldsV = ldsK + BW_KIMG;
 
@@ -137,8 +136,8 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   const i32x4 rq = make_rs(a.q, in_off, a.sT, T, a.cv_in), rk = make_rs(a.k, in_off, a.sT, T, a.cv_in);
   const i32x4 rv = make_rs(a.v, in_off, a.sT, T, a.cv_in), rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
   const i32x4 ro = make_rs(a.o, o_off, a.oT, T, a.cv_out);
-  auto issue_tile = [&](int t) {                     // Q, dO, O rows of query tile t -> ring stage t % 3
-    const int s3 = 3 * (t % 3);
+  auto issue_tile = [&](int t) {                     // Q, dO, O rows of query tile t -> ring stage t % 4
+    const int s3 = 3 * (t % BW_NSTG);
     stq.issue(t, lds0, rq, hm.q.bs, s3);
     sto.issue(t, lds0, rdo, hm.o.bs, s3 + 1);
     sto.issue(t, lds0, ro, hm.o.bs, s3 + 2);
@@ -149,9 +148,9 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   const bool jon = j16 < 10;
   const int jc = jon ? j16 : 9;
   float* const dl = a.delta + stat_off;              // uniform base, 32-bit per-lane index
-  // delta of tile t for query qq from the ring's dO and O tiles (every lane of the row gets the sum)
+  // delta of tile t for query qq from the ring's dO and O tiles
   auto delta_of = [&](int t) {
-    const char* st_ = ring + (t % 3) * BW_STG;
+    const char* st_ = ring + (t % BW_NSTG) * BW_STG;
     const u32x4 dc = *(const u32x4*)tile_chunk(st_ + TILE_B, qq, jc), oc = *(const u32x4*)tile_chunk(st_ + 2 * TILE_B, qq, jc);
     const float d = sum16_from8(sum8(jon ? dot8_bf16(dc, oc, 0.f) : 0.f));
     const int q = 32 * t + qq;
@@ -160,42 +159,6 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
       if (q < T) dl[q] = d;
     }
   };
-
-  // ---------------------------------------------------------------------------------------------------- prologue
-#pragma unroll
-  for (int jt = 0; jt < 8; ++jt) {
-    stq.issue(jt, ldsK, rk, hm.k.bs);
-    stq.issue(jt, ldsV, rv, hm.v.bs);
-  }
-  issue_tile(0);
-  issue_tile(1);
-  {
-    u32x4 xrow = {0, 0, 0, 0};
-    if (wid == 1 && lane < 10) xrow = hm_load16(a.k + in_off + (int64_t)256 * a.sT, lane, hm.k);
-    if (wid == 2 && lane < 10) xrow = hm_load16(a.v + in_off + (int64_t)256 * a.sT, lane, hm.v);
-    for (int t = tid; t < 288; t += 512) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
-    if (tid < 160) acc256[tid] = 0.f;
-    if ((wid == 1 || wid == 2) && lane < 10) *(u32x4*)(xk + (wid - 1) * 160 + lane * 16) = xrow;
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // The K and V rows of the own key tile (B operands of S' and dP) are re-read from the resident images every tile:
-  // 40 registers that the accumulators need more (with them in registers the build spilled 13-96 VGPRs, and every scratch
-  // reload inside the tile loop is an `s_waitcnt vmcnt(0)`, i.e. a drain of the DMA queue)
-  const char* const kt_ = kimg + wid * TILE_B;
-  const char* const vt_ = vimg + wid * TILE_B;
-  delta_of(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  BWT(0);
-  f32x16 dkt[DT], dvt[DT];
-  zero_acc<DT>(dkt);
-  zero_acc<DT>(dvt);
-  char* const mydst = dst + wid * BW_DST;
-  bf16* const dqb = a.dq + g_off;
-  const int gT = (int)a.gT;
 
   // ---- transposing-read geometry of the 16x16x32 products (natural k order: lane group kq holds k = 8 kq + e).
   // A 16 x 32 operand block read out of a 32-row tile image: rows 8 kq + q4 (+ 4), columns 16 db + 4 p .. + 3.
@@ -209,10 +172,104 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
     const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
     return __builtin_bit_cast(bf16x8, w);
   };
+
+  // ---- key 256 (the row that fits no wave) on the matrix pipe with 16x16x32 products, in two parts:
+  //   A (two waves, one query block of 16 each; a tile AHEAD): s'[q] = <Q[q], K[256]>, dp[q] = <dO[q], V[256]> (three
+  //     k-steps each, B = the key row in every column), p and dS of that key -> px (dS is also the rank-1 term of dQ);
+  //   B (five waves, one d-block of 16 each): dV[256] += dO^T p, dK[256] += Q^T dS (B = p / dS in every column) -> acc256.
+  auto key256_a = [&](int u, int qb2) {
+    const char* qt_ = ring + (u % BW_NSTG) * BW_STG;
+    const char* dt_ = qt_ + TILE_B;
+    f32x4 aS = {0, 0, 0, 0}, aD = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks3 = 0; ks3 < 3; ++ks3) {
+      const int c = 4 * ks3 + kq;                    // 16-byte chunk of the head vector (10, 11: beyond head_dim)
+      u32x4 fq = {0, 0, 0, 0}, fd = {0, 0, 0, 0}, fk = {0, 0, 0, 0}, fv = {0, 0, 0, 0};
+      if (c < 10) {
+        fq = *(const u32x4*)tile_chunk(qt_, 16 * qb2 + ti, c);
+        fd = *(const u32x4*)tile_chunk(dt_, 16 * qb2 + ti, c);
+        fk = *(const u32x4*)(xk + c * 16);
+        fv = *(const u32x4*)(xk + 160 + c * 16);
+      }
+      aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq), __builtin_bit_cast(bf16x8, fk), aS, 0, 0, 0);
+      aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fv), aD, 0, 0, 0);
+    }
+    const int q0 = 16 * qb2 + 4 * kq;                // lane (n, rq = kq): queries q0 .. q0 + 3 of the tile (every n alike)
+    const f32x4 l4 = *(const f32x4*)(lse_s + 32 * u + q0), d4 = *(const f32x4*)(del_s + 32 * u + q0);
+    f32x4 p4, s4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p4[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(aS[e], a.scale_log2, -l4[e]));
+      s4[e] = p4[e] * (aD[e] - d4[e]);
+    }
+    if (ti == 0) {
+      float* pb_ = px + (u & 1) * 64;
+      *(f32x4*)(pb_ + q0) = p4;
+      *(f32x4*)(pb_ + 32 + q0) = s4;
+    }
+  };
+  auto key256_b = [&](int t, int db) {
+    const char* qt_ = ring + (t % BW_NSTG) * BW_STG;
+    const char* dt_ = qt_ + TILE_B;
+    const float* pb_ = px + (t & 1) * 64 + 8 * kq;   // B operands: lane (n, kq) holds queries 8 kq + e, the same in every column n
+    const f32x4 a0 = *(const f32x4*)pb_, a1 = *(const f32x4*)(pb_ + 4), b0 = *(const f32x4*)(pb_ + 32), b1 = *(const f32x4*)(pb_ + 36);
+    const float pb[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const float sb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    const int lo = blk_lo(db), hi = blk_hi(db);
+    const f32x4 z = {0, 0, 0, 0};
+    const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(dt_ + lo, dt_ + hi), pack8(pb), z, 0, 0, 0);
+    const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(qt_ + lo, qt_ + hi), pack8(sb), z, 0, 0, 0);
+    if (ti == 0) {                                   // column 0 of the block: elements 16 db + 4 kq .. + 3
+      float* pk = acc256 + 16 * db + 4 * kq;
+      *(f32x4*)pk = *(const f32x4*)pk + dk;
+      *(f32x4*)(pk + 80) = *(const f32x4*)(pk + 80) + dv;
+    }
+  };
+
+  // ---------------------------------------------------------------------------------------------------- prologue
+  // K image, V image (borrowing the dS / quarter buffers) and the first three ring tiles by LDS-DMA; rows 256 of K and V
+#pragma unroll
+  for (int jt = 0; jt < 8; ++jt) {
+    stq.issue(jt, ldsK, rk, hm.k.bs);
+    stq.issue(jt, ldsV, rv, hm.v.bs);
+  }
+  issue_tile(0);
+  issue_tile(1);
+  issue_tile(2);
+  {
+    u32x4 xrow = {0, 0, 0, 0};
+    if (wid == 1 && lane < 10) xrow = hm_load16(a.k + in_off + (int64_t)256 * a.sT, lane, hm.k);
+    if (wid == 2 && lane < 10) xrow = hm_load16(a.v + in_off + (int64_t)256 * a.sT, lane, hm.v);
+    for (int t = tid; t < 288; t += 512) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
+    if (tid < 160) acc256[tid] = 0.f;
+    if ((wid == 1 || wid == 2) && lane < 10) *(u32x4*)(xk + (wid - 1) * 160 + lane * 16) = xrow;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // The V rows of the own key tile (B operand of dP) live in registers; the K rows (B operand of S') are re-read from the
+  // resident K image every tile (both in registers: 13-96 spilled VGPRs, and every scratch reload inside the tile loop is
+  // an `s_waitcnt vmcnt(0)`, i.e. a drain of the DMA queue)
+  bf16x8 vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) vf[ks] = rowfrag(dsb + wid * TILE_B, fa, ks);
+  const char* const kt_ = kimg + wid * TILE_B;
+  delta_of(0);
+  delta_of(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // the V image is dead; delta of tiles 0, 1 is visible
+  if (wid < 2) key256_a(0, wid);                     // (visible after the first tile's barrier)
+
+  BWT(0);
+  f32x16 dkt[DT], dvt[DT];
+  zero_acc<DT>(dkt);
+  zero_acc<DT>(dvt);
+  bf16* const dqb = a.dq + g_off;
+  const int gT = (int)a.gT;
+
   // ---- dQ^T = K^T dS^T in ten blocks of 16 d x 16 queries (block bi: d-block bi % 5, query block bi / 5).  Wave w owns
   // block w over the whole key range (8 k-steps); blocks 8 and 9 are cut into four key quarters of 2 k-steps, wave w takes
   // quarter w >> 1 of block 8 + (w & 1): ten k-steps per wave.  The quarters meet in LDS (f32, 1 KiB each) and are
-  // summed in quarter order by waves 0 / 1 at the start of the next tile.
+  // summed in quarter order by waves 0 / 1 after the next barrier.
   //   A = K^T block out of K tile kt; B = dS^T block out of wave kt's dS tile: rows 8 kq + q4 (+ 4), 32-byte half
   //   qb ^ (row >> 3 & 1), bytes 8 p ..
   const int bi0 = wid, bi1 = 8 + (wid & 1);
@@ -221,109 +278,34 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   // a block's accumulator: lane (n = ti, rq = kq) holds elements 16 db + 4 rq .. + 3 of query position 16 qb + n of the tile
   const int qpos16 = 4 * (ti >> 3) + (ti & 3) + 8 * ((ti & 7) >> 2);       // + 16 qb
   u32x2 pend = {0, 0};                               // dq piece of the previous tile (own block), stored one tile late
-  int pend_off = -1, pend2_off = -1;                 // element offsets of the rows in dq (-1: nothing pending)
-  auto dq_block = [&](int t, int ka_lo, int ka_hi, int kb, int kt0, int nk, int db, int qb, bool rank1) {
-    f32x4 acc = {0, 0, 0, 0};
-#pragma unroll 4
-    for (int k = 0; k < nk; ++k) {
-      const char* kp = kimg + (kt0 + k) * TILE_B;
-      const char* sp = dst + (kt0 + k) * BW_DST + kb;
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + ka_lo, kp + ka_hi), tr8(sp, sp + 256), acc, 0, 0, 0);
-    }
-    if (rank1) {                                     // dS of key 256 for this query: rank-1 term of dQ
-      const float sk = pxs[16 * qb + qpos16];
-      const u32x2 k2 = *(const u32x2*)(xk + (16 * db + 4 * kq) * 2);
-      acc[0] += sk * bf_lo(k2[0]); acc[1] += sk * bf_hi(k2[0]); acc[2] += sk * bf_lo(k2[1]); acc[3] += sk * bf_hi(k2[1]);
-    }
-    (void)t;
-    return acc;
+  auto rank1 = [&](f32x4& acc, int t, int db, int qb) {   // dS of key 256 for this query: rank-1 term of dQ
+    const float sk = px[(t & 1) * 64 + 32 + 16 * qb + qpos16];
+    const u32x2 k2 = *(const u32x2*)(xk + (16 * db + 4 * kq) * 2);
+    acc[0] += sk * bf_lo(k2[0]); acc[1] += sk * bf_hi(k2[0]); acc[2] += sk * bf_lo(k2[1]); acc[3] += sk * bf_hi(k2[1]);
   };
   auto pack_scaled = [&](const f32x4 v) {
     const bf16x4 o = {(bf16)(v[0] * a.scale), (bf16)(v[1] * a.scale), (bf16)(v[2] * a.scale), (bf16)(v[3] * a.scale)};
     return __builtin_bit_cast(u32x2, o);
   };
-  auto store_pending = [&]() {
-    if (pend_off >= 0) {
+  auto store_pending = [&](int tprev) {              // dq of tile tprev: the own block, and (waves 0 / 1) blocks 8 / 9
+    if (tprev < 0) return;
+    const int q0 = 32 * tprev + 16 * (bi0 / 5) + qpos16, q1 = 32 * tprev + 16 + qpos16;   // (recomputed: two registers less)
+    if (q0 < T) {
       const int d0 = 16 * (bi0 % 5) + 4 * kq;
-      hm_store8_at(dqb, pend_off, d0 >> 3, (d0 >> 2) & 1, pend, hm.q);
+      hm_store8_at(dqb, q0 * gT, d0 >> 3, (d0 >> 2) & 1, pend, hm.q);
     }
-    if (wid < 2 && pend2_off >= 0) {                 // blocks 8 / 9 of the previous tile: the four key quarters, in order
-      const f32x4* q4p = (const f32x4*)pq + wid * 256 + lane;
+    if (wid < 2 && q1 < T) {                         // the four key quarters, in quarter order
+      const f32x4* q4p = (const f32x4*)pq + (tprev & 1) * 512 + wid * 256 + lane;
       const f32x4 sum = ((q4p[0] + q4p[64]) + q4p[128]) + q4p[192];
       const int d0 = 16 * (3 + wid) + 4 * kq;
-      hm_store8_at(dqb, pend2_off, d0 >> 3, (d0 >> 2) & 1, pack_scaled(sum), hm.q);
-    }
-  };
-
-  // ---- key 256 (the row that fits no wave) by ONE wave per tile, on the matrix pipe with 16x16x32 products:
-  //   s'[q] = <Q[q], K[256]>, dp[q] = <dO[q], V[256]>   (two query blocks x three k-steps, B = the key row in every column)
-  //   p, dS of that key for the 32 queries -> LDS (pxp, pxs; pxs is also the rank-1 term of dQ)
-  //   dV[256] += dO^T p, dK[256] += Q^T dS               (five d-blocks each, B = p / dS in every column) -> acc256 in LDS
-  auto key256 = [&](int t, const char* qt_, const char* dt_) {
-#pragma unroll
-    for (int qb2 = 0; qb2 < 2; ++qb2) {
-      f32x4 aS = {0, 0, 0, 0}, aD = {0, 0, 0, 0};
-#pragma unroll
-      for (int ks3 = 0; ks3 < 3; ++ks3) {
-        const int c = 4 * ks3 + kq;                  // 16-byte chunk of the head vector (10, 11: beyond head_dim)
-        u32x4 fq = {0, 0, 0, 0}, fd = {0, 0, 0, 0}, fk = {0, 0, 0, 0}, fv = {0, 0, 0, 0};
-        if (c < 10) {
-          fq = *(const u32x4*)tile_chunk(qt_, 16 * qb2 + ti, c);
-          fd = *(const u32x4*)tile_chunk(dt_, 16 * qb2 + ti, c);
-          fk = *(const u32x4*)(xk + c * 16);
-          fv = *(const u32x4*)(xk + 160 + c * 16);
-        }
-        aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fq), __builtin_bit_cast(bf16x8, fk), aS, 0, 0, 0);
-        aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fv), aD, 0, 0, 0);
-      }
-      const int q0 = 16 * qb2 + 4 * kq;              // lane (n, rq = kq): queries q0 .. q0 + 3 of the tile (every n alike)
-      const f32x4 l4 = *(const f32x4*)(lse_s + 32 * t + q0), d4 = *(const f32x4*)(del_s + 32 * t + q0);
-      f32x4 p4, s4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p4[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(aS[e], a.scale_log2, -l4[e]));
-        s4[e] = p4[e] * (aD[e] - d4[e]);
-      }
-      if (ti == 0) {
-        *(f32x4*)(pxp + q0) = p4;
-        *(f32x4*)(pxs + q0) = s4;
-      }
-    }
-    // B operands: lane (n, kq) holds queries 8 kq + e, the same in every column n
-    float pb[8], sb[8];
-    {
-      const f32x4 a0 = *(const f32x4*)(pxp + 8 * kq), a1 = *(const f32x4*)(pxp + 8 * kq + 4);
-      const f32x4 b0 = *(const f32x4*)(pxs + 8 * kq), b1 = *(const f32x4*)(pxs + 8 * kq + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { pb[e] = a0[e]; pb[4 + e] = a1[e]; sb[e] = b0[e]; sb[4 + e] = b1[e]; }
-    }
-    const bf16x8 bp = pack8(pb), bs = pack8(sb);
-#pragma unroll
-    for (int db = 0; db < 5; ++db) {
-      const int lo = blk_lo(db), hi = blk_hi(db);
-      const f32x4 z = {0, 0, 0, 0};
-      const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(dt_ + lo, dt_ + hi), bp, z, 0, 0, 0);
-      const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(qt_ + lo, qt_ + hi), bs, z, 0, 0, 0);
-      if (ti == 0) {                                 // column 0 of the block: elements 16 db + 4 kq .. + 3
-        float* pk = acc256 + 16 * db + 4 * kq;
-        *(f32x4*)pk = *(const f32x4*)pk + dk;
-        *(f32x4*)(pk + 80) = *(const f32x4*)(pk + 80) + dv;
-      }
+      hm_store8_at(dqb, q1 * gT, d0 >> 3, (d0 >> 2) & 1, pack_scaled(sum), hm.q);
     }
   };
 
   for (int t = 0; t < nt; ++t) {
-    // ---- [a_t] tiles t and t + 1 have landed; every wave is done with tile t - 1, the dS tiles and the dQ quarters
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    BWT(1);
-    store_pending();
-    if (t + 2 < nt) issue_tile(t + 2);
-    const char* qt_ = ring + (t % 3) * BW_STG;
+    const char* qt_ = ring + (t % BW_NSTG) * BW_STG;
     const char* dt_ = qt_ + TILE_B;
-    if (t + 1 < nt) delta_of(t + 1);                 // one tile ahead: visible after this tile's barriers
-    if (wid == 2 + t % 6) key256(t, qt_, dt_);
-    BWT(8);
+    char* const mydst = dsb + (t & 1) * (WAVES * BW_DST) + wid * BW_DST;
 
     // ---- S' and dP (query on the accumulator row, key on the lane)
     f32x16 x, dp;
@@ -332,7 +314,7 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_, fa, ks), rowfrag(kt_, fa, ks), x, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(dt_, fa, ks), rowfrag(vt_, fa, ks), dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(dt_, fa, ks), vf[ks], dp, 0, 0, 0);
     }
     BWT(2);
     float ps[16], ds[16];
@@ -356,10 +338,16 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
       *(bf16x8*)(mydst + r * 64 + (sw * 32) + half * 16) = s0;
       *(bf16x8*)(mydst + r * 64 + ((sw ^ 1) * 32) + half * 16) = s1;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     BWT(3);
-    __builtin_amdgcn_s_barrier();                    // ---- [b_t] the eight dS tiles, pxs and delta of the next tile are in LDS
+    // ---- [b_t] the ONE barrier of a tile.  Before it: this wave's dS tile, its share of tile t + 2 (DMA issued a tile
+    // ago), delta of tile t + 1 and px of tile t are complete; after it: all of that is visible, and every wave is done
+    // with tile t - 1 (its ring stage, dS buffer, quarters, px buffer may be overwritten)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     BWT(7);
+    store_pending(t - 1);
+    if (t + 3 < nt) issue_tile(t + 3);
+    BWT(8);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dt_, fa, d, 0), p0, dvt[d], 0, 0, 0);
@@ -368,21 +356,42 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
       dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_, fa, d, 1), s1, dkt[d], 0, 0, 0);
     }
     BWT(4);
-    // ---- dQ^T: the own block over all keys, a key quarter of block 8 / 9
+    // ---- dQ^T: the own block over all keys (two accumulation chains), a key quarter of block 8 / 9
     {
-      const f32x4 own = dq_block(t, ka_lo0, ka_hi0, kb0, 0, 8, bi0 % 5, bi0 / 5, true);
-      const int qloc = 16 * (bi0 / 5) + qpos16;
+      const char* dsr = dsb + (t & 1) * (WAVES * BW_DST);
+      f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+#pragma unroll 2
+      for (int k = 0; k < 8; k += 2) {
+        const char* kp = kimg + k * TILE_B;
+        const char* sp = dsr + k * BW_DST + kb0;
+        e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + ka_lo0, kp + ka_hi0), tr8(sp, sp + 256), e0, 0, 0, 0);
+        e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + TILE_B + ka_lo0, kp + TILE_B + ka_hi0), tr8(sp + BW_DST, sp + BW_DST + 256), e1, 0, 0, 0);
+      }
+      f32x4 own = e0 + e1;
+      rank1(own, t, bi0 % 5, bi0 / 5);
       pend = pack_scaled(own);
-      pend_off = 32 * t + qloc < T ? (32 * t + qloc) * gT : -1;
-      const f32x4 part = dq_block(t, ka_lo1, ka_hi1, kb1, 2 * (wid >> 1), 2, bi1 % 5, 1, wid < 2);
-      ((f32x4*)pq)[(wid & 1) * 256 + (wid >> 1) * 64 + lane] = part;
-      pend2_off = 32 * t + 16 + qpos16 < T ? (32 * t + 16 + qpos16) * gT : -1;
+      const int k2 = 2 * (wid >> 1);
+      const char* kp = kimg + k2 * TILE_B;
+      const char* sp = dsr + k2 * BW_DST + kb1;
+      const f32x4 z = {0, 0, 0, 0};
+      f32x4 part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + ka_lo1, kp + ka_hi1), tr8(sp, sp + 256), z, 0, 0, 0);
+      part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + TILE_B + ka_lo1, kp + TILE_B + ka_hi1), tr8(sp + BW_DST, sp + BW_DST + 256), part, 0, 0, 0);
+      if (wid < 2) rank1(part, t, bi1 % 5, 1);
+      ((f32x4*)pq)[(t & 1) * 512 + (wid & 1) * 256 + (wid >> 1) * 64 + lane] = part;
     }
     BWT(5);
+    // ---- row-wise work for later tiles: delta two tiles ahead; key 256: part A one tile ahead, part B for this tile
+    if (t + 2 < nt) delta_of(t + 2);
+    {
+      const int role = (wid - 2 * t) & 7;            // rotates over the waves: 0, 1 = part A (query block), 2..6 = part B (d-block)
+      if (role < 2) { if (t + 1 < nt) key256_a(t + 1, role); }
+      else if (role < 7) key256_b(t, role - 2);
+    }
+    BWT(6);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                      // the last tile's dQ quarters; every wave is past its ring / image reads
-  store_pending();
+  __builtin_amdgcn_s_barrier();                      // the last tile's dQ quarters and acc256 are complete
+  store_pending(nt - 1);
 
   // ---------------------------------------------------------------------------------------------------- epilogue
   {
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
     store_rows16(a.dk + g_off + (int64_t)ki * a.gT, dkt, a.scale, half, hm.k);
     store_rows16(a.dv + g_off + (int64_t)ki * a.gT, dvt, 1.0f, half, hm.v);
   }
-  if (tid < 160) {                                   // dK[256] | dV[256] (acc256: written by one wave per tile, in tile order)
+  if (tid < 160) {                                   // dK[256] | dV[256] (acc256: one wave per d-block and tile, in tile order)
     const bool isv = tid >= 80;
     const int e = isv ? tid - 80 : tid;
     bf16* row = (isv ? a.dv : a.dk) + g_off + (int64_t)256 * a.gT;

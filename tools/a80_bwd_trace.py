@@ -17,7 +17,7 @@ raw = ctypes.CDLL(out)
 raw.octic_dbg_a80_bwd_trace.restype = ctypes.c_void_p
 hip = ctypes.CDLL("libamdhip64.so")
 B, H, T, hd = 64, 16, 257, 80
-names = ["prologue", "wait+bar a", "S' dP", "softmax+dS", "dV dK", "dQp mfma", "park", "bar b", "reduce+k256", "epilogue", "total"]
+names = ["prologue", "-", "S' dP", "softmax+dS", "dV dK", "dQ blocks", "delta+k256", "wait+barrier", "stores+DMA", "epilogue", "total"]
 for packed in (False, True):
     if packed:
         c = 10 * H
