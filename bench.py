@@ -100,8 +100,10 @@ def main():
     ap.add_argument("--no-wgrad-slabs", action="store_true",
                     help="developer A/B: library weight gradients as one GEMM instead of a batched GEMM over row slabs")
     ap.add_argument("--lib-wgrad", action="store_true",
-                    help="developer A/B: every standard-half weight gradient on the BLAS library (default: functional.WGRAD_HIP "
-                         "shapes on csrc/dense_wgrad.hip)")
+                    help="developer A/B: every standard-half weight gradient on the BLAS library (default: csrc/dense_wgrad.hip "
+                         "wherever ops.dense_wgrad_ok takes the shape)")
+    ap.add_argument("--no-fused-attn-bwd", action="store_true",
+                    help="developer A/B: attention backward as the dq + dkv kernel pair instead of the single-pass kernel")
     ap.add_argument("--no-packed-attn", action="store_true",
                     help="developer A/B: AttentionD8 through the pack / unpack kernels instead of the packed-row attention")
     ap.add_argument("--wgrad-f32-out", action="store_true",
@@ -160,13 +162,15 @@ def main():
         _OF.DENSE_HIP = set() if args.dense_hip == "none" else set(args.dense_hip.split(","))
     if args.no_wgrad_slabs:
         from octic_vits_amd import functional as _OF
-        _OF.WGRAD_SLABS = {}
+        _OF.WGRAD_SLABS = False
     if args.lib_wgrad:
         from octic_vits_amd import functional as _OF
-        _OF.WGRAD_HIP = set()
+        _OF.WGRAD_HIP = False
     if args.no_packed_attn:
         from octic_vits_amd import functional as _OF
         _OF.ATTN_PACKED = False
+    if args.no_fused_attn_bwd:
+        ops.ATTN_BWD_FUSED = False
     if args.wgrad_f32_out:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_F32_OUT = True
@@ -284,7 +288,8 @@ def main():
                        "library_gemm_table": bool(trainer.tuned_gemms),
                        "launch": "hipGraph replay" if graphed is not None else "eager"},
             "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),
-            "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4),
+            # (FLOP_PER_IMG_STEP is the ViT-H/14 count of SURVEY 8d: other --model choices are development figures)
+            "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4) if "huge_patch14" in args.model else None,
         }
         kern = ops.KERNEL_TIMER.summary()
         if kern:

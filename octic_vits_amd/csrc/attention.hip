@@ -37,8 +37,8 @@ __device__ __forceinline__ void stage_two(char* imgA, int rsA, const bf16* srcA,
                                           int T, int Tp, int tid, int nthr, const HeadMap mA = HeadMap{0, 0},
                                           const HeadMap mB = HeadMap{0, 0}) {
   const int c = tid & 15, t0 = tid >> 4, tstep = nthr >> 4;
-  if (mA.cv != 0) {
-    // Packed rows: stage by PIECES - a thread fetches one whole piece (20 bytes of a one-dimensional irrep: 16 + 4, or
+  if (mA.cv != 0 && kcA == 10 && kcB == 10) {
+    // Packed rows at head_dim 80: stage by PIECES - a thread fetches one whole piece (20 bytes of a one-dimensional irrep: 16 + 4, or
     // 40 bytes of an E row: 16 + 16 + 8) and spreads it over the row image's groups.  One cache-line request per
     // piece instead of one per 16-byte group (6 instead of 16 per row).
     // pads first: rows >= T, and groups >= hd / 8 of every row
@@ -131,7 +131,8 @@ __device__ __forceinline__ StageMap stage_map(int tid, int nthr, int kc) {
   return m;
 }
 __device__ __forceinline__ void stage_request(StagePlain& R, const bf16* srcA, int64_t stA, int kcA, const bf16* srcB,
-                                              int64_t stB, int kcB, int T, int tid, int nthr) {
+                                              int64_t stB, int kcB, int T, int tid, int nthr,
+                                              const HeadMap mA = HeadMap{0, 0}, const HeadMap mB = HeadMap{0, 0}) {
   const StageMap sm = stage_map(tid, nthr, kcA > kcB ? kcA : kcB);
   const int c = sm.c, t0 = sm.t0, tstep = sm.tstep;
 #pragma unroll
@@ -139,8 +140,8 @@ __device__ __forceinline__ void stage_request(StagePlain& R, const bf16* srcA, i
     const int t = t0 + it * tstep;
     R.a[it] = u32x4{0, 0, 0, 0};
     R.b[it] = u32x4{0, 0, 0, 0};
-    if (t < T && c < kcA) R.a[it] = *(const u32x4*)(srcA + (int64_t)t * stA + c * 8);
-    if (t < T && c < kcB) R.b[it] = *(const u32x4*)(srcB + (int64_t)t * stB + c * 8);
+    if (t < T && c < kcA) R.a[it] = hm_load16(srcA + (int64_t)t * stA, c, mA);       // (cv == 0: the plain 16-byte chunk)
+    if (t < T && c < kcB) R.b[it] = hm_load16(srcB + (int64_t)t * stB, c, mB);
   }
 }
 __device__ __forceinline__ void stage_write(const StagePlain& R, char* imgA, int rsA, int wcA, char* imgB, int rsB, int wcB,
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
   const int ninstr = kimg >> 10;
   const int cpr = rsk >> 4;                            // chunks per image row (data + pad)
   const bool packed = a.cv_in > 0;                     // head vectors gathered from packed LinearD8 rows (HeadMap)
+  const bool ktail_on = packed && kc > 8;              // head_dim 80: groups 8, 9 are gathered remainders (hd 64: none)
   unsigned voff[MAXI];
   unsigned emask = 0;                                  // packed mode: bit j = instruction j of this lane reads an E piece
 #pragma unroll
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
   HeadMaps hm = head_maps(a, hh);
   bf16x8 qf[KS], qfs[KS];
   issue_k(a.k + in_off, smem_lds, hm.k.bs);
-  if (packed) load_ktail(a.k + in_off, hm.k);
+  if (ktail_on) load_ktail(a.k + in_off, hm.k);
   load_v(a.v + in_off, hm.v);
   load_rows8<KS>(qf, a.q + in_off, a.sT, wid, T, lane, hm.q);
   if (nrows > 0) load_rows8<KS>(qfs, a.q + in_off, a.sT, W, T, lane, hm.q);
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
   __syncthreads();
   write_v();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (packed) write_ktail(smem);
+  if (ktail_on) write_ktail(smem);
   __syncthreads();
 
   int cur = 0;
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
       head_off(un, n_in, n_o, n_st, nh);
       nhm = head_maps(a, nh);
       issue_k(a.k + n_in, smem_lds + (cur ^ 1) * kimg, nhm.k.bs);
-      if (packed) load_ktail(a.k + n_in, nhm.k);
+      if (ktail_on) load_ktail(a.k + n_in, nhm.k);
       load_v(a.v + n_in, nhm.v);
     }
     if (tr_on) ATRACE(0, 1);
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
     if (has_next) write_v();
     if (tr_on) ATRACE(0, 6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the K DMA of the next head has landed
-    if (packed && has_next) write_ktail(smem + (cur ^ 1) * kimg);
+    if (ktail_on && has_next) write_ktail(smem + (cur ^ 1) * kimg);
     if (tr_on) ATRACE(0, 7);
     __syncthreads();
     if (tr_on) ATRACE(0, 8);
@@ -840,19 +842,19 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(AttnBwdArgs a, int rs
   // The shared ninth tile has one real row: its clamped fragment loads touch two lines.
   float* part = (float*)(smem + (size_t)2 * Tp * rs);          // [Tp][hd / 8] delta partials
   const int kc = hd / 8;
-  if (hm.q.cv == 0) {
+  if (hm.q.cv == 0 || hd != 80) {                    // plain rows, or packed rows whose 16-byte groups are whole pieces (hd 64)
     StagePlain qd, kv;
     u32x4 oo[kStageRows];
     const StageMap sm = stage_map(tid, blockDim.x, kc);
     const int c = sm.c, t0 = sm.t0, tstep = sm.tstep;
-    stage_request(qd, a.q + in_off, a.sT, kc, a.dout + o_off, a.oT, kc, T, tid, blockDim.x);
+    stage_request(qd, a.q + in_off, a.sT, kc, a.dout + o_off, a.oT, kc, T, tid, blockDim.x, hm.q, hm.o);
 #pragma unroll
     for (int it = 0; it < kStageRows; ++it) {
       const int t = t0 + it * tstep;
       oo[it] = u32x4{0, 0, 0, 0};
-      if (t < T && c < kc) oo[it] = *(const u32x4*)(a.o + o_off + (int64_t)t * a.oT + c * 8);
+      if (t < T && c < kc) oo[it] = hm_load16(a.o + o_off + (int64_t)t * a.oT, c, hm.o);
     }
-    stage_request(kv, a.k + in_off, a.sT, kc, a.v + in_off, a.sT, kc, T, tid, blockDim.x);
+    stage_request(kv, a.k + in_off, a.sT, kc, a.v + in_off, a.sT, kc, T, tid, blockDim.x, hm.k, hm.v);
     stage_write(qd, Ks, rs, kc, Vs, rs, kc, Tp, tid, blockDim.x);
 #pragma unroll
     for (int it = 0; it < kStageRows; ++it) {
@@ -1023,10 +1025,10 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(AttnBwdArgs a, int r
   // Prologue in one memory round trip (see attn_bwd_dq_kernel): K, V, Q and dO are all requested up front; the own key
   // rows' fragments are read from the LDS images of K and V, which are then overwritten with Q and dO.
   const int kc = hd / 8;
-  if (hm.q.cv == 0) {
+  if (hm.q.cv == 0 || hd != 80) {
     StagePlain kvr, qdr;
-    stage_request(kvr, a.k + in_off, a.sT, kc, a.v + in_off, a.sT, kc, T, tid, blockDim.x);
-    stage_request(qdr, a.q + in_off, a.sT, kc, a.dout + o_off, a.oT, kc, T, tid, blockDim.x);
+    stage_request(kvr, a.k + in_off, a.sT, kc, a.v + in_off, a.sT, kc, T, tid, blockDim.x, hm.k, hm.v);
+    stage_request(qdr, a.q + in_off, a.sT, kc, a.dout + o_off, a.oT, kc, T, tid, blockDim.x, hm.q, hm.o);
     stage_write(kvr, Qs, rs, kc, Ds, rs, kc, Tp, tid, blockDim.x);
     __syncthreads();
     {
@@ -1209,20 +1211,22 @@ int octic_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
 // AttentionD8 on PACKED rows (reference d8_layers.py:631-656 without the pack / unpack copies): qkv is the LinearD8
 // output [B, T, 3*8c] (row stride ld_qkv elements), o the packed [B, T, 8c] input of the output projection (row stride
 // ld_o); head h of tensor s takes c/H channels of every one-dimensional irrep and 2c/H of each E row.  c/H must be 10
-// (head_dim 80: the piece schedule of HeadMap), bf16.
+// (head_dim 80: the piece schedule of HeadMap) or 8 (head_dim 64, ViT-L/16: every 16-byte group of a head vector is a
+// whole piece - A1, A2, B1, B2, two halves of each E row - so only the g < 8 branch of HeadMap is used), bf16.
 int octic_attn_fwd_packed(const void* qkv, void* o, float* lse, int64_t B, int H, int T, int c, int64_t ld_qkv,
                           int64_t ld_o, float scale, void* stream) {
   if (!qkv || !o) return OCTIC_ENULL;
-  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || c <= 0 || c != 10 * H) return OCTIC_ESHAPE;
+  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || c <= 0 || (c != 10 * H && c != 8 * H)) return OCTIC_ESHAPE;
   if (((((uintptr_t)qkv) | ((uintptr_t)o)) & 15) || ((ld_qkv | ld_o) & 7) || ld_qkv < 24 * c || ld_o < 8 * c) return OCTIC_EALIGN;
   AttnArgs a;
   a.q = a.k = a.v = (const bf16*)qkv;
   a.sB = (int64_t)T * ld_qkv; a.sH = 0; a.sT = ld_qkv;
   a.o = (bf16*)o; a.oB = (int64_t)T * ld_o; a.oH = 0; a.oT = ld_o;
   a.lse = lse;
-  a.H = H; a.T = T; a.hd = 80;
+  a.H = H; a.T = T; a.hd = 8 * (c / H);
   a.scale_log2 = scale * 1.4426950408889634f;
   a.cv_in = 3 * c; a.cv_out = c; a.c = c;
+  if (a.hd == 64) return attn_fwd_launch<4, 2>(a, B, (hipStream_t)stream);
   return attn_fwd_launch<5, 3>(a, B, (hipStream_t)stream);
 }
 
@@ -1232,7 +1236,7 @@ int octic_attn_bwd_packed(const void* qkv, const void* o, const void* dout, cons
                           int phase, void* stream) {
   if (!qkv || !o || !dout || !lse || !delta || !dqkv) return OCTIC_ENULL;
   if (phase < 1 || phase > 3) return OCTIC_ESHAPE;
-  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || c <= 0 || c != 10 * H) return OCTIC_ESHAPE;
+  if (B <= 0 || H <= 0 || T <= 0 || T > 320 || c <= 0 || (c != 10 * H && c != 8 * H)) return OCTIC_ESHAPE;
   if (((((uintptr_t)qkv) | ((uintptr_t)o) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) || ((ld_qkv | ld_o | ld_g) & 7) ||
       ld_qkv < 24 * c || ld_g < 24 * c || ld_o < 8 * c)
     return OCTIC_EALIGN;
@@ -1241,10 +1245,11 @@ int octic_attn_bwd_packed(const void* qkv, const void* o, const void* dout, cons
   a.o = (const bf16*)o; a.dout = (const bf16*)dout; a.oB = (int64_t)T * ld_o; a.oH = 0; a.oT = ld_o;
   a.lse = lse; a.delta = delta;
   a.dq = a.dk = a.dv = (bf16*)dqkv; a.gB = (int64_t)T * ld_g; a.gH = 0; a.gT = ld_g;
-  a.H = H; a.T = T; a.hd = 80;
+  a.H = H; a.T = T; a.hd = 8 * (c / H);
   a.scale = scale;
   a.scale_log2 = scale * 1.4426950408889634f;
   a.cv_in = 3 * c; a.cv_out = c; a.c = c;
+  if (a.hd == 64) return attn_bwd_launch<4, 2>(a, B, phase, (hipStream_t)stream);
   return attn_bwd_launch<5, 3>(a, B, phase, (hipStream_t)stream);
 }
 

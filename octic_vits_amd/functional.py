@@ -713,29 +713,45 @@ def _timed_lib(kind, fn, M, N, K):
     return out
 
 
-# Row slabs of the library weight gradients.  dW [N,K] = g^T x reduces over M = 16 448 token rows into few output tiles
-# (100 tiles of 256x256 for 5120x1280: the single GEMM leaves more than a third of the 256 CUs idle and runs at 0.43-0.79
-# PFLOP/s).  As a batched GEMM over S row slabs the same library kernels fill the chip; the slab partials (bf16, like
-# the single GEMM's result) are summed in f32 by one small reduction that replaces the bf16 -> f32 cast.  Measured
-# on MI355X (tools/probe_wgrad_split.py): 311 -> 263, 284 -> 247, 217 -> 188, 124 -> 92 us.
+# Row slabs of the library weight gradients (the fallback path: shapes csrc/dense_wgrad.hip refuses, or WGRAD_HIP off).
+# dW [N,K] = g^T x reduces over the token rows into few output tiles (100 tiles of 256x256 for 5120x1280: the single GEMM
+# leaves more than a third of the 256 CUs idle and runs at 0.43-0.79 PFLOP/s).  As a batched GEMM over S row slabs the
+# same library kernels fill the chip; the slab partials (bf16, like the single GEMM's result) are summed in f32 by one
+# small reduction that replaces the bf16 -> f32 cast.  Measured on MI355X (tools/probe_wgrad_split.py): 311 -> 263,
+# 284 -> 247, 217 -> 188, 124 -> 92 us.  WGRAD_SLABS holds the measured choices; other shapes take the rule
+# "one round of 256 x 256 tiles over the CUs" (wgrad_slabs), False switches slabs off (bench.py --no-wgrad-slabs).
 WGRAD_SLABS = {(5120, 1280): 4, (1280, 5120): 4, (3840, 1280): 2, (1280, 1280): 2}
 
 
-# Weight-gradient shapes (N, K) that run on csrc/dense_wgrad.hip (dW = dY^T X straight from the row-major operands, f32
-# result, fixed-order slab reduction).  Measured against the library's batched row slabs on one MI355X (tools/bench_tn.py):
-# 5120x1280 224-234 vs 296 us, 1280x5120 211 vs 246, 3840x1280 156 vs 187, 1280x1280 93 vs 100.
-WGRAD_HIP = {(5120, 1280), (1280, 5120), (3840, 1280), (1280, 1280)}
+def wgrad_slabs(M, N, K):
+    if WGRAD_SLABS is False:
+        return 1
+    S = WGRAD_SLABS.get((N, K))
+    if S is None:
+        tiles = -(-N // 256) * -(-K // 256)
+        S = max(1, min(8, 256 // max(1, tiles)))
+    while S > 1 and M % S:
+        S -= 1
+    return S
+
+
+# Weight gradients of the standard half on csrc/dense_wgrad.hip (dW = dY^T X straight from the row-major operands, f32
+# result, fixed-order slab reduction) wherever the kernel takes the shape (ops.dense_wgrad_ok: N, K multiples of 256, at
+# most 256 output tiles - ViT-H/14, ViT-L/16, ...), not for a literal list of shapes (round-3 review).  Measured against
+# the library's batched row slabs on one MI355X (tools/bench_tn.py): 5120x1280 224-234 vs 296 us, 1280x5120 211 vs 246,
+# 3840x1280 156 vs 187, 1280x1280 93 vs 100.  False = every weight gradient on the BLAS library (bench.py --lib-wgrad).
+WGRAD_HIP = True
 
 
 def _wgrad_lib(g2, x2):
-    """dW = g^T x (f32 result): the hand-written TN kernel for the shapes in WGRAD_HIP, else the BLAS library."""
+    """dW = g^T x (f32 result): the hand-written TN kernel wherever it takes the shape, else the BLAS library."""
     M, N, K = g2.shape[0], g2.shape[1], x2.shape[1]
-    if ((N, K) in WGRAD_HIP and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+    if (WGRAD_HIP and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
             and g2.stride(1) == 1 and x2.stride(1) == 1 and ops.dense_wgrad_ok(M, N, K)
             and M * max(g2.stride(0), x2.stride(0)) * 2 < 2 ** 31):
         return ops.dense_wgrad_tn(g2, x2)
-    S = WGRAD_SLABS.get((N, K), 1)
-    if S > 1 and M % S == 0 and g2.is_contiguous() and x2.is_contiguous():
+    S = wgrad_slabs(M, N, K)
+    if S > 1 and g2.is_contiguous() and x2.is_contiguous():
         with torch.autocast("cuda", enabled=False):
             return _timed_lib("wgrad", lambda: torch.bmm(g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K))
                               .sum(0, dtype=torch.float32), M, N, K)

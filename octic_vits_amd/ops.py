@@ -448,8 +448,8 @@ def attn_bwd(q, k, v, o, dout, lse, scale, dq, dk, dv):
 
 
 def attn_packed_ok(T, c, H, dtype):
-    """Shapes of octic_attn_{fwd,bwd}_packed: bf16, head_dim 80 (c = 10 H), T <= 320."""
-    return dtype == torch.bfloat16 and c == 10 * H and 0 < T <= 320 and attn_supported(T, 80, dtype)
+    """Shapes of octic_attn_{fwd,bwd}_packed: bf16, head_dim 80 (c = 10 H: ViT-H/14) or 64 (c = 8 H: ViT-L/16), T <= 320."""
+    return dtype == torch.bfloat16 and c in (10 * H, 8 * H) and 0 < T <= 320 and attn_supported(T, 8 * (c // H), dtype)
 
 
 def attn_fwd_packed(qkv, H, c, scale):
@@ -469,7 +469,7 @@ def attn_bwd_packed(qkv, o, dout, lse, H, c, scale):
     B, T = qkv.shape[0], qkv.shape[1]
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
-    for phase, name, nbytes, flops in _attn_bwd_phases(T, 80):
+    for phase, name, nbytes, flops in _attn_bwd_phases(T, 8 * (c // H)):
         t = KERNEL_TIMER.start()
         check(lib().octic_attn_bwd_packed(_p(qkv), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, H, T, c, qkv.stride(1),
                                           o.stride(1), dqkv.stride(1), float(scale), phase, _stream(qkv)))

@@ -92,22 +92,24 @@ def test_attn_fused_qkv_function_matches_reference():
     assert float((qkv.grad.float() - ref.grad).abs().max()) <= 3e-2 * scale
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 257, 16), (3, 197, 16), (1, 64, 4), (2, 33, 8)])
-def test_packed_attention_matches_pack_attention_unpack(B, T, H):
+@pytest.mark.parametrize("B,T,H,w", [(2, 257, 16, 10), (3, 197, 16, 10), (1, 64, 4, 10), (2, 33, 8, 10),
+                                     (3, 197, 16, 8), (2, 257, 16, 8), (1, 64, 4, 8)])
+def test_packed_attention_matches_pack_attention_unpack(B, T, H, w):
     """octic_attn_{fwd,bwd}_packed (AttentionD8 between its two linears, reference d8_layers.py:631-656, on the packed rows)
     against the three-step path it replaces: pack kernels (bit-exact vs the oracle's pack_heads, test_kernels_gpu) ->
     attention kernels on [B,H,T,80] -> unpack.  Same arithmetic per head in a different element order inside the dot
     products: outputs and gradients agree to bf16 rounding (2e-2 of scale)."""
     from octic_vits_amd import functional as OF, ops
-    c = 10 * H
+    c = w * H                                    # w = 10: head_dim 80 (ViT-H/14); w = 8: head_dim 64 (ViT-L/16), round 4
+    hd = 8 * w
     torch.manual_seed(B * 1000 + T)
     qkv = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16().requires_grad_(True)
     do = torch.randn(B, T, 8 * c, device="cuda").bfloat16()
     assert ops.attn_packed_ok(T, c, H, qkv.dtype)
-    o1 = OF.AttnPackedFn.apply(qkv, H, c, 80 ** -0.5)
+    o1 = OF.AttnPackedFn.apply(qkv, H, c, hd ** -0.5)
     (g1,) = torch.autograd.grad(o1, qkv, do)
     q, k, v = OF.PackHeadsFn.apply(qkv, H, c)
-    o2 = OF.UnpackHeadsFn.apply(OF.AttnFn.apply(q, k, v, 80 ** -0.5), c)
+    o2 = OF.UnpackHeadsFn.apply(OF.AttnFn.apply(q, k, v, hd ** -0.5), c)
     (g2,) = torch.autograd.grad(o2, qkv, do)
     for a, b, name in ((o1, o2, "o"), (g1, g2, "dqkv")):
         a, b = a.float(), b.float()
