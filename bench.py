@@ -72,6 +72,37 @@ def cpu_baseline(batch=4, steps=2):
                       f"{steps} timed step(s) after 1 warm-up, CPU oracle (oracle/octic_ref.py)"}
 
 
+def step_variants(trainer, model, samples, targets, args, n=8):
+    """How the SAME step runs when it cannot be one hipGraph (N > 1 GPUs, gradient accumulation): launched eagerly, and as
+    segment graphs (train.SegmentedModel: 2 x 8 graph replays + eager loss / hooks / optimizer).  Measured after the timed
+    region on the same weights, so that the 1-GPU line says what the N > 1 lines should be compared with; `*_host_issue` is the
+    host time to enqueue a step (no sync inside the loop): a step is host-bound when it approaches the step time."""
+    from octic_vits_amd.train import Trainer
+
+    def timed(tr):
+        for _ in range(2):
+            tr.step(samples, targets)
+        torch.cuda.synchronize()
+        w0 = tr._watch.wait_s
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(samples, targets)
+        issued = time.perf_counter() - t0 - (tr._watch.wait_s - w0)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, issued / n * 1e3
+
+    out = {}
+    ms, host = timed(trainer)
+    out["eager_ms_per_step"], out["eager_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
+    del trainer
+    seg = Trainer(model, segment_graphs=8)           # (re-links the blocks inside the slices: keep this last)
+    seg.step(samples, targets)
+    seg.capture_segments(samples)
+    ms, host = timed(seg)
+    out["segment_graph_ms_per_step"], out["segment_graph_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
+    return out
+
+
 def _baseline_metric():
     """BASELINE.json's metric string, verbatim (the driver matches on it)."""
     try:
@@ -121,6 +152,14 @@ def main():
     ap.add_argument("--accum", type=int, default=1,
                     help="micro-batches of --batch images per optimizer step (gradient accumulation; BASELINE configs[2] "
                          "= --gpus 8 --batch 64 --accum 4: global batch 2048)")
+    ap.add_argument("--segment-graphs", type=int, default=None,
+                    help="forward / backward as 2 n hipGraph replays (train.SegmentedModel), loss + gradient hooks + optimizer "
+                         "eager (default 0: off; the step is ONE graph at 1 GPU and eager launches at N > 1)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="developer: wrap the model in DistributedDataParallel at world size 1 (one-rank RCCL group): the N > 1 "
+                         "code path on one GPU")
+    ap.add_argument("--no-step-variants", action="store_true",
+                    help="skip the extra figures of the 1-GPU line (eager_ms_per_step, segment_graph_ms_per_step)")
     ap.add_argument("--bucket-mb", type=int, default=None, help="DDP gradient bucket size (default: train.DDP_BUCKET_MB)")
     ap.add_argument("--bf16-buckets", action="store_true", help="all-reduce the gradient buckets in bf16")
     args = ap.parse_args()
@@ -174,7 +213,10 @@ def main():
     if args.wgrad_f32_out:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_F32_OUT = True
-    world, rank, local_rank = init_distributed()
+    if args.force_ddp and "WORLD_SIZE" not in os.environ:
+        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
+    world, rank, local_rank = init_distributed(force=args.force_ddp)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", local_rank)
@@ -184,8 +226,14 @@ def main():
     model = create_model(args.model, num_classes=1000, drop_path_rate=0.5, img_size=224).to(dev)
     log("model on device")
     tkw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
-    trainer = Trainer(model, distributed=world > 1, local_rank=local_rank, accum_steps=args.accum,
-                      bf16_buckets=args.bf16_buckets, **tkw)
+    ddp = world > 1 or args.force_ddp
+    one_graph = not ddp and args.accum == 1 and not args.no_graph
+    # segment graphs are opt-in: on one MI355X the 2 x 8 replays run the step in 75.7 ms against 67.8 ms for eager launches
+    # (gradient clones out of the static buffers, cut fusion links, per-slice mask pools) - they pay once the eager step
+    # is host-bound (tools/host_profile.py: ~45 ms of Python / ctypes per step), which at 67 ms of kernels it is not
+    nseg = args.segment_graphs or 0
+    trainer = Trainer(model, distributed=ddp, local_rank=local_rank, accum_steps=args.accum,
+                      bf16_buckets=args.bf16_buckets, segment_graphs=nseg, **tkw)
     samples, targets = synthetic_batch(args.batch * args.accum, 1000, dev, 4242 + rank)
     n_ranks_seen = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
 
@@ -200,7 +248,13 @@ def main():
             torch.cuda.synchronize()
             log("first warm-up step done")
     graphed = None
-    if world == 1 and not args.no_graph and args.accum == 1:
+    if nseg:
+        trainer.capture_segments(samples[:args.batch])
+        for _ in range(2):
+            trainer.step(samples, targets)
+        torch.cuda.synchronize()
+        log(f"forward / backward captured as {len(trainer.segmented._segments)} x 2 hipGraphs")
+    if one_graph and not nseg:
         try:
             graphed = trainer.capture(samples, targets, warmup=1)
             for _ in range(2):
@@ -220,10 +274,13 @@ def main():
     # no host read of the loss inside it (train._LossWatch checks two steps late on a pinned copy).  The per-kernel HIP
     # events (~1800 records per step, which slow a step by ~20 %) are taken AFTER it, in the same process on the same
     # weights: see `step_breakdown.note`.
+    w0 = trainer._watch.wait_s
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = graphed.replay() if graphed is not None else trainer.step(samples, targets)
-    issued = time.perf_counter() - t0          # host time to enqueue the steps (no sync inside): launch-bound if ~ elapsed
+    # host time to ENQUEUE the steps: wall time of the loop minus the time the loss watch spent waiting for the event of
+    # the step two back (that wait only keeps the host from running more than two steps ahead).  Host-bound if ~ elapsed.
+    issued = time.perf_counter() - t0 - (trainer._watch.wait_s - w0)
     sync()
     elapsed = time.perf_counter() - t0
     sampled = []
@@ -286,7 +343,9 @@ def main():
                        "global_batch": world * args.batch * args.accum, "per_gpu_batch": args.batch,
                        "accum_steps": args.accum, "parallelism": f"dp{world}",
                        "library_gemm_table": bool(trainer.tuned_gemms),
-                       "launch": "hipGraph replay" if graphed is not None else "eager"},
+                       "launch": "hipGraph replay (whole step)" if graphed is not None else
+                                 (f"{len(trainer.segmented._segments)} x 2 segment hipGraphs + eager loss / all-reduce hooks / optimizer"
+                                  if nseg else "eager")},
             "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),
             # (FLOP_PER_IMG_STEP is the ViT-H/14 count of SURVEY 8d: other --model choices are development figures)
             "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4) if "huge_patch14" in args.model else None,
@@ -399,6 +458,8 @@ def main():
                                               "iterations with no event records and no host read; other = ATen glue + optimizer"}
         if fwd_only is not None:
             line["extra"] = {"forward_only": fwd_only}
+        if world == 1 and not ddp and graphed is not None and not args.no_step_variants:
+            line.update(step_variants(trainer, model, samples, targets, args))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -369,6 +369,132 @@ def octic_weight_preps(model):
     return [m._prep for m in model.modules() if isinstance(m, LinearD8)]
 
 
+class _Segment(nn.Module):
+    """A tensor-in / tensor-out slice of an OcticVisionTransformer: blocks[lo:hi], plus the patch embedding in front of
+    the first slice and the final norm + pooling + head behind the last one.  The blocks (and, for the first / last slice,
+    the embedding parameters and the head) are the MODEL's own modules, registered here a second time only so that
+    ``parameters()`` lists exactly what this slice touches - ``torch.cuda.make_graphed_callables`` captures one forward
+    and one backward hipGraph per slice with those parameters as the static input surface."""
+
+    def __init__(self, model, lo, hi, first, last):
+        super().__init__()
+        self.blocks = nn.ModuleList(model.blocks[lo:hi])
+        self.first, self.last, self.lo, self.hi = first, last, lo, hi
+        self.brk = model.octic_equi_break_layer
+        object.__setattr__(self, "_model", model)       # not a sub-module (the model owns these modules)
+        if first:
+            self.patch_embed, self.pos_embed, self.cls_token = model.patch_embed, model.pos_embed, model.cls_token
+        if lo < self.brk <= hi and model.invariant:
+            self.invariantization, self.invariant_proj = model.invariantization, model.invariant_proj
+        if last:
+            self.norm, self.head = model.norm, model.head
+
+    def forward(self, x):
+        from .d8_layers import arm_drop_path_pool
+        from .d8_utils import packed_pos_embed
+        from . import functional as OF
+        m = self._model
+        c = m.embed_dim // 8
+        # autocast without the weight cache (a captured slice must not depend on a cache another slice filled)
+        with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=False):
+            arm_drop_path_pool(True)                    # every slice draws its own pool of drop-path masks
+            try:
+                if self.first:
+                    pos = packed_pos_embed(m.pos_embed)
+                    cls_row = None if m.global_pool else m._cls_row()
+                    x = m.patch_embed.tokens(x, pos, cls_row)
+                for i, blk in enumerate(self.blocks):
+                    j = self.lo + i
+                    if j < self.brk:
+                        xs = blk(x if isinstance(x, OF.Octic) else OF.Octic(x, c))
+                        x = xs
+                        if j + 1 == self.brk:           # hand-off to the standard half (model.py:196-200)
+                            if m.invariant:
+                                x = m.invariant_proj(m.invariantization(xs, _out_dtype=OF.compute_dtype(xs.packed)))
+                            else:
+                                x = OF.HandoffCatFn.apply(xs.packed, c, xs.packed.dtype)
+                    else:
+                        x = blk(x)
+                if isinstance(x, OF.Octic):
+                    x = x.packed
+                if self.last:
+                    if m.dropout_rate:
+                        raise RuntimeError("SegmentedModel: dropout in front of the head is applied by the wrapper; "
+                                           "slice the model with the head outside or set dropout_rate = 0")
+                    x = m.norm(x)
+                    x = x.mean(dim=1) if m.global_pool else x[:, 0]
+                    x = m.head(x)
+            finally:
+                arm_drop_path_pool(False)
+        return x
+
+
+class SegmentedModel(nn.Module):
+    """The model as a chain of ``n_segments`` slices (``_Segment``) whose forward and backward are hipGraphs.
+
+    Why: a captured WHOLE step (``Trainer.capture``) cannot contain DDP's bucketed all-reduce, so with N > 1 the step was
+    issued eagerly - ~45 ms of Python / ctypes / autograd per step against ~66 ms of kernels (round-3 review, item 4).
+    Here forward and backward are 2 x n_segments graph launches; what stays eager is what has to: the loss, autograd's
+    gradient accumulation (where DDP's hooks fire, slice by slice, so the all-reduce of a slice's buckets overlaps the
+    backward graphs of the slices in front of it) and the fused optimizer.  The fused residual + next-LayerNorm links
+    (vit.link_blocks / d8_layers.link_octic_blocks) are cut at the slice boundaries (the carried norm is not a tensor in
+    the slice's signature): one extra LayerNorm pass per boundary; the eager run of a SegmentedModel has the same links,
+    so graphed and eager steps are bitwise equal."""
+
+    def __init__(self, model, n_segments=8):
+        super().__init__()
+        from .vit import link_blocks
+        from .d8_layers import link_octic_blocks
+        self.model = model
+        nb, brk = len(model.blocks), model.octic_equi_break_layer
+        n_segments = max(1, min(int(n_segments), nb))
+        # boundaries: evenly spaced, and the octic / standard hand-off is always one of them
+        cuts = sorted(set([0, nb] + [round(i * nb / n_segments) for i in range(1, n_segments)] + ([brk] if 0 < brk < nb else [])))
+        segs = [_Segment(model, lo, hi, lo == 0, hi == nb) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        object.__setattr__(self, "_segments", segs)     # share the model's modules: not registered twice under this module
+        for b in model.blocks:                          # re-link inside the slices only
+            if hasattr(b, "_next_norm"):
+                del b._next_norm
+        for sg in segs:
+            link_octic_blocks([b for j, b in zip(range(sg.lo, sg.hi), sg.blocks) if j < brk])
+            link_blocks([b for j, b in zip(range(sg.lo, sg.hi), sg.blocks) if j >= brk])
+        self.graphed = False
+
+    def no_weight_decay(self):
+        return {"model." + n for n in self.model.no_weight_decay()} | set(self.model.no_weight_decay())
+
+    def train(self, mode=True):
+        super().train(mode)
+        for sg in self._segments:                       # (a graphed slice replays its graphs only in the mode it was captured in)
+            sg.training = mode
+        return self
+
+    def forward(self, x):
+        for sg in self._segments:
+            x = sg(x)
+        if self.model.dropout_rate:
+            x = torch.nn.functional.dropout(x, p=float(self.model.dropout_rate), training=self.training)
+        return x
+
+    def capture(self, samples, warmup=3):
+        """Replace every slice's forward / backward by hipGraph replays (static shapes: those of ``samples``)."""
+        if self.graphed:
+            return self
+        self.train()
+        for sg in self._segments:
+            sg.train()
+        args, x = [], samples
+        with torch.no_grad():
+            for sg in self._segments:
+                args.append((x.detach().clone().requires_grad_(not sg.first),))
+                x = sg(x)
+        torch.cuda.synchronize()
+        graphed = torch.cuda.make_graphed_callables(tuple(self._segments), tuple(args), num_warmup_iters=warmup)
+        object.__setattr__(self, "_segments", list(graphed))
+        self.graphed = True
+        return self
+
+
 class _LossWatch:
     """The non-finite-loss check of deit/engine.py:67-71 without a per-step stream drain.
 
@@ -384,6 +510,7 @@ class _LossWatch:
         self.cuda = device_type == "cuda"
         self.lag = lag
         self.n = 0
+        self.wait_s = 0.0                               # host time spent waiting for a two-steps-old event (throttle, not issue cost)
         if self.cuda:
             self.host = torch.zeros(lag + 1, dtype=torch.float32).pin_memory()
             self.events = [torch.cuda.Event() for _ in range(lag + 1)]
@@ -408,7 +535,11 @@ class _LossWatch:
         slot = k % (self.lag + 1)
         if self.cuda:
             if block:
-                self.events[slot].synchronize()
+                if not self.events[slot].query():
+                    import time
+                    t0 = time.perf_counter()
+                    self.events[slot].synchronize()
+                    self.wait_s += time.perf_counter() - t0
             elif not self.events[slot].query():
                 return
         if not math.isfinite(float(self.host[slot])):
@@ -433,10 +564,16 @@ class Trainer:
 
     def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
                  fused_optimizer=True, tuned_gemms=True, opt_eps=1e-8, accum_steps=1, bf16_buckets=False,
-                 autocast=True, check_every=1, device_type=None, bucket_cap_mb=None):
+                 autocast=True, check_every=1, device_type=None, bucket_cap_mb=None, segment_graphs=0):
+        """segment_graphs = n > 0 (GPU only): forward and backward run as 2 n hipGraph replays (``SegmentedModel``), the
+        loss, the gradient all-reduce hooks and the optimizer stay eager - the cheap-on-the-host step for N > 1 GPUs and
+        for gradient accumulation, where the whole-step graph of ``capture`` does not apply."""
         self.raw_model = model
+        self.segmented = None
+        if segment_graphs:
+            self.segmented = SegmentedModel(model, segment_graphs)
         self.tuned_gemms = use_tuned_gemms() if (tuned_gemms and torch.cuda.is_available()) else False
-        self.model = model
+        self.model = self.segmented if self.segmented is not None else model
         self.accum_steps = int(accum_steps)
         self.device_type = device_type or next(model.parameters()).device.type
         self.autocast = autocast
@@ -445,7 +582,7 @@ class Trainer:
         if distributed:
             # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)
             self.model = nn.parallel.DistributedDataParallel(
-                model, device_ids=[local_rank] if self.device_type == "cuda" else None,
+                self.model, device_ids=[local_rank] if self.device_type == "cuda" else None,
                 bucket_cap_mb=bucket_cap_mb or DDP_BUCKET_MB,
                 gradient_as_bucket_view=True, find_unused_parameters=False, static_graph=False)
             if bf16_buckets:
@@ -463,6 +600,14 @@ class Trainer:
             self.ema = ModelEma(model, ema_decay) if ema_decay else None
         self.criterion = nn.BCEWithLogitsLoss()
         self._watch = _LossWatch(self.device_type)
+
+    def capture_segments(self, samples, warmup=3):
+        """hipGraphs for the slices of a ``segment_graphs`` trainer (call once, with a batch of the training shape, after
+        at least one eager step has built the lazily created caches)."""
+        if self.segmented is None:
+            raise RuntimeError("Trainer.capture_segments: construct the trainer with segment_graphs=n")
+        self.segmented.capture(samples, warmup=warmup)
+        return self
 
     def _forward_loss(self, samples, targets):
         if self.autocast:
@@ -510,7 +655,8 @@ class Trainer:
         if self.device_type != "cuda" or not isinstance(self.optimizer, FusedLamb):
             raise RuntimeError("Trainer.capture needs the GPU and the fused optimizer")
         if self.model is not self.raw_model:
-            raise RuntimeError("Trainer.capture: distributed steps are not captured")
+            raise RuntimeError("Trainer.capture: distributed / segmented steps are not captured as one graph "
+                               "(use segment_graphs=n + capture_segments)")
         if self.accum_steps != 1:
             raise RuntimeError("Trainer.capture: accum_steps > 1 is not captured")
         from . import ops
@@ -563,12 +709,12 @@ class _null:
         return False
 
 
-def init_distributed():
-    """One process per GPU, RCCL via torch.distributed (backend name 'nccl' on ROCm)."""
+def init_distributed(force=False):
+    """One process per GPU, RCCL via torch.distributed (backend name 'nccl' on ROCm).  force: also at world size 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
