@@ -96,7 +96,6 @@ def step_variants(trainer, model, samples, targets, args, n=8):
     out["eager_ms_per_step"], out["eager_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
     del trainer
     seg = Trainer(model, segment_graphs=8)           # (re-links the blocks inside the slices: keep this last)
-    seg.step(samples, targets)
     seg.capture_segments(samples)
     ms, host = timed(seg)
     out["segment_graph_ms_per_step"], out["segment_graph_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
@@ -242,18 +241,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if nseg:
+        trainer.capture_segments(samples[:args.batch])
+        log(f"forward / backward captured as {len(trainer.segmented._segments)} x 2 hipGraphs")
     for i in range(args.warmup):
         trainer.step(samples, targets)
         if i == 0:
             torch.cuda.synchronize()
             log("first warm-up step done")
     graphed = None
-    if nseg:
-        trainer.capture_segments(samples[:args.batch])
-        for _ in range(2):
-            trainer.step(samples, targets)
-        torch.cuda.synchronize()
-        log(f"forward / backward captured as {len(trainer.segmented._segments)} x 2 hipGraphs")
     if one_graph and not nseg:
         try:
             graphed = trainer.capture(samples, targets, warmup=1)

@@ -111,9 +111,12 @@ class TritonGeluD8(nn.Module):
     """d8_gelu.py:480-482 (name kept for drop-in; the kernel is HIP, not Triton)."""
 
     def forward(self, xs):
+        # through the dispatcher (custom_ops.py: torch.ops.octic.gelu_d8*, schema + fake kernel + autograd formula), so
+        # torch.compile traces through this op instead of breaking the graph at a ctypes call
+        from . import custom_ops as _co          # noqa: F401  (registers the ops)
         if isinstance(xs, Octic):
-            return Octic(OF.GeluD8PackedFn.apply(xs.packed, xs.c), xs.c)
-        return OF.GeluD8Function.apply(xs[0], xs[1], xs[2], xs[3], xs[4])
+            return Octic(torch.ops.octic.gelu_d8(xs.packed, xs.c), xs.c)
+        return tuple(torch.ops.octic.gelu_d8_tuple(xs[0], xs[1], xs[2], xs[3], xs[4]))
 
 
 class GeluD8(nn.Module):

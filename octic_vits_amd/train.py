@@ -231,6 +231,31 @@ class FusedLamb:
         self.betas = tuple(h.get("betas", self.betas))
         self.max_grad_norm, self.ema_decay = h.get("max_grad_norm", self.max_grad_norm), h.get("ema_decay", self.ema_decay)
 
+    @torch.no_grad()
+    def prime(self):
+        """Bring every buffer a step refreshes on the device to its post-step form WITHOUT stepping: the bf16 shadow copies
+        of the standard half's weights (+ their transposed copies) and the batched LinearD8 weight preparation, adopted by
+        the layers' caches.  After this, the addresses a forward pass reads its compute-dtype weights from are the ones
+        every later optimizer step rewrites - what a hipGraph captured BEFORE the first step needs (segment graphs under
+        DDP are captured before the data-parallel wrapper exists, i.e. before any step).  Values: the same round-to-nearest
+        casts the caches would make themselves.  Needs one forward pass first (the LinearD8 caches record their operands)."""
+        import ctypes
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.m.device).cuda_stream)
+        for (lin, cache, wb, bb, _) in self._shadows:
+            wb.copy_(lin.weight)
+            if bb is not None:
+                bb.copy_(lin.bias)
+        if self._wt_items is not None:
+            self._lib.check(self._lib.lib().octic_dense_prep_batch(vp(self._wt_items), self._wt_count, self._wt_blocks,
+                                                                   self._lib.BF16, stream))
+        for (lin, cache, wb, bb, _), wt in zip(self._shadows, self._wt):
+            cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16, wt_copy=wt)
+        if self._prep_source is not None:
+            from .functional import PrepBatch
+            self._prep_batch = PrepBatch(self._prep_source())
+            self._prep_batch.run()
+
     def prepare_capture(self):
         """Page-locked staging for the gradient address table of a step that is about to be captured (host
         allocations are not allowed while a stream is capturing)."""
@@ -579,15 +604,14 @@ class Trainer:
         self.autocast = autocast
         self.check_every = max(1, int(check_every))
         self._steps = 0
+        self._ddp_args = None
         if distributed:
-            # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)
-            self.model = nn.parallel.DistributedDataParallel(
-                self.model, device_ids=[local_rank] if self.device_type == "cuda" else None,
-                bucket_cap_mb=bucket_cap_mb or DDP_BUCKET_MB,
-                gradient_as_bucket_view=True, find_unused_parameters=False, static_graph=False)
-            if bf16_buckets:
-                from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-                self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
+            self._ddp_args = (local_rank, bucket_cap_mb, bf16_buckets)
+            # With segment graphs the slices are captured FIRST and wrapped in DistributedDataParallel afterwards
+            # (capture_segments): capturing the backward graphs of parameters that a DDP reducer already manages crashed
+            # inside torch.autograd.grad (segfault on ROCm 7 / torch 2.10); the documented order is graphs, then DDP.
+            if self.segmented is None:
+                self._wrap_ddp()
         groups = param_groups_weight_decay(model, weight_decay, model.no_weight_decay())
         if fused_optimizer:
             # LAMB and EMA in one fused step; it also refreshes the bf16 weights of the library-GEMM layers
@@ -601,12 +625,32 @@ class Trainer:
         self.criterion = nn.BCEWithLogitsLoss()
         self._watch = _LossWatch(self.device_type)
 
+    def _wrap_ddp(self):
+        local_rank, bucket_cap_mb, bf16_buckets = self._ddp_args
+        # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)
+        self.model = nn.parallel.DistributedDataParallel(
+            self.model, device_ids=[local_rank] if self.device_type == "cuda" else None,
+            bucket_cap_mb=bucket_cap_mb or DDP_BUCKET_MB,
+            gradient_as_bucket_view=True, find_unused_parameters=False, static_graph=False)
+        if bf16_buckets:
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
+
     def capture_segments(self, samples, warmup=3):
-        """hipGraphs for the slices of a ``segment_graphs`` trainer (call once, with a batch of the training shape, after
-        at least one eager step has built the lazily created caches)."""
+        """hipGraphs for the slices of a ``segment_graphs`` trainer (call once, with ONE micro-batch of the training
+        shape).  A distributed trainer must call this before its first step: the data-parallel wrapper is built here,
+        around the graphed slices."""
         if self.segmented is None:
             raise RuntimeError("Trainer.capture_segments: construct the trainer with segment_graphs=n")
+        if isinstance(self.optimizer, FusedLamb) and self.optimizer.step_count == 0:
+            # no step yet: one forward (the weight caches record their operands), then the static weight buffers
+            self.segmented.train()
+            with torch.no_grad():
+                self.segmented(samples)
+            self.optimizer.prime()
         self.segmented.capture(samples, warmup=warmup)
+        if self._ddp_args is not None and self.model is self.segmented:
+            self._wrap_ddp()
         return self
 
     def _forward_loss(self, samples, targets):
@@ -617,13 +661,26 @@ class Trainer:
         return self.criterion(self.model(samples).float(), targets)
 
     def step(self, samples, targets):
+        if self._ddp_args is not None and self.model is self.segmented:
+            raise RuntimeError("Trainer(distributed=True, segment_graphs=n): call capture_segments(micro_batch) before the "
+                               "first step (the slices are captured, then wrapped in DistributedDataParallel)")
         self.model.train()
         # engine.py:67-71 two steps late on a pinned host copy (_LossWatch): no stream drain per step
         self._steps += 1
         if self._steps % self.check_every == 0:
             self._watch.check()
-        self.optimizer.zero_grad(set_to_none=True)
         k = self.accum_steps
+        if k > 1 and self.segmented is not None and self.segmented.graphed:
+            # Graphed slices hand autograd the SAME static gradient buffers every backward: with .grad = None the first
+            # micro-batch's gradient would be adopted by reference and overwritten by the second replay before it is added.
+            # Accumulate into gradients of our own instead (zeroed in place, one multi-tensor launch).
+            params = [p for p in self.raw_model.parameters() if p.requires_grad]
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            torch._foreach_zero_([p.grad for p in params])
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         if k == 1:
             loss = self._forward_loss(samples, targets)
             loss.backward()

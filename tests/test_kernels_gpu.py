@@ -367,3 +367,46 @@ def test_lift_gemm_matches_patch_embed(p, G, D, dtype):
     dw = o.lift_wgrad(patches, dout.to(DEV), Kpad, D)
     ref = dout.double().t() @ patches.double().cpu()
     close(dw, ref, 1e-4, 1e-4, "lift wgrad")
+
+
+def test_gelu_d8_is_a_dispatcher_op_that_torch_compile_traces_through():
+    """Round 4 (review item 8): the reference's one custom-op boundary (TritonGeluD8Function, d8_gelu.py:456-478) as
+    torch.library ops with schema, fake kernel and autograd formula (octic_vits_amd/custom_ops.py).  (a) torch.library.opcheck
+    (schema, fake-tensor agreement, autograd registration, AOT dispatch) on GPU tensors; (b) torch.compile with
+    fullgraph=True - i.e. ZERO graph breaks - of the module the reference compiles, on the 5-tensor and the packed form,
+    forward and backward BITWISE equal to the eager op (backend aot_eager: the op itself is the HIP kernel either way)."""
+    import torch
+    from octic_vits_amd import custom_ops  # noqa: F401
+    from octic_vits_amd.d8_layers import TritonGeluD8
+    from octic_vits_amd.functional import Octic
+    torch.manual_seed(3)
+    c = 16
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(3, 7, 8 * c, device=DEV).to(dt)
+        torch.library.opcheck(torch.ops.octic.gelu_d8, (x.clone().requires_grad_(True), c))
+        xs5 = [torch.randn(3, 7, c, device=DEV).to(dt).requires_grad_(True) for _ in range(4)] + \
+              [torch.randn(3, 7, 2, 2 * c, device=DEV).to(dt).requires_grad_(True)]
+        torch.library.opcheck(torch.ops.octic.gelu_d8_tuple, tuple(xs5))
+
+        mod = TritonGeluD8()
+        comp = torch.compile(mod, backend="aot_eager", fullgraph=True)      # fullgraph: any graph break raises
+        gs = [torch.randn_like(t) for t in xs5]
+        ye = mod(tuple(xs5))
+        ge = torch.autograd.grad(ye, xs5, gs)
+        yc = comp(tuple(xs5))
+        gc = torch.autograd.grad(yc, xs5, gs)
+        for a_, b_ in zip(list(ye) + list(ge), list(yc) + list(gc)):
+            assert torch.equal(a_, b_)
+
+        def packed(t):
+            return torch.ops.octic.gelu_d8(t, c) * 2.0
+
+        xp = x.clone().requires_grad_(True)
+        ye = packed(xp)
+        (ge,) = torch.autograd.grad(ye, xp, torch.ones_like(ye))
+        yc = torch.compile(packed, backend="aot_eager", fullgraph=True)(xp)
+        (gc,) = torch.autograd.grad(yc, xp, torch.ones_like(yc))
+        assert torch.equal(ye, yc) and torch.equal(ge, gc)
+        # and the module on the engine's native container runs through the same op
+        y_o = mod(Octic(x, c))
+        assert torch.equal(y_o.packed, torch.ops.octic.gelu_d8(x, c))

@@ -486,14 +486,17 @@ def test_segment_graphs_replay_like_the_eager_segmented_step_also_under_ddp_hook
     def run(graphed, **kw):
         torch.manual_seed(1234)
         torch.cuda.manual_seed(1234)
-        tr = Trainer(_small_hybrid(seed=9, drop_path=0.2), lr=1e-3, segment_graphs=3, **kw)
-        tr.step(x, y)                                   # builds the lazily created caches
-        if graphed:
+        ddp = kw.pop("distributed", False)
+        tr = Trainer(_small_hybrid(seed=9, drop_path=0.2), lr=1e-3, segment_graphs=3, distributed=ddp and graphed, **kw)
+        if graphed:                                     # (a distributed trainer captures first: graphs, then the DDP wrapper)
             tr.capture_segments(x[: x.shape[0] // kw.get("accum_steps", 1)])     # static shape = one micro-batch
             assert tr.segmented.graphed
+        elif ddp:
+            tr._ddp_args = (0, None, False)
+            tr._wrap_ddp()                              # eager slices under DDP
         torch.manual_seed(77)
         torch.cuda.manual_seed(77)                      # same device RNG stream for the drop-path masks from here on
-        losses = [float(tr.step(bx, by)) for bx, by in batches + batches]
+        losses = [float(tr.step(bx, by)) for bx, by in [(x, y)] + batches + batches]
         return losses, [p.detach().clone() for p in tr.raw_model.parameters()]
 
     la, pa = run(False)
