@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 7
+#define OCTIC_ABI_VERSION 8
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -346,6 +346,10 @@ int octic_dense_prep_batch(const octic_dense_prep_item* items_dev, int n_items, 
  * by the caller when it is allocated (the kernels re-arm their counters; calls sharing a workspace must be stream-ordered). */
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K);
 int octic_dense_gemm_colsum_rows(int M, int N, int K);
+/* Output tile width the kernel will use for this problem and mode: 256 (256 x 256 tile) or 320 (256 x 320 tile: plain mode,
+ * N % 320 == 0, chosen where it makes the launch ONE round of workgroups - the N = 1280 problems of ViT-H).  Informational
+ * (profilers see two kernel symbols: dense_nt_kernel<mode, 4> and <0, 5>). */
+int octic_dense_gemm_tile(int M, int N, int K, int mode);
 int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs,
                         int64_t rows_per_sample, const float* X, float* OUT, const void* H, float* colsum,

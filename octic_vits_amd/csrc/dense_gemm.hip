@@ -872,6 +872,11 @@ int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K) {
   return need;
 }
 
+int octic_dense_gemm_tile(int M, int N, int K, int mode) {
+  if (M <= 0 || N <= 0 || K < 2 * DG_BK) return 256;
+  return dense_plan(M, N, K, dense_cus(), mode).nt == 5 ? 320 : 256;
+}
+
 // developer switch: force the tile width of the plain mode (0 = cost model, 4 = 256-wide, 5 = 320-wide where N % 320 == 0)
 void octic_dbg_dense_tile(int nt) { g_dense_force_nt = (nt == 4 || nt == 5) ? nt : 0; }
 void octic_dbg_dense_split(int s) { g_dense_force_split = s > 0 ? s : 0; }

@@ -723,7 +723,9 @@ def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h
                                     _p(gamma), _p(rs), int(rps), _p(x), _p(out), _p(h), _p(cs), _p(ws), _stream(a)))
     if t is not None:
         nb = 2 * (M * K + N * K + M * N * (2 if mode in (1, 3) else 1)) + (8 * M * N if mode == 2 else 0)
-        KERNEL_TIMER.stop(t, name or f"dense_nt_kernel<{mode}>", nb, 2.0 * M * N * K)
+        # "@320": the launch ran the 256 x 320 tile (kernel symbol dense_nt_kernel<0, 5>), else <mode, 4>
+        wide = "@320" if lib().octic_dense_gemm_tile(M, N, K, mode) == 320 else ""
+        KERNEL_TIMER.stop(t, (name or f"dense_nt_kernel<{mode}>") + wide, nb, 2.0 * M * N * K)
     if mode == 1:
         return c, c2
     if mode == 2:

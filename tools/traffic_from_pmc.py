@@ -20,8 +20,11 @@ NAMES = [
     (r"wgrad_ring_kernel", "wgrad_ring_kernel<bf16>"),
     (r"attn_fwd(_persist)?_kernel|a80.{0,4}fwd(_os)?_kernel|fwd_os_kernel", "attn_fwd_kernel"),
     (r"dense_tn_kernel", "dense_tn_kernel<wgrad, all shapes>"),
-    (r"dense_nt_kernel(ILi0E|<0>)", "dense_nt_kernel<0>"),
-    (r"dense_nt_kernel(ILi1E|<1>)", "dense_nt_kernel<1>"),
+    (r"dense_nt_kernel(ILi0ELi5E|<0, 5>)", "dense_nt_kernel<0, 5>"),
+    (r"dense_nt_kernel(ILi0ELi4E|<0, 4>)", "dense_nt_kernel<0, 4>"),
+    (r"dense_nt_kernel(ILi1ELi4E|<1, 4>)", "dense_nt_kernel<1>"),
+    (r"dense_nt_kernel(ILi3ELi4E|<3, 4>)", "dense_nt_kernel<3>"),
+    (r"a80.{0,6}bwd_kernel|bwd_kernel\(octic::AttnBwdArgs", "attn_bwd_kernel"),
     (r"heads_permute_kernel", "heads_permute_kernel<bf16>"),
     (r"lamb_stage1_kernel", "lamb_stage1_kernel"),
     (r"lamb_stage2_kernel", "lamb_stage2_kernel"),
