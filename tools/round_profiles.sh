@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out
 B="python3 bench.py --no-cpu-baseline --no-forward-only --no-kernel-timing --no-graph"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_trace -- python3 bench.py --no-cpu-baseline --no-forward-only --steps 10 --warmup 3 > $O/prof_trace.json 2> $O/prof_trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_trace -- python3 bench.py --no-cpu-baseline --no-forward-only --no-step-variants --steps 10 --warmup 3 > $O/prof_trace.json 2> $O/prof_trace.log
 python3 tools/rocprof_summary.py $O/prof_trace $O/rocprof_r4_bench.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --steps 3 --warmup 2 > /dev/null 2> $O/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B --steps 3 --warmup 2 > /dev/null 2> $O/pmc_write.log
