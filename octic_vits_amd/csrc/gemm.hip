@@ -14,6 +14,7 @@
 // bf16: v_mfma_f32_16x16x32_bf16.  f32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain) for the
 // reference's fp32 tolerances.
 #include <stdlib.h>
+#include <type_traits>
 #include "gemm_args.hpp"
 
 namespace octic {
@@ -302,12 +303,6 @@ constexpr int kRingBN = 80;
 constexpr int kRingS = 3;
 constexpr int kRingStage = (kBM + kRingBN) * 128;
 
-// Sink for the stores of out-of-range lanes: every epilogue store instruction is executed by the whole wave
-// (exact vmcnt bookkeeping needs a fixed number of VMEM instructions per epilogue), lanes that have nothing to
-// write are pointed here.
-__device__ char g_store_sink[64 * 16 * 2];
-
-
 // NT = 16-column MFMA tiles per wave (tile width BN = 16 NT: 80 or 160), S = ring stages.  The wide tile (NT = 10,
 // S = 2: 72 KiB, still two workgroups per CU) is for the long-K / narrow-N problems (fc2, input gradients of qkv and
 // fc1: N = 160 | 320): with 80-column tiles their X panel went through the L2->LDS path once per n-tile and each X
@@ -338,7 +333,6 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int WI = BN / 8;                  // W DMA instructions per tile (8 rows each)
   constexpr int WQ = (WI + NW - 1) / NW;      // per wave, at most
-  constexpr int NSTORE = NT * MT;             // store instructions per wave per epilogue
   typedef typename Elem<TIN>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char lds[];  // S stages x (128 + BN) rows x 128 B
 
@@ -463,86 +457,142 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
   const int rd_x = (wid * 32 + fr) * 128;               // + j*2048
   const int ch0 = (kg ^ sw) << 4, ch1 = ((4 + kg) ^ sw) << 4;
 
-  // ---- epilogue constants (per workgroup): output row base pointers (or the sink), residual rows, drop-path scale
-  TOUT* ybase[MT];
-  const TOUT* rbase[MT];
+  // ---- epilogue constants: drop-path scale of this lane's two MFMA rows
   float rsv[MT];
-  bool rok[MT];
-  TOUT* const sink = (TOUT*)(g_store_sink + lane * 16);
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int64_t mm = m0 + wid * 32 + j * 16 + fr;
-    rok[j] = mm < G.rows;
-    const int64_t mc = rok[j] ? mm : 0;
+    const int64_t mc = mm < G.rows ? mm : 0;
     const int64_t token = G.pair ? (mc >> 1) : mc;
-    int64_t yoff, roff;
-    if (args.lift_np > 0) {
-      const int64_t b = mc / args.lift_np, p = mc - b * args.lift_np;
-      yoff = (b * (args.lift_np + args.lift_tok0) + args.lift_tok0 + p) * G.y_ld;
-      roff = p * G.r_ld;
-    } else {
-      yoff = G.pair ? (mc >> 1) * G.y_ld + (mc & 1) * (int64_t)N : mc * G.y_ld;
-      roff = G.pair ? (mc >> 1) * G.r_ld + (mc & 1) * (int64_t)N : mc * G.r_ld;
-    }
-    ybase[j] = (TOUT*)G.y + yoff;
-    rbase[j] = (const TOUT*)G.resid + roff;
     rsv[j] = (EPI == 1 && args.rs) ? args.rs[token / args.rps] : 1.0f;
   }
   const bool has_bias = G.bias != nullptr;
   const bool has_cs = EPI == 1 && G.cs != nullptr, has_rs = EPI == 1 && args.rs != nullptr,
              has_res = EPI == 1 && G.resid != nullptr;
-  int e_nt = nt_begin;
+  // ---- epilogue (once per item: a workgroup owns ONE output tile).  Storing straight from the MFMA layout - a lane holds 4
+  // consecutive channels of one token, so a wave-instruction touches 16 rows x 64 B (f32) or 32 B (bf16) - is bound by the
+  // address path (tools/ring_trace.py: 7.8 k cycles per item, a fifth of a short item).  The tile goes through the idle
+  // ring instead: per pass a wave parks 16 rows x BN f32 (bias / column scale / row scale applied) in its own LDS strip
+  // and walks them row-wise, 16 contiguous bytes per lane for the residual load and the store.  Same arithmetic in the same
+  // order as the direct form: results are bit-identical.
   auto epilogue = [&]() {
-    const int nb = e_nt * BN + kg * 4;
-    ++e_nt;
+    constexpr int RS = BN * 4 + 16;                   // strip row stride: the 16 B skew keeps ds_write_b128 conflict-free
+    constexpr int OPC = 16 / (int)sizeof(TOUT);       // output columns per 16-byte piece
+    constexpr int CPR = BN / OPC;                     // pieces per row
+    constexpr int PIECES = 16 * CPR;                  // per wave and pass
+    static_assert(NW * 16 * RS + 2 * BN * 4 <= S * STAGE, "the strips and the column vectors must fit the ring");
+    static_assert(BN / 4 <= BM * 2, "one thread per four columns");
+    const int nb = nt_begin * BN;
+    // bias and column scale of the tile's BN columns go through LDS as well (per-n-tile global loads in the MFMA layout
+    // compile to twenty serial round trips)
+    f32x4 bias_r = {0, 0, 0, 0}, cs_r = {1, 1, 1, 1};
+    const int cvi = threadIdx.x;                      // this thread's four columns
+    if (cvi < BN / 4 && nb + 4 * cvi < N) {
+      if (has_bias) bias_r = *(const f32x4*)(G.bias + nb + 4 * cvi);
+      if (has_cs) cs_r = *(const f32x4*)(G.cs + nb + 4 * cvi);
+    }
+    __syncthreads();                                  // every wave is done with the ring
+    char* strip = lds + wid * (16 * RS);
+    const char* colv = lds + NW * 16 * RS;            // [bias BN f32 | column scale BN f32]
+    if (cvi < BN / 4) {
+      *(f32x4*)(lds + NW * 16 * RS + cvi * 16) = bias_r;
+      *(f32x4*)(lds + NW * 16 * RS + BN * 4 + cvi * 16) = cs_r;
+    }
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = nb + i * 16;
-      const bool nok = n < N;
-      const int nc2 = nok ? n : 0;
-      f32x4 bv = {0, 0, 0, 0}, sv = {1, 1, 1, 1};
-      if (has_bias) bv = *(const f32x4*)(G.bias + nc2);
-      if (has_cs) sv = *(const f32x4*)(G.cs + nc2);
+    for (int j = 0; j < MT; ++j) {
+      // (compile-time variants: a run-time `if (has_bias)` per n-tile puts every LDS read in its own block behind a wait)
+      auto park = [&](auto hb_c, auto hc_c) {
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const bool ok = nok && rok[j];
-        f32x4 v = acc[i][j];
-        if (has_bias) v += bv;
-        if (has_cs) v *= sv;
-        if (has_rs) v *= rsv[j];
-        if (has_res) v += load_out4<TOUT>(ok ? rbase[j] + n : (const TOUT*)sink);
-        store_out4<TOUT>(ok ? ybase[j] + n : sink, v);     // always issued: exactly NSTORE stores per epilogue
-        acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int i = 0; i < NT; ++i) {
+          f32x4 v = acc[i][j];
+          if constexpr (decltype(hb_c)::value) v += *(const f32x4*)(colv + (i * 16 + kg * 4) * 4);
+          if constexpr (decltype(hc_c)::value) v *= *(const f32x4*)(colv + BN * 4 + (i * 16 + kg * 4) * 4);
+          if constexpr (EPI == 1) v *= rsv[j];          // 1.0f without a row scale: exact
+          *(f32x4*)(strip + fr * RS + (i * 16 + kg * 4) * 4) = v;
+        }
+      };
+      if (has_bias && has_cs) park(std::true_type(), std::true_type());
+      else if (has_bias) park(std::true_type(), std::false_type());
+      else if (has_cs) park(std::false_type(), std::true_type());
+      else park(std::false_type(), std::false_type());
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // row pass: every residual load of the pass is requested (from clamped, always valid addresses) before the first
+      // use; the stores are predicated
+      constexpr int NIT = (PIECES + 63) / 64;
+      int64_t yo[NIT];
+      bool okp[NIT];
+      typedef typename std::conditional<sizeof(TOUT) == 4, f32x4, bf16x8>::type piece_t;
+      piece_t rv[NIT];
+      const int pshift = G.pair ? 1 : 0;               // pair groups: GEMM row mm = token mm >> 1, half mm & 1
+      auto request = [&](auto lift_c) {                // (the lift addressing divides: its own straight-line variant)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int p = it * 64 + lane;
+          const int r = p / CPR, c = p - r * CPR;
+          const int64_t mm = m0 + wid * 32 + j * 16 + r;
+          const int n = nb + c * OPC;
+          okp[it] = p < PIECES && mm < G.rows && n < N;
+          const int64_t mc = okp[it] ? mm : 0;
+          const int ncl = okp[it] ? n : 0;
+          int64_t roff;
+          if constexpr (decltype(lift_c)::value) {
+            const unsigned b = (unsigned)mc / (unsigned)args.lift_np, q = (unsigned)mc - b * (unsigned)args.lift_np;   // rows < 2^31
+            yo[it] = ((int64_t)b * (args.lift_np + args.lift_tok0) + args.lift_tok0 + q) * G.y_ld + ncl;
+            roff = (int64_t)q * G.r_ld + ncl;
+          } else {
+            const int64_t tok = mc >> pshift, half = mc & pshift;
+            yo[it] = tok * G.y_ld + half * N + ncl;
+            roff = tok * G.r_ld + half * N + ncl;
+          }
+          if constexpr (EPI == 1) rv[it] = *(const piece_t*)((const TOUT*)(has_res ? G.resid : G.y) + (has_res ? roff : yo[it]));
+        }
+      };
+      if (args.lift_np > 0) request(std::true_type());
+      else request(std::false_type());
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int p = it * 64 + lane;
+        const int r = p / CPR, c = p - r * CPR;
+        const char* src = strip + (p < PIECES ? r * RS + c * (OPC * 4) : 0);
+        if constexpr (sizeof(TOUT) == 4) {
+          f32x4 v = *(const f32x4*)src;
+          if constexpr (EPI == 1) {
+            if (has_res) v += rv[it];
+          }
+          if (okp[it]) *(f32x4*)((float*)G.y + yo[it]) = v;
+        } else {
+          f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 16);
+          if constexpr (EPI == 1) {
+            if (has_res) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v0[e] += (float)rv[it][e];
+                v1[e] += (float)rv[it][4 + e];
+              }
+            }
+          }
+          const bf16x8 o = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+          if (okp[it]) *(bf16x8*)((bf16*)G.y + yo[it]) = o;
+        }
       }
+      __builtin_amdgcn_wave_barrier();                // the strip is rewritten by the next pass
     }
   };
 
-  // ---- ring.  VMEM program order per step s:  [wait tile s][barrier] DMA(s+2)  compute(s)  [stores if n-tile done]
-  // so the ops younger than DMA(s) at the wait of step s are: stores(s-2)?, DMA(s+1), stores(s-1)?.
+  // ---- ring.  VMEM program order per step s:  [wait tile s][barrier] DMA(s+S-1)  compute(s)
   issue();
   if (S > 2 && steps > 1) issue();
   RTRACE(1);
   int c_kt = 0, c_stage = 0;
-  int st1 = 0, st2 = 0;   // store instructions issued in step s-1 / s-2
   for (int s = 0; s < steps; ++s) {
-    // S = 3: DMA runs two tiles ahead (tile s+1 may still be in flight at this wait); S = 2: one tile ahead, so
-    // only the stores of step s-1 are younger than DMA(s)
-    // (the immediates are picked by two or three scalar compares: a `switch` over all counts compiles to a compare
-    // ladder of ~500 cycles, most of a 640-cycle MFMA step)
-    if (has_res) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // residual loads have VGPR destinations: keep hipcc's own waits exact
-    } else if (S > 2) {
-      // younger than DMA(s): DMA(s+1) (dma_cnt = 6 | 7) and the stores of steps s-1, s-2 (0 | NSTORE each); rounding the
-      // count down only waits for the oldest of them, stores issued two steps ago
-      const int n = s + 1 < steps ? dma_cnt + st1 + st2 : 0;
-      if (n >= 6 && n < 16) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (st1 == NSTORE && NSTORE == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else if (st1 == NSTORE && NSTORE == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // S = 3: DMA runs two tiles ahead (tile s+1 may still be in flight at this wait: dma_cnt = 6 | 7 younger
+    // instructions; a fixed immediate, two scalar compares - a `switch` over all counts compiles to a ~500-cycle
+    // compare ladder); S = 2: one tile ahead, nothing is younger than DMA(s)
+    if (S > 2 && s + 1 < steps && dma_cnt >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RTRACE(2 + 3 * s);
     __builtin_amdgcn_s_barrier();             // every wave's share of tile s has landed; the stage of tile s-1 is free
     RTRACE(3 + 3 * s);
@@ -588,15 +638,11 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
           for (int j = 0; j < MT; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
       }
     }
-    st2 = st1;
-    st1 = 0;
-    if (++c_kt == nkt) {
-      c_kt = 0;
-      epilogue();
-      st1 = NSTORE;
-    }
+    ++c_kt;
     RTRACE(4 + 3 * s);
   }
+  epilogue();
+  RTRACE(62);
 }
 
 template <typename TIN, typename TOUT, int NT, int S, int BM = 128>
@@ -607,13 +653,8 @@ int launch_ring_nt(GemmArgs& a, hipStream_t s) {
   for (int i = 0; i < a.ngroups; ++i) {
     a.g[i].n_tiles = (a.g[i].N + BN - 1) / BN;
     a.g[i].m_tiles = (int)((a.g[i].rows + BM - 1) / BM);
-    constexpr int target_steps = 1;    // one output tile per workgroup (measured best in situ on MI355X)
-    const int bke = 128 / (int)sizeof(TIN);
-    const int nkt = (a.g[i].K + bke - 1) / bke;
-    int chunk = target_steps / nkt;
-    chunk = chunk < 1 ? 1 : (chunk > a.g[i].n_tiles ? a.g[i].n_tiles : chunk);
-    a.g[i].chunk = chunk;
-    a.g[i].n_chunks = (a.g[i].n_tiles + chunk - 1) / chunk;
+    a.g[i].chunk = 1;                  // one output tile per workgroup (measured best in situ on MI355X; the staged epilogue
+    a.g[i].n_chunks = a.g[i].n_tiles;  // of the kernel relies on it: the ring is idle when the tile is complete)
     a.g[i].tile_begin = t;
     t += a.g[i].n_chunks * a.g[i].m_tiles;
     fused = fused || a.g[i].cs || a.g[i].resid;

@@ -29,6 +29,8 @@ hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(src), n * 8, 3)
 tr = buf.cpu().numpy().reshape(2048, 4, 64).copy()
 ids = tr[:, 0, 63].copy()
 tr[:, :, 63] = 0
+end = tr[:, :, 62].copy()          # stamp after the epilogue
+tr[:, :, 62] = 0
 live = [i for i in range(2048) if tr[i, 0, 0] != 0]
 print(f"{len(live)} workgroups traced")
 # where each workgroup ran: XCC id, and (se, sh, cu) from HW_ID
@@ -49,7 +51,7 @@ for key in list(sorted(percu))[:3] + list(sorted(percu))[-2:]:
 spans = []
 for key, v in percu.items():
     base = min(tr[i, :, 0].min() for i in v)
-    spans.append(max(tr[i].max() for i in v) - base)
+    spans.append(max(max(tr[i].max(), end[i].max()) for i in v) - base)
 print(f"per-CU span (first start -> last stamp): mean {np.mean(spans):.0f}  max {np.max(spans):.0f}")
 # per-step statistics (wave 0 of every workgroup)
 wa, ba, wo, pro = [], [], [], []
@@ -64,6 +66,8 @@ for wg in live:
         wa.append(t[2 + 3 * s_] - prev); ba.append(t[3 + 3 * s_] - t[2 + 3 * s_]); wo.append(t[4 + 3 * s_] - t[3 + 3 * s_])
 f = lambda v: f"mean {np.mean(v):8.0f}  median {np.median(v):8.0f}  p90 {np.percentile(v, 90):8.0f}  max {np.max(v):8.0f}"
 print("prologue   ", f(pro)); print("wait       ", f(wa)); print("barrier    ", f(ba)); print("work       ", f(wo))
+epi = [int(end[wg, 0] - tr[wg, 0].max()) for wg in live if end[wg, 0]]
+if epi: print("epilogue   ", f(epi))
 for wg in (live[0], live[-1]):
     t = tr[wg, 0]; nz = np.nonzero(t)[0]; steps = (nz.max() - 1) // 3
     print(f"WG {wg}: {steps} steps; (wait, barrier, work):", [(int(t[2 + 3 * s_] - (t[1] if s_ == 0 else t[4 + 3 * (s_ - 1)])), int(t[3 + 3 * s_] - t[2 + 3 * s_]), int(t[4 + 3 * s_] - t[3 + 3 * s_])) for s_ in range(steps)])
