@@ -15,6 +15,7 @@
 // reference's fp32 tolerances.
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 #include "gemm_args.hpp"
 
 namespace octic {
@@ -344,7 +345,28 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
   // XCDs 0-3 ran only E items and XCDs 4-7 only short ones (HW_ID timeline, tools/ring_trace.py: per-CU spans of
   // 95 k .. 200 k cycles for one launch).  Segment k of the order = [share k of group 0 | share k of group 1 | ...].
   int gi = 0, lt = 0;
-  {
+  if (args.plan_mode == 1) {
+    // planned order (plan_ring below): XCD x runs, in dispatch order, a few short items, its share of the long group, then
+    // short items - so that the workgroup slots that must take a third item are slots that started with a short one
+    const int l = bid >> 3;
+    int a_x = 0, e_x = 0, eb_x = 0, sb_x = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)          // constant indices + scalar selects (no dynamic indexing of the argument block)
+      if (xcd == i) {
+        a_x = args.plan_a[i];
+        e_x = args.plan_e[i];
+        eb_x = args.plan_eb[i];
+        sb_x = args.plan_sb[i];
+      }
+    if (l >= a_x && l < a_x + e_x) {
+      gi = 0;
+      lt = eb_x + (l - a_x);
+    } else {
+      const int sidx = sb_x + (l < a_x ? l : l - e_x);
+      gi = 1 + sidx % args.plan_nshort;
+      lt = sidx / args.plan_nshort;
+    }
+  } else {
     int T[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -645,6 +667,126 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
   RTRACE(62);
 }
 
+// ---- dispatch plan of a ring launch.  One long group (E: twice the K steps) + equal short groups, two workgroups per CU:
+// at ViT-H that is 514 long + 516 short items on 512 slots - six items more than two rounds.  Workgroups are dispatched in
+// blockIdx order, round-robin over the XCDs, to whichever slot of the XCD frees first; with "long items first" the six
+// leftovers land as THIRD items behind a long and a short one (tools/ring_trace.py: six CUs end at 150 k cycles, the other
+// 250 at 101 k - the launch is half again as long as its mean).  The plan gives every XCD its own list
+// [a short items | e long items | short items]: an XCD with an odd item starts one slot on a short item, which then has
+// time for three short ones; XCDs without odd items take the long items the others gave up (a slot with two long items
+// ends about when a three-short slot does).  e[x] and a[x] come from a small DP over simulated in-order dispatch; the
+// plan depends on the launch shape only and is cached.
+struct RingPlan {
+  int key[6];
+  short a[8], e[8];
+};
+inline int sim_xcd(int n, int a, int e, int slots, int c_short, int c_long) {
+  // makespan of the list [a short | e long | n - a - e short] dispatched in order to `slots` slots
+  int t[256];
+  slots = slots > 256 ? 256 : slots;
+  for (int i = 0; i < slots; ++i) t[i] = 0;
+  int mk = 0;
+  for (int i = 0; i < n; ++i) {
+    int best = 0;
+    for (int j = 1; j < slots; ++j)
+      if (t[j] < t[best]) best = j;
+    t[best] += (i >= a && i < a + e) ? c_long : c_short;
+    mk = t[best] > mk ? t[best] : mk;
+  }
+  return mk;
+}
+static int g_ring_plan_off = 0;   // developer switch (octic_dbg_ring_plan): 1 = the even spread of round 3
+inline bool plan_ring(GemmArgs& a, int nwg, int slots_per_xcd) {
+  a.plan_mode = 0;
+  if (g_ring_plan_off || a.ngroups < 2 || nwg < 16) return false;
+  const int bke = 64;   // (cost model in K steps of the bf16 kernel; only ratios matter)
+  auto items = [&](int g) { return a.g[g].n_chunks * a.g[g].m_tiles; };
+  auto cost = [&](int g) { return (a.g[g].K + bke - 1) / bke + 2; };       // + prologue and epilogue, about two steps
+  const int c_long = cost(0), c_short = cost(1), n_short1 = items(1);
+  if (c_long <= c_short) return false;
+  for (int g = 2; g < a.ngroups; ++g)
+    if (cost(g) != c_short || items(g) != n_short1) return false;
+  const int E = items(0), nshort = a.ngroups - 1;
+  static RingPlan cache[16];
+  static int cached = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  const int key[6] = {nwg, slots_per_xcd, E, c_long, c_short, nshort};
+  const RingPlan* hit = nullptr;
+  for (int i = 0; i < cached && !hit; ++i) {
+    bool same = true;
+    for (int j = 0; j < 6; ++j) same = same && cache[i].key[j] == key[j];
+    if (same) hit = &cache[i];
+  }
+  if (!hit) {
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    constexpr int AMAX = 4;
+    // mk[type][e][a]: type 0 = XCDs with q8 + 1 workgroups, 1 = q8
+    const int nmax = q8 + 2;
+    int* mk = (int*)malloc(sizeof(int) * 2 * nmax * AMAX);
+    for (int ty = 0; ty < 2; ++ty)
+      for (int e = 0; e < nmax; ++e)
+        for (int aa = 0; aa < AMAX; ++aa) {
+          const int n = q8 + (ty == 0 ? 1 : 0);
+          mk[(ty * nmax + e) * AMAX + aa] = (e + aa <= n) ? sim_xcd(n, aa, e, slots_per_xcd, c_short, c_long) : (1 << 30);
+        }
+    // f[x][u]: best (max makespan, then sum) for XCDs 0..x-1 using u long items
+    // (ties: the most even spread of the long items, then the smallest sum of the XCD makespans)
+    struct Cell { int mx, maxe; long long sum; short e, a; };
+    Cell* f = (Cell*)malloc(sizeof(Cell) * 9 * (E + 1));
+    for (int u = 0; u <= E; ++u) f[u] = Cell{u == 0 ? 0 : (1 << 30), 0, 0, 0, 0};
+    for (int x = 0; x < 8; ++x) {
+      const int ty = x < r8 ? 0 : 1, n = q8 + (ty == 0 ? 1 : 0);
+      for (int u = 0; u <= E; ++u) {
+        Cell best{1 << 30, 0, 0, 0, 0};
+        for (int e = 0; e <= n && e <= u; ++e) {
+          const Cell& prev = f[x * (E + 1) + (u - e)];
+          if (prev.mx >= (1 << 30)) continue;
+          for (int aa = 0; aa < AMAX; ++aa) {
+            const int m = mk[(ty * nmax + e) * AMAX + aa];
+            if (m >= (1 << 30)) continue;
+            const int mx = m > prev.mx ? m : prev.mx, maxe = e > prev.maxe ? e : prev.maxe;
+            const long long sum = prev.sum + m;
+            if (mx < best.mx || (mx == best.mx && (maxe < best.maxe || (maxe == best.maxe && sum < best.sum))))
+              best = Cell{mx, maxe, sum, (short)e, (short)aa};
+          }
+        }
+        f[(x + 1) * (E + 1) + u] = best;
+      }
+    }
+    RingPlan pl;
+    for (int j = 0; j < 6; ++j) pl.key[j] = key[j];
+    bool ok = f[8 * (E + 1) + E].mx < (1 << 30);
+    int u = E;
+    for (int x = 7; x >= 0 && ok; --x) {
+      const Cell& c = f[(x + 1) * (E + 1) + u];
+      pl.e[x] = c.e;
+      pl.a[x] = c.a;
+      u -= c.e;
+    }
+    free(f);
+    free(mk);
+    if (!ok) return false;
+    RingPlan& slot = cache[cached < 16 ? cached++ : 15];
+    slot = pl;
+    hit = &slot;
+  }
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  int eb = 0, sb = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int n = q8 + (x < r8 ? 1 : 0);
+    a.plan_a[x] = hit->a[x];
+    a.plan_e[x] = hit->e[x];
+    a.plan_eb[x] = eb;
+    a.plan_sb[x] = sb;
+    eb += hit->e[x];
+    sb += n - hit->e[x];
+  }
+  a.plan_nshort = nshort;
+  a.plan_mode = 1;
+  return true;
+}
+
 template <typename TIN, typename TOUT, int NT, int S, int BM = 128>
 int launch_ring_nt(GemmArgs& a, hipStream_t s) {
   constexpr int BN = 16 * NT;
@@ -661,6 +803,10 @@ int launch_ring_nt(GemmArgs& a, hipStream_t s) {
   }
   a.total_tiles = t;
   const size_t smem = (size_t)S * (BM + BN) * 128;
+  {
+    const int per_cu = (int)(160 * 1024 / smem) < 2 ? (int)(160 * 1024 / smem) : 2;   // __launch_bounds__(BM * 2, 2)
+    plan_ring(a, t, device_cus() / 8 * (per_cu > 0 ? per_cu : 1));
+  }
   static DeviceOnce once;
   if (once.first()) {
     (void)hipFuncSetAttribute((const void*)linear_d8_ring_kernel<TIN, TOUT, 0, NT, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -767,6 +913,8 @@ inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
 }  // namespace octic
 
 using namespace octic;
+
+extern "C" void octic_dbg_ring_plan(int off) { octic::g_ring_plan_off = off; }
 
 extern "C" {
 

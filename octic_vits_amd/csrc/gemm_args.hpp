@@ -32,6 +32,12 @@ struct GemmArgs {
   // lift mode: output row = (row / lift_np) * (lift_np + lift_tok0) + lift_tok0 + row % lift_np ; resid row = row % lift_np
   int64_t lift_np;
   int lift_tok0;
+  // ring kernel dispatch plan (gemm.hip plan_ring): 0 = groups spread evenly over the XCDs; 1 = per XCD x (workgroups
+  // x, x + 8, ... in dispatch order): plan_a[x] items of the short groups, plan_e[x] items of group 0, then short items
+  int plan_mode;
+  int plan_nshort;    // short groups (1 .. ngroups-1), equal item counts
+  int plan_a[8], plan_e[8];
+  int plan_eb[8], plan_sb[8];   // first long / short item of XCD x
 };
 
 // MFMA operand reads as inline asm with hand-counted waits: inside the GEMM loops hipcc protects every MFMA group with

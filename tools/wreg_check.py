@@ -95,6 +95,8 @@ M = 64 * 257
 SHORT = (("qkv", 160, 480, bf, False), ("fc1", 160, 640, bf, False), ("proj+res", 160, 160, f32, True),
          ("dgrad fc2", 160, 640, bf, False), ("proj bf16 res", 160, 160, bf, True))
 LONG = (("fc2+res", 640, 160, f32, True), ("dgrad fc1", 640, 160, bf, False), ("dgrad qkv", 480, 160, bf, False))
+if "--no-plan" in sys.argv:
+    L.octic_dbg_ring_plan(1)
 for name, cin, cout, out_dt, fused in (LONG if "--long" in sys.argv else SHORT):
     ok = run(M, cin, cout, out_dt, fused, bias_on=name != "dgrad fc2", time_it=True) and ok
 print("ALL OK" if ok else "FAILED")
