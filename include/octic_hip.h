@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 8
+#define OCTIC_ABI_VERSION 9
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -357,12 +357,15 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
 
 /* Weight gradient of an nn.Linear of the standard half (the autograd of deit/vit.py:33,46 and of timm Mlp.fc1 / fc2):
  *     dW[N,K] = dY[M,N]^T . X[M,K]     f32, nn.Linear layout
- * dY, X bf16 row-major (ldy, ldx row strides in elements), N % 256 == 0, K % 256 == 0, (N/256)(K/256) <= 1024,
- * M * ld * 2 < 2^31.  The reduction over the M token rows is cut into row slabs (one workgroup per slab and 256 x 256
- * tile, all tiles of a slab walking the same rows in lockstep); the f32 partial tiles are summed in slab order by the
+ * dY, X bf16 row-major (ldy, ldx row strides in elements), N % 256 == 0, K % 256 == 0 or K % 320 == 0, at most 1024
+ * output tiles, M * ld * 2 < 2^31.  The reduction over the M token rows is cut into row slabs (one workgroup per slab and
+ * 256 x 256 or 256 x 320 tile, all tiles of a slab walking the same rows in lockstep); the f32 partial tiles are summed in slab order by the
  * last workgroup of a tile (bitwise reproducible).  workspace: octic_dense_wgrad_workspace_bytes(M,N,K) bytes, zeroed
  * once at allocation.                                                                                                 */
 int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K);
+/* Tile width along K the launch will use: 256 (256 x 256 tiles, whenever K % 256 == 0) or 320 (256 x 320 tiles: K % 320 == 0
+ * only).  Informational (profilers see dense_tn_kernel<4> / <5>). */
+int octic_dense_wgrad_tile(int M, int N, int K);
 int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
                          void* workspace, void* stream);
 

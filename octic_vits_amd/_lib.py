@@ -95,6 +95,7 @@ _PROTOS = {
                                     c_void_p]),
     "octic_dense_colsum": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p]),
     "octic_dense_wgrad_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "octic_dense_wgrad_tile": (c_int, [c_int, c_int, c_int]),
     "octic_dense_wgrad_tn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p]),
 }
 
@@ -120,7 +121,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.octic_abi_version() != 8:
+        if L.octic_abi_version() != 9:
             raise RuntimeError("octic_vits_amd: ABI version mismatch between _lib.py and liboctic_hip.so")
         _LIB = L
     return _LIB

@@ -27,12 +27,23 @@
 
 namespace octic {
 
-constexpr int DW_T = 256;                     // output tile side
+constexpr int DW_T = 256;                     // output tile side along n (and along k for the 256-wide tile)
 constexpr int DW_BR = 64;                     // token rows per reduction step
 constexpr int DW_UNIT = 64 * 256;             // bytes per unit: 64 rows x 128 bf16 columns
-#ifndef DW_NSLOT
-#define DW_NSLOT 8
-#endif
+constexpr int DW_UNIT_X2 = 64 * 128;          // the third X piece of the 320-wide tile: 64 rows x 64 columns
+// Tile width along k (KW = 16-column MFMA k-tiles per wave; 4 waves along k): KW = 4 is the 256 x 256 tile, KW = 5 a
+// 256 x 320 one for K % 320 == 0 (round 4; see dw_plan() for where it is used).  A wave's 80 columns are k-sets of 2 + 3
+// tiles; the units of a step are Y0 | X0 | X1 (+ X2) | Y1 = 16 / 16 / 24 / 16 KiB, two steps fill the ring.
+template <int KW> struct DwGeom {
+  static constexpr int BK = 64 * KW;                           // tile width along k
+  static constexpr int WK = 16 * KW;                           // columns per wave
+  static constexpr int U2 = DW_UNIT + (KW == 5 ? DW_UNIT_X2 : 0);
+  static constexpr int STEP = 3 * DW_UNIT + U2;                // bytes of one step in the ring (64 / 72 KiB)
+  static constexpr int RING = 2 * STEP;
+  __host__ __device__ static constexpr int unit_off(int kind) { return kind == 0 ? 0 : kind == 1 ? DW_UNIT : kind == 2 ? 2 * DW_UNIT : 2 * DW_UNIT + U2; }
+  __host__ __device__ static constexpr int unit_instr(int kind) { return kind == 2 && KW == 5 ? 3 : 2; }
+  static constexpr int INFLIGHT = KW == 5 ? 9 : 8;             // DMA instructions of the 4 youngest units (one of each kind)
+};
 #ifndef DW_DIST
 #define DW_DIST 6
 #endif
@@ -44,8 +55,9 @@ constexpr int DW_UNIT = 64 * 256;             // bytes per unit: 64 rows x 128 b
 #ifndef DW_AUX
 #define DW_AUX 0        // cache policy bits of the LDS-DMA loads (2 = nt)
 #endif
-constexpr int DW_SLOTS = DW_NSLOT;
+constexpr int DW_SLOTS = 8;                   // ring = two steps of four units
 constexpr int DW_D = DW_DIST;
+static_assert(DW_D == 6, "the counted waits assume a prefetch distance of 6 units");
 
 struct DwArgs {
   const bf16* Y;      // dY [M, N]
@@ -53,12 +65,12 @@ struct DwArgs {
   int64_t ldy, ldx;
   int M, N, K;
   float* W;           // dW [N, K]
-  int tiles_k;        // K / 256
+  int tiles_k;        // K / tile width
   int tiles;          // (N / 256) * (K / 256), tile = tn * tiles_k + tk
   int tiles8;         // tiles rounded up to a multiple of 8: items per slab (the padding items exit at once)
   int steps;          // ceil(M / 64) reduction steps per tile
   int S;              // row slabs: slab s covers steps [steps s / S, steps (s + 1) / S)
-  float* slabs;       // [tiles][S] x 256 x 256 f32 partial tiles
+  float* slabs;       // [tiles][S] x 256 x (256 | 320) f32 partial tiles
   int* tickets;       // [tiles], zero when the workspace is created; the last arriver of a tile re-arms its ticket
 };
 
@@ -70,23 +82,30 @@ __device__ inline void dw_wait_vmcnt(int n) {
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
-__device__ inline void dw_wait_steady() {          // steady state: all but the 2 (D - 2) youngest DMA instructions landed
-  static_assert(DW_D == 4 || DW_D == 6 || DW_D == 8, "add the immediate");
-  if constexpr (DW_D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (DW_D == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+template <int N> __device__ inline void dw_wait_steady() {          // steady state: all but the 4 youngest units landed
+  static_assert(N == 8 || N == 9, "add the immediate");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 }
 
+template <int KW>
 __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];   // DW_SLOTS x 16 KiB
+  typedef DwGeom<KW> G;
+  constexpr int KB = KW - 2;                  // k-tiles of a wave's second k-set (the first has 2)
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // two steps of G::STEP bytes
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wid >> 2, wc = wid & 3;      // wr: 128-wide n half of the tile, wc: 64-wide k quarter
+  const int wr = wid >> 2, wc = wid & 3;      // wr: 128-wide n half of the tile, wc: k quarter (64 | 80 columns)
   const bool hi = wr != 0;
   const int fr = lane & 15, kg = lane >> 4;
 
@@ -113,10 +132,13 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
   // position (lane & 15) = 32-byte slot (lane >> 1) & 7, half (lane & 1); the slot holds source slot ^ f(row), with
   // f(row) = (row & 3) | ((row >> 3) & 1) << 2 and row = 8 * wid + 4 * j + (lane >> 4) for instruction j of the wave.
   // Unit column c (0..127) of dY-units = tile column (c >> 6) * 128 + (c & 63) (+64 for the second halves); of X-units =
-  // (c >> 5) * 64 + (c & 31) (+32).
+  // (c >> 5) * WK + (c & 31) (+32): the first two 16-column k-tiles of every wave, then the next two.
+  // KW = 5: the fifth k-tile of the four waves is a third X piece of 64 rows x 64 columns (128-byte rows, 8 per
+  // wave-instruction: lane -> row (lane >> 3), slot (lane >> 1) & 3, f(row) = ((row >> 1) & 1) | ((row >> 3) & 1) << 1),
+  // column c (0..63) = tile column (c >> 4) * 80 + 64 + (c & 15).
   const int drow = lane >> 4;                 // 0..3
   const int dpos = lane & 15;
-  unsigned voY[2], voX[2];
+  unsigned voY[2], voX[2], voX2 = 0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = 8 * wid + 4 * j + drow;                         // unit row 0..63
@@ -124,18 +146,26 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
     const int src_slot = ((dpos >> 1) & 7) ^ f;
     const int c = src_slot * 16 + (dpos & 1) * 8;                    // first unit column of this lane's 8 bf16
     voY[j] = (unsigned)(((int64_t)row * a.ldy + (c >> 6) * 128 + (c & 63)) * 2);
-    voX[j] = (unsigned)(((int64_t)row * a.ldx + (c >> 5) * 64 + (c & 31)) * 2);
+    voX[j] = (unsigned)(((int64_t)row * a.ldx + (c >> 5) * G::WK + (c & 31)) * 2);
+  }
+  if constexpr (KW == 5) {
+    const int row = 8 * wid + (lane >> 3);
+    const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    const int src_slot = ((lane >> 1) & 3) ^ f;
+    const int c = src_slot * 16 + (lane & 1) * 8;
+    voX2 = (unsigned)(((int64_t)row * a.ldx + (c >> 4) * 80 + 64 + (c & 15)) * 2);
   }
 
   // ---- fragment read constants (transposing reads): lane fr = 4 q + p of a 16-lane group addresses row q, columns
   // 4 p .. 4 p + 3 of a 4 x 16 block and receives column fr of its 4 rows
   const int frow = kg * 8 + (fr >> 2);
   const int ff = ((fr >> 2) & 3) | ((kg & 1) << 2);                  // f(row) for rows frow (+4) (+32 ks)
-  int offY[4], offX[2];                                              // byte offsets inside a unit, k-step 0, "lo" rows
+  int offY[4], offX[2], offX2 = 0;                                   // byte offsets inside a unit, k-step 0, "lo" rows
 #pragma unroll
   for (int j = 0; j < 4; ++j) offY[j] = frow * 256 + (((wr * 4 + j) ^ ff) << 5) + (fr & 3) * 8;
 #pragma unroll
   for (int i = 0; i < 2; ++i) offX[i] = frow * 256 + (((wc * 2 + i) ^ ff) << 5) + (fr & 3) * 8;
+  if constexpr (KW == 5) offX2 = frow * 128 + ((wc ^ (((fr >> 3) & 1) | ((kg & 1) << 1))) << 5) + (fr & 3) * 8;
 
   // ---- this workgroup's (slab, tile) item.  Items of a slab are consecutive; item j of a slab runs on XCD j % 8
   // (workgroups are dealt round-robin over the XCDs), which owns a contiguous chunk of the tn-major tile list: the
@@ -167,19 +197,17 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
     const int s0 = (int)((int64_t)a.steps * slab_i / a.S);
     const int s1 = (int)((int64_t)a.steps * (slab_i + 1) / a.S);
     const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
-    const int n0 = tn * DW_T, k0 = tk * DW_T;
+    const int n0 = tn * DW_T, k0 = tk * G::BK;
     const int nkt = s1 - s0;                                 // >= 1 (the launcher keeps S <= max(1, steps / 2))
     const int nunits = 4 * nkt;
 
-    f32x4 acc[2][2][4][2];               // [n-half][k-half][n-tile][k-tile]
+    f32x4 acc[2][KW][4];                 // [n-half][k-tile][n-tile]   (k-tiles 0, 1 = first k-set, 2 .. KW-1 = second)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int q = 0; q < KW; ++q)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) acc[i][j][p][q] = f32x4{0, 0, 0, 0};
+        for (int p = 0; p < 4; ++p) acc[i][q][p] = f32x4{0, 0, 0, 0};
 
     // scalar offsets of this segment: first token row, tile columns
     const int sbY = (int)(((int64_t)s0 * DW_BR * a.ldy + n0) * 2);
@@ -187,69 +215,95 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
     const int stepY = (int)(a.ldy * DW_BR * 2), stepX = (int)(a.ldx * DW_BR * 2);
 
     int u_issue = 0;
-    // KIND 0 / 3: first / second 64-column halves of the dY tile halves; KIND 1 / 2: first / second 32-column halves of X
+    // KIND 0 / 3: first / second 64-column halves of the dY tile halves; KIND 1 / 2: first / second k-sets of X
     auto issue_unit = [&](auto kind_c) {
       constexpr int KIND = decltype(kind_c)::value;
       constexpr bool isY = KIND == 0 || KIND == 3;
-      constexpr bool second = KIND >= 2;
-      const unsigned dst = lds0 + (u_issue % DW_SLOTS) * DW_UNIT + wid * 2048;
+      const unsigned dst = lds0 + ((u_issue >> 2) & 1) * G::STEP + G::unit_off(KIND) + wid * 2048;
       const int t = u_issue >> 2;
       if constexpr (isY) {
-        const int so = sbY + t * stepY + (second ? 128 : 0);
+        const int so = sbY + t * stepY + (KIND == 3 ? 128 : 0);
         dma16(dst, voY[0], so, rsY);
         dma16(dst + 1024, voY[1], so, rsY);
       } else {
-        const int so = sbX + t * stepX + (second ? 64 : 0);
+        const int so = sbX + t * stepX + (KIND == 2 ? 64 : 0);
         dma16(dst, voX[0], so, rsX);
         dma16(dst + 1024, voX[1], so, rsX);
+        if constexpr (KIND == 2 && KW == 5)
+          dma16(lds0 + ((u_issue >> 2) & 1) * G::STEP + G::unit_off(2) + DW_UNIT + wid * 1024, voX2, sbX + t * stepX, rsX);
       }
       ++u_issue;
     };
 #define DW_IC(v) std::integral_constant<int, v>()
 
     bf16x8 Yf[2][4];                     // [k-step][n-tile]   (the n half in use)
-    bf16x8 Xf[2][2][2];                  // [k-half][k-step][k-tile]
-    auto tr8 = [&](const char* p) {
+    bf16x8 XfA[2][2];                    // first k-set:  [k-step][k-tile]
+    bf16x8 XfB[2][KB];                   // second k-set
+    auto tr8s = [&](const char* p, int hi_off) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
-      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * 256));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + hi_off));
       const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
       return __builtin_bit_cast(bf16x8, v);
     };
-    auto readY = [&](int unit) {
-      const char* base = lds + (unit % DW_SLOTS) * DW_UNIT;
+    auto tr8 = [&](const char* p) { return tr8s(p, 4 * 256); };
+    auto unit_base = [&](int unit) { return lds + ((unit >> 2) & 1) * G::STEP; };   // + G::unit_off(kind)
+    auto readY = [&](int unit, auto kind_c) {
+      const char* base = unit_base(unit) + G::unit_off(decltype(kind_c)::value);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j) Yf[ks][j] = tr8(base + ks * (32 * 256) + offY[j]);
     };
-    auto readX = [&](int kh, int unit) {
-      const char* base = lds + (unit % DW_SLOTS) * DW_UNIT;
+    auto readXA = [&](int unit) {
+      const char* base = unit_base(unit) + G::unit_off(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) Xf[kh][ks][i] = tr8(base + ks * (32 * 256) + offX[i]);
+        for (int i = 0; i < 2; ++i) XfA[ks][i] = tr8(base + ks * (32 * 256) + offX[i]);
     };
-    auto mma = [&](int nh, int kh) {
+    auto readXB = [&](int unit) {
+      const char* base = unit_base(unit) + G::unit_off(2);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) XfB[ks][i] = tr8(base + ks * (32 * 256) + offX[i]);
+        if constexpr (KW == 5) XfB[ks][2] = tr8s(base + DW_UNIT + ks * (32 * 128) + offX2, 4 * 128);
+      }
+    };
+    auto mma = [&](int nh, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (SET == 0) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[nh][kh][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Xf[kh][ks][i], Yf[ks][j], acc[nh][kh][j][i], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+              acc[nh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XfA[ks][i], Yf[ks][j], acc[nh][i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < KB; ++i)
+              acc[nh][2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XfB[ks][i], Yf[ks][j], acc[nh][2 + i][j], 0, 0, 0);
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
 
     int g = 0;
+    auto younger = [&](int units) {          // DMA instructions of this wave in the `units` youngest issued units
+      int n = 0;
+      for (int v = u_issue - units; v < u_issue; ++v) n += (KW == 5 && (v & 3) == 2) ? 3 : 2;
+      return n;
+    };
     auto wait_landed = [&]() {
       int need = g + 2;
       need = need < nunits - 1 ? need : nunits - 1;
       const int ok = (u_issue - 1) - need;
-      if (ok == DW_D - 2) dw_wait_steady();
-      else dw_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+      if (ok == DW_D - 2) dw_wait_steady<G::INFLIGHT>();
+      else dw_wait_vmcnt(ok > 0 ? younger(ok) : 0);
     };
 
     // ---- prologue (see csrc/dense_gemm.hip for the protocol)
@@ -260,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
 #undef DW_PRO
     {
       const int ok = (u_issue - 1) - 1;
-      dw_wait_vmcnt(ok > 0 ? 2 * ok : 0);
+      dw_wait_vmcnt(ok > 0 ? younger(ok) : 0);
     }
     if (hi) __builtin_amdgcn_s_barrier();
 
@@ -271,41 +325,41 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
         if (STEADY || u_issue < nunits) issue_unit(kind_c);
       };
       auto landed = [&]() {
-        if constexpr (STEADY) dw_wait_steady();
+        if constexpr (STEADY) dw_wait_steady<G::INFLIGHT>();
         else wait_landed();
       };
       // phase 0: first n half x first k half
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(2);
       dma(DW_IC((0 + DW_D) & 3));
-      readY(b0);
-      readX(0, b0 + 1);
+      readY(b0, DW_IC(0));
+      readXA(b0 + 1);
       __builtin_amdgcn_s_setprio(0);
       if (hi) landed();
       __builtin_amdgcn_s_barrier();
-      mma(0, 0);
+      mma(0, DW_IC(0));
       if (!hi) landed();
       ++g;
       // phase 1: first n half x second k half
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(2);
       dma(DW_IC((1 + DW_D) & 3));
-      readX(1, b0 + 2);
+      readXB(b0 + 2);
       __builtin_amdgcn_s_setprio(0);
       if (hi) landed();
       __builtin_amdgcn_s_barrier();
-      mma(0, 1);
+      mma(0, DW_IC(1));
       if (!hi) landed();
       ++g;
       // phase 2: second n half x second k half
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(2);
       dma(DW_IC((2 + DW_D) & 3));
-      readY(b0 + 3);
+      readY(b0 + 3, DW_IC(3));
       __builtin_amdgcn_s_setprio(0);
       if (hi) landed();
       __builtin_amdgcn_s_barrier();
-      mma(1, 1);
+      mma(1, DW_IC(1));
       if (!hi) landed();
       ++g;
       // phase 3: second n half x first k half
@@ -315,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
       __builtin_amdgcn_s_setprio(0);
       if (hi) landed();
       __builtin_amdgcn_s_barrier();
-      mma(1, 0);
+      mma(1, DW_IC(0));
       if (!hi) landed();
       ++g;
     };
@@ -328,73 +382,92 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
     if (!hi) __builtin_amdgcn_s_barrier();   // re-align the two groups
     __builtin_amdgcn_s_barrier();            // the ring is idle
 
-    // ---- partial tile: publish, last arriver of the tile reduces (plain stores -> drain -> barrier -> agent release ->
-    // ticket; reducer: agent acquire -> barrier).
-    bool reducer = a.S == 1;
-    if (a.S > 1) {
-      float* slab = a.slabs + ((int64_t)tile * a.S + slab_i) * (DW_T * DW_T);
-      f32x4* sw4 = (f32x4*)slab + (int64_t)wid * 32 * 64 + lane;
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) sw4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64] = acc[nh][kh][j][i];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int* flag = (int*)lds;
-      if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int old = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = (old == a.S - 1) ? 1 : 0;
-        if (old == a.S - 1) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-        }
-      }
-      __syncthreads();
-      reducer = flag[0] != 0;
-      __syncthreads();
-      if (reducer) {
-        // fixed order: slab 0 + slab 1 + ... (the reducer's own partial is re-read from its slab)
-        for (int w = 0; w < a.S; ++w) {
-          const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)tile * a.S + w) * (DW_T * DW_T)) + (int64_t)wid * 32 * 64 + lane;
-#pragma unroll
-          for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                  const f32x4 o = o4[(((nh * 2 + kh) * 4 + j) * 2 + i) * 64];
-                  acc[nh][kh][j][i] = w == 0 ? o : acc[nh][kh][j][i] + o;
-                }
-        }
-      }
-    }
-
-    // ---- epilogue: lane (fr, kg) of MFMA tile (n-tile j, k-tile i) holds dW[n = .. + fr][k = .. + 4 kg .. + 3]
-    if (reducer) {
+    // ---- partial tiles.  Ticket FIRST (one word per tile: arrivals in the low half, completed publications in the high
+    // half): the first S - 1 workgroups to arrive publish their f32 partial (plain stores -> drain -> barrier -> agent
+    // release -> count) and leave; the LAST arriver publishes nothing - it waits until the others' partials are complete
+    // (they all hold a ticket, i.e. they are running: the wait cannot deadlock), then sums the S partials in slab order with
+    // its own taken from the accumulator registers, half a tile at a time (the running sum lives in the registers the
+    // operand fragments used).  Slab traffic is (S - 1) / S of "everyone publishes, the last arriver re-reads all S"
+    // (tools/ab_tn_tile.py --slabs: the round trip was 52 us of a 219 us launch at S = 2, in proportion to the bytes).
+    if (a.S == 1) {
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = n0 + wr * 128 + nh * 64 + j * 16 + fr;
-          if (n < a.N) {
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const int k = k0 + wc * 64 + kh * 32 + i * 16 + kg * 4;
-                if (k < a.K) *(f32x4*)(a.W + (int64_t)n * a.K + k) = acc[nh][kh][j][i];
-              }
+          for (int q = 0; q < KW; ++q) {
+            const int k = k0 + wc * G::WK + q * 16 + kg * 4;
+            if (n < a.N && k < a.K) *(f32x4*)(a.W + (int64_t)n * a.K + k) = acc[nh][q][j];
           }
         }
+    } else {
+      int* flag = (int*)lds;
+      if (threadIdx.x == 0) {
+        const unsigned old = (unsigned)__hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = ((int)(old & 0xFFFFu) == a.S - 1) ? 1 : 0;
+      }
+      __syncthreads();
+      const bool last = flag[0] != 0;
+      if (!last) {
+        float* slab = a.slabs + ((int64_t)tile * a.S + slab_i) * (DW_T * G::BK);
+        f32x4* sw4 = (f32x4*)slab + (int64_t)wid * (8 * KW) * 64 + lane;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int q = 0; q < KW; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sw4[((nh * KW + q) * 4 + j) * 64] = acc[nh][q][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_fetch_add(a.tickets + tile, 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        if (threadIdx.x == 0) {
+          while (((unsigned)__hip_atomic_load(a.tickets + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) != (unsigned)(a.S - 1))
+            __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int jh = 0; jh < 2; ++jh) {                 // a quarter of the wave's tile at a time: 2 n-tiles x KW k-tiles
+            f32x4 t[KW][2];
+            for (int w = 0; w < a.S; ++w) {
+              if (w == slab_i) {
+#pragma unroll
+                for (int q = 0; q < KW; ++q)
+#pragma unroll
+                  for (int j = 0; j < 2; ++j) t[q][j] = w == 0 ? acc[nh][q][jh * 2 + j] : t[q][j] + acc[nh][q][jh * 2 + j];
+              } else {
+                const f32x4* o4 = (const f32x4*)(a.slabs + ((int64_t)tile * a.S + w) * (DW_T * G::BK)) + (int64_t)wid * (8 * KW) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < KW; ++q)
+#pragma unroll
+                  for (int j = 0; j < 2; ++j) {
+                    const f32x4 o = o4[((nh * KW + q) * 4 + jh * 2 + j) * 64];
+                    t[q][j] = w == 0 ? o : t[q][j] + o;
+                  }
+              }
+            }
+            // lane (fr, kg) of MFMA tile (n-tile j, k-tile q) holds dW[n = .. + fr][k = .. + 4 kg .. + 3]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int n = n0 + wr * 128 + nh * 64 + (jh * 2 + j) * 16 + fr;
+#pragma unroll
+              for (int q = 0; q < KW; ++q) {
+                const int k = k0 + wc * G::WK + q * 16 + kg * 4;
+                if (n < a.N && k < a.K) *(f32x4*)(a.W + (int64_t)n * a.K + k) = t[q][j];
+              }
+            }
+          }
+      }
     }
   }
 }
@@ -403,11 +476,28 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
 
 using namespace octic;
 
+template <int KW>
+static int dw_launch(DwArgs& a, hipStream_t s) {
+  const int smem = DwGeom<KW>::RING;
+  static DeviceOnce once;
+  if (once.first()) {
+    (void)hipFuncSetAttribute((const void*)dense_tn_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipGetLastError();
+  }
+#if DW_MAP == 1
+  dense_tn_kernel<KW><<<(a.tiles * a.S + 255) / 256 * 256, 512, smem, s>>>(a);
+#else
+  dense_tn_kernel<KW><<<a.tiles8 * a.S, 512, smem, s>>>(a);
+#endif
+  return launch_status();
+}
+
 extern "C" {
 
 // Row slabs: the items (tiles8 x S) run in ceil(items / CUs) rounds of ceil(steps / S) reduction steps each; every item
 // also pays a fixed prologue + slab epilogue (about 8 steps' worth).  Pick the S with the shortest estimate.
 static int g_tn_slabs_override = 0;
+static int g_tn_width_override = 0;    // developer knob: 256 | 320 forces the tile width where the shape allows it
 static int dw_slabs(int tiles, int steps) {
   if (g_tn_slabs_override > 0) return g_tn_slabs_override <= steps / 2 ? g_tn_slabs_override : (steps / 2 > 0 ? steps / 2 : 1);
   const int cus = device_cus();
@@ -431,50 +521,80 @@ static int dw_slabs(int tiles, int steps) {
   return best;
 }
 
+// Tile width along k.  The 320-wide tile was built for occupancy (at M = 16 448: 5120 x 1280 and 1280 x 5120 are 100 tiles
+// x 2 slabs = 200 workgroups at 256 wide, 80 x 3 = 240 at 320) and measured NO faster on any ViT-H shape
+// (tools/ab_tn_tile.py, same process, us at 256 | 320: 5120 x 1280 200-213 | 198-207, 1280 x 5120 210-214 | 209-212,
+// 3840 x 1280 154 | 169, 1280 x 1280 90 | 109): with 240 instead of 200 CUs busy every step gets slower - the launch is
+// bound by what the whole chip sustains (~1.05 PFLOP/s for this kernel), not by idle CUs.  So the 256-wide tile is used
+// wherever K allows it; the 320-wide one serves K % 320 == 0 && K % 256 != 0 (and the developer knob).
+struct DwPlan { int kw, tiles_k, tiles, S; };
+static DwPlan dw_plan(int M, int N, int K) {
+  const int steps = (M + DW_BR - 1) / DW_BR;
+  auto make = [&](int kw) {
+    DwPlan p;
+    p.kw = kw;
+    p.tiles_k = K / (64 * kw);
+    p.tiles = (N / DW_T) * p.tiles_k;
+    p.S = dw_slabs(p.tiles, steps);
+    return p;
+  };
+  const bool ok4 = K % 256 == 0, ok5 = K % 320 == 0;          // (the entry points refuse K that fits neither)
+  if (ok5 && (!ok4 || g_tn_width_override == 320)) return make(5);
+  return make(4);
+}
+
 int octic_dbg_dense_wgrad_slabs(int S) {      // developer knob: force the number of row slabs (0 = automatic)
   const int old = g_tn_slabs_override;
   g_tn_slabs_override = S;
   return old;
 }
 
+int octic_dbg_dense_wgrad_tile(int width) {   // developer knob: force the tile width (256 | 320; 0 = automatic)
+  const int old = g_tn_width_override;
+  g_tn_width_override = width;
+  return old;
+}
+
+int octic_dense_wgrad_tile(int M, int N, int K) {      // tile width the launch uses (256 | 320)
+  if (M <= 0 || N <= 0 || K <= 0 || (N % DW_T) || ((K % 256) && (K % 320))) return 0;
+  return dw_plan(M, N, K).kw * 64;
+}
+
 int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K) {
-  const int tiles = (N / DW_T) * (K / DW_T);
+  // room for either width and any forced slab count: [4 KiB tickets (<= 1024 tiles) | slabs]
   const int steps = (M + DW_BR - 1) / DW_BR;
-  const int S = g_tn_slabs_override > 0 ? 16 : dw_slabs(tiles, steps);      // room for any forced value
-  return (int64_t)tiles * S * (DW_T * DW_T) * 4 + 4096;      // [4 KiB tickets (<= 1024 tiles) | slabs]
+  int64_t need = 0;
+  for (int kw = 4; kw <= 5; ++kw) {
+    if (K % (64 * kw)) continue;
+    const int tiles = (N / DW_T) * (K / (64 * kw));
+    const int S = g_tn_slabs_override > 0 ? 16 : dw_slabs(tiles, steps);
+    const int64_t b = (int64_t)tiles * S * (DW_T * 64 * kw) * 4;
+    need = b > need ? b : need;
+  }
+  return need + 4096;
 }
 
 int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
                          void* workspace, void* stream) {
   if (!dY || !X || !dW || !workspace) return OCTIC_ENULL;
-  if (M <= 0 || N <= 0 || K <= 0 || (N % DW_T) || (K % DW_T) || (ldy % 8) || (ldx % 8)) return OCTIC_ESHAPE;
-  if ((N / DW_T) * (K / DW_T) > 1024) return OCTIC_ESHAPE;    // ticket region
+  if (M <= 0 || N <= 0 || K <= 0 || (N % DW_T) || ((K % 256) && (K % 320)) || (ldy % 8) || (ldx % 8)) return OCTIC_ESHAPE;
   if ((int64_t)M * ldy * 2 >= (1ll << 31) || (int64_t)M * ldx * 2 >= (1ll << 31)) return OCTIC_ESHAPE;   // 32-bit buffer offsets
   if ((((uintptr_t)dY) | ((uintptr_t)X) | ((uintptr_t)dW)) & 15) return OCTIC_EALIGN;
+  const DwPlan pl = dw_plan(M, N, K);
+  if (pl.tiles > 1024) return OCTIC_ESHAPE;                   // ticket region
   DwArgs a = {};
   a.Y = (const bf16*)dY; a.X = (const bf16*)X; a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
   a.W = dW;
-  a.tiles_k = K / DW_T;
-  a.tiles = (N / DW_T) * a.tiles_k;
+  a.tiles_k = pl.tiles_k;
+  a.tiles = pl.tiles;
   a.tiles8 = (a.tiles + 7) / 8 * 8;
   a.steps = (M + DW_BR - 1) / DW_BR;
-  a.S = dw_slabs(a.tiles, a.steps);
+  a.S = pl.S;
   a.tickets = (int*)workspace;
   char* p = (char*)workspace + 4096;         // fixed ticket region: a workspace shared by several shapes keeps its zeros
   a.slabs = (float*)p;
   hipStream_t s = (hipStream_t)stream;
-  const int smem = DW_SLOTS * DW_UNIT;
-  static DeviceOnce once;
-  if (once.first()) {
-    (void)hipFuncSetAttribute((const void*)dense_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipGetLastError();
-  }
-#if DW_MAP == 1
-  dense_tn_kernel<<<(a.tiles * a.S + 255) / 256 * 256, 512, smem, s>>>(a);
-#else
-  dense_tn_kernel<<<a.tiles8 * a.S, 512, smem, s>>>(a);
-#endif
-  return launch_status();
+  return pl.kw == 5 ? dw_launch<5>(a, s) : dw_launch<4>(a, s);
 }
 
 }  // extern "C"

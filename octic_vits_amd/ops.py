@@ -248,7 +248,7 @@ _DW_WS = {}
 
 
 def dense_wgrad_ok(M, N, K):
-    return N % 256 == 0 and K % 256 == 0 and (N // 256) * (K // 256) <= 256 and M > 0
+    return N % 256 == 0 and (K % 256 == 0 or K % 320 == 0) and (N // 256) * (K // 256) <= 256 and M > 0
 
 
 def dense_wgrad_tn(dy, x, name=None):

@@ -277,3 +277,79 @@ def test_dense_wgrad_tn_integer_operands_exact(M, N, K):
     dw = o.dense_wgrad_tn(dy, x)
     want = dy.double().t() @ x.double()          # |sum| <= 6 * 16448 < 2^24: exact in f32
     assert torch.equal(dw.double(), want), f"{int((dw.double() != want).sum())} wrong elements"
+
+
+# round 4: the 256 x 320 tile of the TN kernel (K % 320 == 0: 80 tiles x 3 slabs instead of 100 x 2 for the MLP weights)
+def _force_tn_tile(width):
+    """developer switch of csrc/dense_wgrad.hip: tile width along K (0 = launch estimate, 256, 320)"""
+    import ctypes
+    from octic_vits_amd import _lib
+    _lib.lib()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.octic_dbg_dense_wgrad_tile.argtypes = [ctypes.c_int]
+    raw.octic_dbg_dense_wgrad_tile.restype = ctypes.c_int
+    raw.octic_dbg_dense_wgrad_tile(width)
+
+
+TN320_SHAPES = [(200, 256, 320), (64, 512, 640), (1, 256, 320), (130, 256, 960), (1000, 768, 1280), (16448, 1280, 1280),
+                (16448, 3840, 1280), (16448, 5120, 1280), (16448, 1280, 5120), (12608, 1024, 1280)]
+
+
+@pytest.mark.parametrize("M,N,K", TN320_SHAPES)
+def test_dense_wgrad_tn_both_tile_widths_integer_exact(M, N, K):
+    """Small-integer operands: every partial sum is an integer below 2^24, so both tile widths, every slab count and the
+    fp64 product agree bit for bit (ragged M: rows past M read as zero through the buffer descriptor)."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    dy = torch.randint(-2, 3, (M, N), generator=g, device=DEV).to(torch.bfloat16)
+    x = torch.randint(-3, 4, (M, K), generator=g, device=DEV).to(torch.bfloat16)
+    want = dy.double().t() @ x.double()
+    try:
+        for width in (320, 256, 0):
+            _force_tn_tile(width)
+            if width and K % width == 0:
+                assert lib_tile(o, M, N, K) == width
+            dw = o.dense_wgrad_tn(dy, x)
+            assert torch.equal(dw.double(), want), f"width {width}: {int((dw.double() != want).sum())} wrong elements"
+    finally:
+        _force_tn_tile(0)
+
+
+def lib_tile(o, M, N, K):
+    from octic_vits_amd import _lib
+    return int(_lib.lib().octic_dense_wgrad_tile(M, N, K))
+
+
+@pytest.mark.parametrize("M,N,K", [(16448, 5120, 1280), (16448, 1280, 5120), (16448, 1280, 1280), (700, 512, 640)])
+def test_dense_wgrad_tn_320_wide_tile_random_operands(M, N, K):
+    """Random operands at the 320-wide tile vs fp64 (2e-4 of scale, the bound of test_dense_wgrad_tn), bitwise repeatable -
+    also right after a launch of another shape and width went through the shared workspace - and within f32 summation
+    noise of the 256-wide tile."""
+    o = ops()
+    dy, x = rnd((M, N), 61), rnd((M, K), 62)
+    want = dy.double().t() @ x.double()
+    try:
+        _force_tn_tile(320)
+        first = o.dense_wgrad_tn(dy, x)
+        close(first, want, 2e-4, f"wgrad 320-wide {M}x{N}x{K}")
+        _force_tn_tile(256)
+        other = o.dense_wgrad_tn(dy, x)
+        o.dense_wgrad_tn(rnd((900, 512), 63), rnd((900, 1280), 64))
+        _force_tn_tile(320)
+        o.dense_wgrad_tn(rnd((3000, 256), 65), rnd((3000, 640), 66))
+        for _ in range(2):
+            assert torch.equal(o.dense_wgrad_tn(dy, x), first), "320-wide wgrad not bitwise repeatable"
+        scale = max(1.0, float(want.abs().max()))
+        assert float((first - other).abs().max()) <= 1e-4 * scale
+    finally:
+        _force_tn_tile(0)
+
+
+def test_dense_wgrad_tn_default_width():
+    """256-wide tiles wherever K allows (the 320-wide tile measured no faster on the ViT-H shapes: csrc/dense_wgrad.hip
+    dw_plan), 320-wide for K % 320 == 0 only."""
+    o = ops()
+    for N, K in ((3840, 1280), (1280, 1280), (5120, 1280), (1280, 5120), (1024, 1024)):
+        assert lib_tile(o, 16448, N, K) == 256, (N, K)
+    assert lib_tile(o, 16448, 1280, 960) == 320
+    assert lib_tile(o, 16448, 1280, 200) == 0

@@ -6,6 +6,7 @@ O=gpurun_out
 B="python3 bench.py --no-cpu-baseline --no-forward-only --no-kernel-timing --no-graph"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_trace -- python3 bench.py --no-cpu-baseline --no-forward-only --no-step-variants --steps 10 --warmup 3 > $O/prof_trace.json 2> $O/prof_trace.log
 python3 tools/rocprof_summary.py $O/prof_trace $O/rocprof_r4_bench.txt
+python3 tools/step_gaps.py $O/prof_trace $O/step_gaps_r4.txt > /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --steps 3 --warmup 2 > /dev/null 2> $O/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B --steps 3 --warmup 2 > /dev/null 2> $O/pmc_write.log
 python3 tools/traffic_from_pmc.py $O/pmc_fetch $O/pmc_write $O/traffic_r4.json > $O/traffic_r4.txt
