@@ -168,6 +168,10 @@ extern "C" void* octic_dbg_dense_trace2(void) {
 // GELU for the fused epilogues.  The epilogue runs after the main loop with nothing to hide its VALU work behind (one
 // workgroup per CU), and libm's erff costs ~40 instructions per element (~100 us for the 84 M elements of fc1).  erf by
 // Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, one v_exp + one v_rcp + 6 fma) is far inside the bf16 output's 2^-9.
+// (Round 4: the math of the GELU tail is 3.8 us of a tile's 8.3 us epilogue - tools/dense_phases.py with FLAGS=-DDG_ABL=32 - and
+// VALU-throughput bound: a transcendental-free form, Phi(x) = 1/2 + x P12(0.08 x^2 - 1) on |x| <= 5, thirteen packed fmas and
+// 3.9e-7 of error, was built and timed EQUAL (245 vs 246 us per launch): the quarter-rate v_exp / v_rcp overlap the packed
+// fmas of the other wave, so the form with fewer full-rate instructions stays.)
 __device__ inline float dg_erf(float x) {
   const float ax = fabsf(x);
   // v_rcp_f32 (1 ulp): __frcp_rn / 1.0f/x expand to the IEEE division sequence (div_scale x2, rcp, 4 fma, div_fmas,
@@ -177,10 +181,15 @@ __device__ inline float dg_erf(float x) {
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
+#if DG_ABL & 32   // timing-only ablation: the fused tails without their transcendental math (what the VALU part of the epilogue costs)
+__device__ inline float dg_gelu(float x) { return 0.5f * x; }
+__device__ inline float dg_gelu_grad(float x) { return 0.5f + 0.25f * x; }
+#else
 __device__ inline float dg_gelu(float x) { return 0.5f * x * (1.0f + dg_erf(x * kSqrt1Over2)); }
 __device__ inline float dg_gelu_grad(float x) {
   return 0.5f * (1.0f + dg_erf(x * kSqrt1Over2)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
 }
+#endif
 
 template <int N>
 __device__ inline void dg_wait_imm() {

@@ -35,6 +35,14 @@ for (N, K) in [(3840, 1280), (1280, 1280), (5120, 1280), (1280, 5120), (1280, 38
     b = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
     t = timeit(lambda: ops.dense_gemm_nt(a, b, 0))
     out.append("%%6.1f" %% (2.0 * M * N * K / t / 1e6))
+if os.environ.get("TAILS"):            # fused tails at the MLP shape: us of fc1 + GELU and of the fc2 input gradient x GELU'
+    a = torch.randn(M, 1280, device="cuda").to(torch.bfloat16)
+    b = (torch.randn(5120, 1280, device="cuda") * 1280 ** -0.5).to(torch.bfloat16)
+    h = torch.randn(M, 5120, device="cuda").to(torch.bfloat16)
+    bias = torch.randn(5120, device="cuda")
+    out.append("| gelu %%6.1f us" %% timeit(lambda: ops.dense_gemm_nt(a, b, 1, bias=bias)))
+    out.append("dgelu %%6.1f us" %% timeit(lambda: ops.dense_gemm_nt(a, b, 3, h=h, want_colsum=True)))
+    out.append("plain %%6.1f us" %% timeit(lambda: ops.dense_gemm_nt(a, b, 0, bias=bias)))
 print(" ".join(out))
 ''' % ROOT
 for r in range(rounds):
