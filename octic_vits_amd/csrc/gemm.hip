@@ -324,27 +324,13 @@ extern "C" void* octic_dbg_ring_trace(void) {
 #define RTRACE(slot) do {} while (0)
 #endif
 
-template <typename TIN, typename TOUT, int EPI, int NT, int S, int BM = 128>
-__global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args) {
-  constexpr int NW = BM / 32;                 // waves: each owns 32 rows x BN columns
-  constexpr int EPC = Elem<TIN>::EPC;
-  constexpr int BKE = 8 * EPC;
-  constexpr int MT = 2;
-  constexpr int BN = 16 * NT;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int WI = BN / 8;                  // W DMA instructions per tile (8 rows each)
-  constexpr int WQ = (WI + NW - 1) / NW;      // per wave, at most
-  typedef typename Elem<TIN>::frag frag;
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // S stages x (128 + BN) rows x 128 B
-
-  const int nwg = gridDim.x, bid = blockIdx.x;
+// Work item of workgroup `bid` of a ring launch of `nwg` workgroups: group gi, item lt of the group (m-tile x n-chunk).
+// Workgroups are dealt round-robin to the eight XCDs; `tile` walks the launch XCD by XCD.
+__host__ __device__ inline void ring_item_of(const GemmArgs& args, int nwg, int bid, int& gi, int& lt) {
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  // `tile` walks the launch XCD by XCD.  Every group's items are spread evenly over the eight XCDs, the E irrep's
-  // first: an E item takes 1.6x the time of a one-dimensional one, and with the groups laid out one after the other
-  // XCDs 0-3 ran only E items and XCDs 4-7 only short ones (HW_ID timeline, tools/ring_trace.py: per-CU spans of
-  // 95 k .. 200 k cycles for one launch).  Segment k of the order = [share k of group 0 | share k of group 1 | ...].
-  int gi = 0, lt = 0;
+  gi = 0;
+  lt = 0;
   if (args.plan_mode == 1) {
     // planned order (plan_ring below): XCD x runs, in dispatch order, a few short items, its share of the long group, then
     // short items - so that the workgroup slots that must take a third item are slots that started with a short one
@@ -394,6 +380,31 @@ __global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args
       if (!found) r -= sz;
     }
   }
+}
+
+template <typename TIN, typename TOUT, int EPI, int NT, int S, int BM = 128>
+__global__ __launch_bounds__(BM * 2, 2) void linear_d8_ring_kernel(GemmArgs args) {
+  constexpr int NW = BM / 32;                 // waves: each owns 32 rows x BN columns
+  constexpr int EPC = Elem<TIN>::EPC;
+  constexpr int BKE = 8 * EPC;
+  constexpr int MT = 2;
+  constexpr int BN = 16 * NT;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int WI = BN / 8;                  // W DMA instructions per tile (8 rows each)
+  constexpr int WQ = (WI + NW - 1) / NW;      // per wave, at most
+  typedef typename Elem<TIN>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // S stages x (128 + BN) rows x 128 B
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // `tile` walks the launch XCD by XCD.  Every group's items are spread evenly over the eight XCDs, the E irrep's
+  // first: an E item takes 1.6x the time of a one-dimensional one, and with the groups laid out one after the other
+  // XCDs 0-3 ran only E items and XCDs 4-7 only short ones (HW_ID timeline, tools/ring_trace.py: per-CU spans of
+  // 95 k .. 200 k cycles for one launch).  Segment k of the order = [share k of group 0 | share k of group 1 | ...].
+  (void)tile;                                 // (the timeline build indexes its stamps with it)
+  int gi, lt;
+  ring_item_of(args, nwg, bid, gi, lt);
   const GemmGroup& G = args.g[gi];
   // work item = (m-tile, chunk of consecutive n-tiles); the DMA ring runs continuously over its (n-tile, k-tile) steps
   const int mt = lt / G.n_chunks, nc = lt - mt * G.n_chunks;
@@ -915,6 +926,30 @@ inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
 using namespace octic;
 
 extern "C" void octic_dbg_ring_plan(int off) { octic::g_ring_plan_off = off; }
+
+// Developer / test entry (host only, no device call): the item order of a ring launch.  items[g] / ksteps[g] describe
+// group g (group 0 = the long one); out_group / out_item receive, per workgroup in blockIdx order, the item it would run.
+// Returns the plan mode (1 = planned order, 0 = even spread) or a negative error.
+extern "C" int octic_dbg_ring_order(int ngroups, const int* items, const int* ksteps, int slots_per_xcd, int* out_group,
+                                    int* out_item) {
+  if (ngroups < 1 || ngroups > 5 || !items || !ksteps || !out_group || !out_item) return OCTIC_ENULL;
+  GemmArgs a = {};
+  a.ngroups = ngroups;
+  int t = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    a.g[g].K = ksteps[g] * 64;
+    a.g[g].n_chunks = 1;
+    a.g[g].chunk = 1;
+    a.g[g].n_tiles = 1;
+    a.g[g].m_tiles = items[g];
+    a.g[g].tile_begin = t;
+    t += items[g];
+  }
+  a.total_tiles = t;
+  plan_ring(a, t, slots_per_xcd);
+  for (int bid = 0; bid < t; ++bid) ring_item_of(a, t, bid, out_group[bid], out_item[bid]);
+  return a.plan_mode;
+}
 
 extern "C" {
 

@@ -245,3 +245,51 @@ def test_loss_watch_raises_two_steps_late_and_never_on_finite_losses():
     w2.push(torch.tensor(float("inf")))
     with pytest.raises(FloatingPointError):
         w2.drain()
+
+
+# ------------------------------------------------------------------------------------------------ ring dispatch plan
+def _ring_order(items, ksteps, slots=64):
+    """csrc/gemm.hip plan_ring + ring_item_of through the host-only developer entry (no device call)."""
+    import ctypes
+    from octic_vits_amd import _lib
+    _lib.lib()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    n = sum(items)
+    arr = lambda v: (ctypes.c_int * len(v))(*v)
+    og, oi = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    raw.octic_dbg_ring_order.restype = ctypes.c_int
+    mode = raw.octic_dbg_ring_order(len(items), arr(items), arr(ksteps), slots, og, oi)
+    return mode, list(zip(og, oi))
+
+
+@pytest.mark.parametrize("items,ksteps", [
+    ([514, 129, 129, 129, 129], [20, 10, 10, 10, 10]),       # ViT-H fc2 / dgrad fc1 at M = 16 448: six items past two rounds
+    ([514, 129, 129, 129, 129], [15, 8, 8, 8, 8]),            # dgrad qkv
+    ([394, 99, 99, 99, 99], [16, 8, 8, 8, 8]),                # ViT-L
+    ([40, 10, 10, 10, 10], [20, 10, 10, 10, 10]),             # fewer items than slots
+    ([7, 3, 3], [4, 2, 2]),                                   # tiny launch: the even spread
+    ([100, 30, 20], [20, 10, 10]),                            # unequal short groups: the even spread
+    ([64], [10])])
+def test_ring_dispatch_plan_runs_every_item_exactly_once(items, ksteps):
+    """Whatever order the planner picks, the workgroups of a launch cover every (group, item) once."""
+    mode, order = _ring_order(items, ksteps)
+    assert mode in (0, 1)
+    want = {(g, i) for g, n in enumerate(items) for i in range(n)}
+    assert len(order) == len(want) and set(order) == want
+
+
+def test_ring_dispatch_plan_at_vit_h_spreads_the_long_items():
+    """ViT-H long-K launch: 1030 items on 8 x 64 slots.  XCDs with an odd item (129 workgroups) get at most 63 long items, so
+    the slot that takes a third item is one that never ran a long one (csrc/gemm.hip plan_ring)."""
+    items, ksteps = [514, 129, 129, 129, 129], [20, 10, 10, 10, 10]
+    mode, order = _ring_order(items, ksteps)
+    assert mode == 1
+    n = len(order)
+    for x in range(8):
+        mine = [order[b] for b in range(x, n, 8)]
+        longs = sum(1 for g, _ in mine if g == 0)
+        if len(mine) == 129:
+            assert longs <= 63, (x, longs)
+        first_long = next(i for i, (g, _) in enumerate(mine) if g == 0)
+        last_long = max(i for i, (g, _) in enumerate(mine) if g == 0)
+        assert last_long - first_long + 1 == longs                # the long items of an XCD are one contiguous run
