@@ -134,6 +134,9 @@ def main():
                          "wherever ops.dense_wgrad_ok takes the shape)")
     ap.add_argument("--no-fused-attn-bwd", action="store_true",
                     help="developer A/B: attention backward as the dq + dkv kernel pair instead of the single-pass kernel")
+    ap.add_argument("--no-batched-finishes", action="store_true",
+                    help="developer A/B: the parameter-gradient slab reductions of the backward pass as immediate launches "
+                         "instead of one batched launch at its end (ops._DeferredFinishes)")
     ap.add_argument("--no-packed-attn", action="store_true",
                     help="developer A/B: AttentionD8 through the pack / unpack kernels instead of the packed-row attention")
     ap.add_argument("--wgrad-f32-out", action="store_true",
@@ -215,6 +218,9 @@ def main():
         _OF.ATTN_PACKED = False
     if args.no_fused_attn_bwd:
         ops.ATTN_BWD_FUSED = False
+    if args.no_batched_finishes:
+        from octic_vits_amd import train as _T
+        _T.BATCHED_FINISHES = False
     if args.wgrad_f32_out:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_F32_OUT = True

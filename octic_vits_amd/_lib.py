@@ -57,6 +57,7 @@ _PROTOS = {
                                           c_i64, c_int, c_void_p]),
     "octic_dense_layernorm_bwd_tail": (c_int, [c_void_p] * 10 + [c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "octic_dense_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octic_dense_finish_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "octic_dense_gelu_blocks": (c_int, []),
     "octic_dense_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "octic_scale_residual_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int,
@@ -121,7 +122,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.octic_abi_version() != 9:
+        if L.octic_abi_version() != 10:
             raise RuntimeError("octic_vits_amd: ABI version mismatch between _lib.py and liboctic_hip.so")
         _LIB = L
     return _LIB

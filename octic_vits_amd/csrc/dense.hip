@@ -473,6 +473,45 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
   }
 }
 
+// The same reduction for up to 64 slab sets in one launch (blockIdx.y = job): the backward of a standard block ends in six
+// of these 5-us reductions (LayerNorm weight / bias, layer-scale gamma, projection and MLP bias gradients), 96 launches per
+// ViT-H step whose results nothing reads before the optimizer.  Job fields are 8- and 4-byte members only: hipcc mis-addresses
+// a wave-uniform index into a 4-byte kernel-argument array when a 2-byte array shares the index (tools/dbg/kernarg_index_test.hip).
+struct FinishPack {
+  octic_finish_job j[64];
+};
+__global__ __launch_bounds__(256) void dense_finish_batch_kernel(FinishPack pack) {
+  __shared__ float red[16][17];
+  const octic_finish_job& job = pack.j[blockIdx.y];
+  const float* __restrict__ partials = job.partials;
+  const int nblocks = job.nblocks, d = job.d;
+  if ((int)blockIdx.x * 16 >= 2 * d) return;                    // (uniform over the workgroup)
+  const int cx = threadIdx.x & 15, gy = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + cx;
+  float s = 0.f;
+  if (j < 2 * d) {
+    int b = gy;                                   // the summation order of dense_finish_kernel: results are bit-identical
+    for (; b + 48 < nblocks; b += 64) {
+      const float t0 = partials[(long)b * 2 * d + j], t1 = partials[(long)(b + 16) * 2 * d + j],
+                  t2 = partials[(long)(b + 32) * 2 * d + j], t3 = partials[(long)(b + 48) * 2 * d + j];
+      s += t0; s += t1; s += t2; s += t3;
+    }
+    for (; b < nblocks; b += 16) s += partials[(long)b * 2 * d + j];
+  }
+  red[gy][cx] = s;
+  __syncthreads();
+  if (gy == 0 && j < 2 * d) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    if (j < d) {
+      if (job.out0) job.out0[j] = t;
+    } else if (job.out1) {
+      job.out1[j - d] = job.scale1 ? t * job.scale1[j - d] : t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ GELU backward (+ bias grad)
 // dh = gelu'(h) * g for dense bf16 [rows, d] (the standard MLP's hidden activations, d = 4 * dim) and, on the side,
 // the column sums of dh = gradient of the bias of the projection that produced h.  A workgroup is 64 column chunks
@@ -757,6 +796,26 @@ int octic_dense_finish(const float* partials, int nblocks, int d, float* out0, f
   if (nblocks <= 0 || d <= 0) return OCTIC_ESHAPE;
   hipLaunchKernelGGL(dense_finish_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nblocks,
                      d, out0, out1, scale1);
+  return launch_status();
+}
+
+int octic_dense_finish_batch(const octic_finish_job* jobs, int njobs, void* stream) {
+  if (!jobs) return OCTIC_ENULL;
+  if (njobs < 0) return OCTIC_ESHAPE;
+  for (int i = 0; i < njobs; ++i) {
+    if (!jobs[i].partials) return OCTIC_ENULL;
+    if (jobs[i].nblocks <= 0 || jobs[i].d <= 0) return OCTIC_ESHAPE;
+  }
+  for (int i0 = 0; i0 < njobs; i0 += 64) {
+    const int n = njobs - i0 < 64 ? njobs - i0 : 64;
+    FinishPack pack = {};
+    int dmax = 0;
+    for (int i = 0; i < n; ++i) {
+      pack.j[i] = jobs[i0 + i];
+      dmax = jobs[i0 + i].d > dmax ? jobs[i0 + i].d : dmax;
+    }
+    hipLaunchKernelGGL(dense_finish_batch_kernel, dim3((2 * dmax + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, pack);
+  }
   return launch_status();
 }
 

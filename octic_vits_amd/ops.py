@@ -537,6 +537,72 @@ def lift_wgrad(patches, dout, Kpad, D):
 
 
 # ------------------------------------------------------------------------------------------ standard half
+class _FinishJob(ctypes.Structure):
+    _fields_ = [("partials", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("out1", ctypes.c_void_p),
+                ("scale1", ctypes.c_void_p), ("nblocks", ctypes.c_int), ("d", ctypes.c_int)]
+
+
+class _DeferredFinishes:
+    """Parameter-gradient slab reductions (octic_dense_finish) postponed to the end of the running backward pass and issued
+    as ONE batched launch (octic_dense_finish_batch: same summation order, bit-identical results).  Only the caller knows that
+    nothing reads those gradients earlier (no gradient accumulation into an existing .grad - which includes a parameter used
+    twice in one pass: autograd adds its second gradient to the first at once -, no DDP bucket hooks, no tensor hooks):
+    `train.Trainer` switches this on for its single-GPU, single-micro-batch step of a model whose parameters each enter the
+    graph once; the default is immediate launches."""
+
+    def __init__(self):
+        self.enabled = False
+        self.jobs = []          # (partials, nblk, d, out0_ptr, out1_ptr, scale1, keep-alive tensors, stream)
+        self.armed = False
+
+    def add(self, partials, nblk, d, out0_ptr, out1_ptr, scale1, keep, stream):
+        self.jobs.append((partials, nblk, d, out0_ptr, out1_ptr, scale1, keep, stream))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        jobs, self.jobs, self.armed = self.jobs, [], False
+        if not jobs:
+            return
+        arr = (_FinishJob * len(jobs))()
+        for i, (partials, nblk, d, o0, o1, sc, _keep, _s) in enumerate(jobs):
+            arr[i].partials = partials.data_ptr()
+            arr[i].out0 = o0
+            arr[i].out1 = o1
+            arr[i].scale1 = sc.data_ptr() if sc is not None else None
+            arr[i].nblocks = nblk
+            arr[i].d = d
+        t = KERNEL_TIMER.start()
+        check(lib().octic_dense_finish_batch(ctypes.cast(arr, ctypes.c_void_p), len(jobs), jobs[0][7]))
+        KERNEL_TIMER.stop(t, "dense_finish_batch_kernel", sum(j[1] * 2 * j[2] * 4 for j in jobs))
+
+
+DEFERRED_FINISHES = _DeferredFinishes()
+
+
+def _in_backward():
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except Exception:
+        return False
+
+
+def _finish(partials, nblk, d, out0, out1, scale1, stream, out1_ptr=None):
+    """out0[j] = sum_b partials[b][0][j], out1[j] = scale1[j] * sum_b partials[b][1][j] - now, or (see _DeferredFinishes) at the
+    end of the running backward pass.  out1_ptr: raw address for an out1 that is the second half of out0's storage."""
+    o0 = out0.data_ptr() if out0 is not None else None
+    o1 = out1_ptr if out1_ptr is not None else (out1.data_ptr() if out1 is not None else None)
+    if DEFERRED_FINISHES.enabled and _in_backward():
+        # keep the outputs' STORAGE alive, not the tensors: a second reference to the tensor would make AccumulateGrad clone
+        # the (not yet written) gradient instead of adopting it
+        keep = tuple(t.untyped_storage() for t in (out0, out1) if t is not None)
+        DEFERRED_FINISHES.add(partials, nblk, d, o0, o1, scale1, keep, stream)
+        return
+    check(lib().octic_dense_finish(_p(partials), nblk, d, ctypes.c_void_p(o0) if o0 else None,
+                                   ctypes.c_void_p(o1) if o1 else None, _p(scale1), stream))
+
+
 def dense_layernorm_fwd(x, w, b, eps, out_dtype):
     """x: f32 [..., d] contiguous -> (y out_dtype, stats [rows, 2] f32 = (mean, rstd))."""
     _require_cuda(x)
@@ -582,7 +648,7 @@ def dense_layernorm_bwd(gy, x, w, stats, dres, want_param_grads=True):
         return dx, None, None
     dw = torch.empty(d, dtype=torch.float32, device=x.device)
     db = torch.empty(d, dtype=torch.float32, device=x.device)
-    check(lib().octic_dense_finish(_p(partials), nblk, d, _p(dw), _p(db), _p(None), _stream(x)))
+    _finish(partials, nblk, d, dw, db, None, _stream(x))
     return dx, dw, db
 
 
@@ -611,11 +677,11 @@ def dense_layernorm_bwd_tail(gy, x, w, stats, dres, yb, gamma, rs, rps, want_par
     if want_param_grads:
         dw = torch.empty(d, dtype=torch.float32, device=x.device)
         db = torch.empty(d, dtype=torch.float32, device=x.device)
-        check(lib().octic_dense_finish(_p(p1), nblk, d, _p(dw), _p(db), _p(None), _stream(x)))
+        _finish(p1, nblk, d, dw, db, None, _stream(x))
     if want2:
         dgamma = torch.empty(d, dtype=torch.float32, device=x.device) if want_gamma else None
         colsum = torch.empty(d, dtype=torch.float32, device=x.device) if want_colsum else None
-        check(lib().octic_dense_finish(_p(p2), nblk, d, _p(dgamma), _p(colsum), _p(gamma), _stream(x)))
+        _finish(p2, nblk, d, dgamma, colsum, gamma, _stream(x))
     return dx, dw, db, gyb, dgamma, colsum
 
 
@@ -648,7 +714,7 @@ def scale_residual_bwd(gout, y, gamma, rs, rps, want_gamma=True, want_colsum=Tru
         return gy, None, None
     dgamma = torch.empty(d, dtype=torch.float32, device=gout.device) if want_gamma else None
     colsum = torch.empty(d, dtype=torch.float32, device=gout.device) if want_colsum else None
-    check(lib().octic_dense_finish(_p(partials), nblk, d, _p(dgamma), _p(colsum), _p(gamma), _stream(gout)))
+    _finish(partials, nblk, d, dgamma, colsum, gamma, _stream(gout))
     return gy, dgamma, colsum
 
 
@@ -667,8 +733,7 @@ def dense_gelu_bwd(h, g, want_colsum=True):
         return dh, None
     out = torch.empty(d, dtype=torch.float32, device=h.device)
     half = d // 2
-    check(lib().octic_dense_finish(_p(partials), nblk, half, _p(out), ctypes.c_void_p(out.data_ptr() + 4 * half),
-                                   _p(None), _stream(h)))
+    _finish(partials, nblk, half, out, None, None, _stream(h), out1_ptr=out.data_ptr() + 4 * half)
     return dh, out
 
 
@@ -698,8 +763,7 @@ def dense_colsum(g):
     KERNEL_TIMER.stop(t, "dense_colsum_kernel", rows * d * 2)
     out = torch.empty(d, dtype=torch.float32, device=g.device)
     half = d // 2
-    check(lib().octic_dense_finish(_p(partials), nblk, half, _p(out), ctypes.c_void_p(out.data_ptr() + 4 * half),
-                                   _p(None), _stream(g)))
+    _finish(partials, nblk, half, out, None, None, _stream(g), out1_ptr=out.data_ptr() + 4 * half)
     return out
 
 
@@ -732,7 +796,6 @@ def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h
         return c, out
     if cs is not None:
         colsum = torch.empty(N, dtype=torch.float32, device=a.device)
-        check(lib().octic_dense_finish(_p(cs), cs_rows, N // 2, _p(colsum), ctypes.c_void_p(colsum.data_ptr() + 2 * N),
-                                       _p(None), _stream(a)))
+        _finish(cs, cs_rows, N // 2, colsum, None, None, _stream(a), out1_ptr=colsum.data_ptr() + 2 * N)
         return c, colsum
     return c

@@ -660,6 +660,14 @@ class Trainer:
                 return self.criterion(outputs.float(), targets)
         return self.criterion(self.model(samples).float(), targets)
 
+    def _batched_finishes(self):
+        """The parameter-gradient slab reductions of the backward pass as one batched launch at its end
+        (ops._DeferredFinishes) - only where nothing can read those gradients earlier: one micro-batch into .grad = None,
+        no DDP bucket hooks, no graphed slices."""
+        from . import ops
+        safe = (BATCHED_FINISHES and self.device_type == "cuda" and self.model is self.raw_model and self.accum_steps == 1)
+        return _FinishScope(ops.DEFERRED_FINISHES, safe)
+
     def step(self, samples, targets):
         if self._ddp_args is not None and self.model is self.segmented:
             raise RuntimeError("Trainer(distributed=True, segment_graphs=n): call capture_segments(micro_batch) before the "
@@ -683,7 +691,8 @@ class Trainer:
             self.optimizer.zero_grad(set_to_none=True)
         if k == 1:
             loss = self._forward_loss(samples, targets)
-            loss.backward()
+            with self._batched_finishes():
+                loss.backward()
         else:
             xs, ys = samples.chunk(k), targets.chunk(k)
             loss = None
@@ -729,9 +738,28 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(graph):
             loss = self._forward_loss(sx, sy)
-            loss.backward()
+            with self._batched_finishes():
+                loss.backward()
             self.optimizer.step()
         return GraphedStep(self, graph, sx, sy, loss.detach())
+
+
+BATCHED_FINISHES = True    # `bench.py --no-batched-finishes` for the A/B
+
+
+class _FinishScope:
+    def __init__(self, deferred, on):
+        self.deferred, self.on = deferred, on
+
+    def __enter__(self):
+        self.prev = self.deferred.enabled
+        self.deferred.enabled = self.on
+        return self
+
+    def __exit__(self, *exc):
+        self.deferred.enabled = self.prev
+        self.deferred.flush()            # (the engine's end-of-backward callback has normally emptied the list already)
+        return False
 
 
 class GraphedStep:

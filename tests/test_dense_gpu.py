@@ -322,3 +322,72 @@ def test_ln_tail_fusion_in_a_block_chain_matches_the_unfused_chain():
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for (n, _), a, b in zip(blocks.named_parameters(), res[True][2], res[False][2]):
         assert float((a.float() - b.float()).abs().max()) <= 1e-5 * max(1.0, float(b.float().abs().max())), n
+
+
+def test_dense_finish_batch_is_bitwise_the_single_launches():
+    """octic_dense_finish_batch over 70 jobs of mixed sizes (two launches: 64 + 6) against 70 octic_dense_finish calls."""
+    import ctypes
+    from octic_vits_amd import ops as o, _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    jobs, want, keep = [], [], []
+    for i in range(70):
+        d = [1280, 640, 2560, 256, 12][i % 5]
+        nblk = [256, 257, 16, 65, 3][i % 5]
+        part = torch.randn(nblk, 2, d, device=DEV, generator=g)
+        scale = torch.rand(d, device=DEV, generator=g) + 0.5 if i % 3 == 0 else None
+        o0 = torch.full((d,), float("nan"), device=DEV) if i % 7 else None
+        o1 = torch.full((d,), float("nan"), device=DEV) if i % 4 else None
+        r0 = torch.full((d,), float("nan"), device=DEV) if o0 is not None else None
+        r1 = torch.full((d,), float("nan"), device=DEV) if o1 is not None else None
+        o.check(L.octic_dense_finish(o._p(part), nblk, d, o._p(r0), o._p(r1), o._p(scale), o._stream(part)))
+        jobs.append((part, nblk, d, o0, o1, scale))
+        want.append((r0, r1))
+        keep.append((part, scale))
+    arr = (o._FinishJob * len(jobs))()
+    for i, (part, nblk, d, o0, o1, scale) in enumerate(jobs):
+        arr[i].partials = part.data_ptr()
+        arr[i].out0 = o0.data_ptr() if o0 is not None else None
+        arr[i].out1 = o1.data_ptr() if o1 is not None else None
+        arr[i].scale1 = scale.data_ptr() if scale is not None else None
+        arr[i].nblocks, arr[i].d = nblk, d
+    o.check(L.octic_dense_finish_batch(ctypes.cast(arr, ctypes.c_void_p), len(jobs), o._stream(jobs[0][0])))
+    torch.cuda.synchronize()
+    for (part, nblk, d, o0, o1, scale), (r0, r1) in zip(jobs, want):
+        if o0 is not None:
+            assert torch.equal(o0, r0)
+        if o1 is not None:
+            assert torch.equal(o1, r1)
+    assert L.octic_dense_finish_batch(None, 1, None) == -4           # OCTIC_ENULL
+    assert L.octic_dense_finish_batch(ctypes.cast(arr, ctypes.c_void_p), 0, None) == 0
+
+
+def test_deferred_finishes_give_bitwise_the_same_parameter_gradients():
+    """A standard block's backward with the parameter-gradient reductions postponed to the end of the pass (one batched
+    launch, ops._DeferredFinishes) against the immediate launches: every gradient bit for bit; outside a backward pass and
+    with the switch off nothing is postponed."""
+    from octic_vits_amd import ops as o
+    from octic_vits_amd.vit import Layer_scale_init_Block
+    torch.manual_seed(0)
+    # two DISTINCT blocks (chained fusions: next-norm, LayerNorm tail).  A parameter used twice in one pass would have its
+    # second gradient added to the first before the postponed launch has produced either - the precondition in the docstring
+    # of ops._DeferredFinishes ("nothing reads those gradients earlier") includes autograd's own accumulation.
+    blk = torch.nn.Sequential(*[Layer_scale_init_Block(dim=256, num_heads=4, qkv_bias=True, init_values=0.5, drop_path=0.0)
+                                for _ in range(2)]).cuda().train()
+    x = torch.randn(6, 65, 256, device=DEV)
+    cot = torch.randn(6, 65, 256, device=DEV)
+    res = {}
+    for mode in (False, True):
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(xi)
+        o.DEFERRED_FINISHES.enabled = mode
+        try:
+            y.backward(cot)
+        finally:
+            o.DEFERRED_FINISHES.enabled = False
+        assert not o.DEFERRED_FINISHES.jobs and not o.DEFERRED_FINISHES.armed
+        res[mode] = [xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
