@@ -94,6 +94,22 @@ def step_variants(trainer, model, samples, targets, args, n=8):
     out = {}
     ms, host = timed(trainer)
     out["eager_ms_per_step"], out["eager_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
+    # Stochastic depth as batch compaction (d8_layers.COMPACT_DROP_PATH, opt-in): every branch on the samples its per-sample
+    # Bernoulli(1 - drop_path) mask keeps, instead of on every sample with half the results multiplied by zero - the same loss
+    # and gradients (tests/test_train_gpu.py::test_compacted_stochastic_depth_equals_the_masked_full_batch), eager launches
+    # because the shapes follow the draws.  Reported beside `value`, never as it.
+    from octic_vits_amd import d8_layers as _L
+    if True:
+        _L.COMPACT_DROP_PATH = True
+        try:
+            for _ in range(40):                       # the per-shape plans / workspaces of ~30 distinct kept counts
+                trainer.step(samples, targets)
+            ms, host = timed(trainer)
+            out["compact_drop_path_ms_per_step"] = round(ms, 3)
+            out["compact_drop_path_host_issue_ms_per_step"] = round(host, 2)
+            out["compact_drop_path_images_per_s"] = round(samples.shape[0] / ms * 1e3, 2)
+        finally:
+            _L.COMPACT_DROP_PATH = False
     del trainer
     seg = Trainer(model, segment_graphs=8)           # (re-links the blocks inside the slices: keep this last)
     seg.capture_segments(samples)
@@ -134,6 +150,10 @@ def main():
                          "wherever ops.dense_wgrad_ok takes the shape)")
     ap.add_argument("--no-fused-attn-bwd", action="store_true",
                     help="developer A/B: attention backward as the dq + dkv kernel pair instead of the single-pass kernel")
+    ap.add_argument("--compact-drop-path", action="store_true",
+                    help="opt-in: stochastic depth as batch compaction (d8_layers.COMPACT_DROP_PATH): every branch runs on the "
+                         "samples its per-sample Bernoulli mask keeps - same loss and gradients, about half the branch work at "
+                         "drop_path 0.5.  Launch shapes vary per step: implies --no-graph")
     ap.add_argument("--no-batched-finishes", action="store_true",
                     help="developer A/B: the parameter-gradient slab reductions of the backward pass as immediate launches "
                          "instead of one batched launch at its end (ops._DeferredFinishes)")
@@ -221,6 +241,10 @@ def main():
     if args.no_batched_finishes:
         from octic_vits_amd import train as _T
         _T.BATCHED_FINISHES = False
+    if args.compact_drop_path:
+        from octic_vits_amd import d8_layers as _L
+        _L.COMPACT_DROP_PATH = True
+        args.no_graph = True
     if args.wgrad_f32_out:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_F32_OUT = True

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <mutex>
+#include <vector>
 #include "gemm_args.hpp"
 
 namespace octic {
@@ -718,13 +719,14 @@ inline bool plan_ring(GemmArgs& a, int nwg, int slots_per_xcd) {
   for (int g = 2; g < a.ngroups; ++g)
     if (cost(g) != c_short || items(g) != n_short1) return false;
   const int E = items(0), nshort = a.ngroups - 1;
-  static RingPlan cache[16];
-  static int cached = 0;
+  // (the key space is small for a fixed model, but a run with varying batch sizes visits dozens of launch shapes: a plan
+  // costs milliseconds of host time, so none is ever computed twice)
+  static std::vector<RingPlan> cache;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   const int key[6] = {nwg, slots_per_xcd, E, c_long, c_short, nshort};
   const RingPlan* hit = nullptr;
-  for (int i = 0; i < cached && !hit; ++i) {
+  for (size_t i = 0; i < cache.size() && !hit; ++i) {
     bool same = true;
     for (int j = 0; j < 6; ++j) same = same && cache[i].key[j] == key[j];
     if (same) hit = &cache[i];
@@ -778,9 +780,8 @@ inline bool plan_ring(GemmArgs& a, int nwg, int slots_per_xcd) {
     free(f);
     free(mk);
     if (!ok) return false;
-    RingPlan& slot = cache[cached < 16 ? cached++ : 15];
-    slot = pl;
-    hit = &slot;
+    cache.push_back(pl);
+    hit = &cache.back();
   }
   const int q8 = nwg >> 3, r8 = nwg & 7;
   int eb = 0, sb = 0;

@@ -57,6 +57,8 @@ def arm_drop_path_pool(on=True):
     if on:
         for pool in _mask_pool.values():
             pool[1] = DROP_PATH_POOL
+        for pool in _compact_pool.values():
+            pool[2] = DROP_PATH_POOL
 
 
 def _pool_usable():
@@ -88,6 +90,119 @@ def _drop_path_mask(B, drop_prob, device, scale_by_keep=True):
     m = pool[0][pool[1]]
     pool[1] += 1
     return m
+
+
+# ---- stochastic depth as batch compaction (opt-in) ---------------------------------------------------------------------------
+# The reference draws one Bernoulli(keep) per sample and branch, computes the branch for EVERY sample and multiplies the
+# dropped ones by zero (drop_path_d8, d8_layers.py:249-270; timm DropPath in deit/vit.py) - with the DeiT-III recipe's constant
+# drop_path = 0.5 (model.py:114: `dpr = [drop_path_rate for i in range(depth)]`) half of every branch's GEMMs, attention
+# and row passes, forward and backward, is work whose result is discarded and whose gradients are exactly zero.
+# COMPACT_DROP_PATH = True computes a branch on the kept samples only:  x[idx] += scale * cs * f(norm(x[idx])),  idx = the samples
+# the SAME per-sample Bernoulli mask keeps (drawn on the host's generator, because the launch shapes depend on the count).
+# Same loss, same gradients (a dropped sample's contribution to every parameter gradient is an exact zero in the reference
+# too); what changes is which rows the kernels are launched on.  Shapes vary from step to step, so this mode runs eagerly
+# (no hipGraph of the whole step).  DINOv2's own block does the same with a fixed-size random subset
+# (dinov2/layers/block.py:113-140, `drop_add_residual_stochastic_depth`).
+COMPACT_DROP_PATH = False
+compact_mask_source = None          # test hook: (B, keep_prob) -> CPU float mask [B] of zeros and ones
+_compact_pool = {}
+_scale_cache = {}
+
+
+def _compact_indices(B, drop_prob, device):
+    """Next branch's kept sample indices (device int64 [n]) and n, from a per-forward pool of host-drawn masks."""
+    keep = 1.0 - drop_prob
+    if compact_mask_source is not None:
+        idx = compact_mask_source(B, keep).flatten().nonzero().flatten()
+        return idx.to(device), int(idx.numel())
+    key = (str(device), int(B), float(keep))
+    pool = _compact_pool.get(key)
+    if pool is None or pool[2] >= DROP_PATH_POOL or not _pool_armed:
+        m = torch.empty(DROP_PATH_POOL, B).bernoulli_(keep)
+        counts = m.sum(1).to(torch.int64).tolist()
+        rows = m.nonzero()[:, 1].contiguous()                   # kept sample ids, mask after mask
+        host = rows.pin_memory() if device.type == "cuda" else rows
+        dev = host.to(device, non_blocking=True)
+        offs = [0]
+        for cnt in counts:
+            offs.append(offs[-1] + cnt)
+        pool = _compact_pool[key] = [dev, offs, 0, host]
+    i = pool[2]
+    pool[2] += 1
+    return pool[0][pool[1][i]:pool[1][i + 1]], pool[1][i + 1] - pool[1][i]
+
+
+def _compact_plan(B, dp, device):
+    """(kept sample indices, their count, row scale) of the next compacted branch.  A mask that keeps nobody (probability
+    2^-B) still runs the branch - on sample 0 with scale 0 - so that its parameters receive their exact-zero gradients."""
+    idx, n = _compact_indices(B, dp.drop_prob, device)
+    scale = 1.0 / (1.0 - dp.drop_prob) if (dp.scale_by_keep and dp.drop_prob < 1.0) else 1.0
+    if n == 0:
+        return torch.zeros(1, dtype=torch.int64, device=device), 1, 0.0
+    return idx, n, scale
+
+
+def _const_scale(n, value, device):
+    key = (int(n), float(value), str(device))
+    t = _scale_cache.get(key)
+    if t is None:
+        t = _scale_cache[key] = torch.full((n,), value, dtype=torch.float32, device=device)
+    return t
+
+
+class _RowLink:
+    """Shared by the gather / scatter pair around one compacted branch (see _GatherRowsFn)."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """xa = x[idx] (rows = samples) for a compacted branch, paired with _ScatterRowsFn through `link`.
+    The pair keeps the stream's cotangent ONE tensor that flows backward through the blocks and is edited in place: the
+    scatter's backward hands over the cotangent g of the stream after the branch (and returns no gradient for the stream
+    itself); this backward writes the branch's input cotangent over rows idx of g - those rows of the old stream reach the
+    new one only through the branch, whose own residual connection is inside g_xa - and returns g as the gradient of the old
+    stream.  Composed from index_select / index_copy autograd would clone the stream forward, and clone, zero-fill,
+    index_add and add full-size tensors backward: 14 ms per ViT-H step."""
+
+    @staticmethod
+    def forward(ctx, x, idx, link):
+        ctx.idx, ctx.link = idx, link
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g_xa):
+        g, ctx.link.g = ctx.link.g, None
+        if g is None:
+            raise RuntimeError("_GatherRowsFn: the stream cotangent of the paired scatter is missing")
+        g.index_copy_(0, ctx.idx, g_xa.to(g.dtype))
+        return g, None, None
+
+
+class _ScatterRowsFn(torch.autograd.Function):
+    """x[idx] = out (in place; out = the compacted branch's result INCLUDING its residual connection)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, out, link):
+        ctx.idx, ctx.link = idx, link
+        x.index_copy_(0, idx, out)
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        if not g.is_contiguous():
+            g = g.contiguous()
+        ctx.link.g = g
+        return None, None, g.index_select(0, ctx.idx), None
+
+
+def compact_active(dp):
+    """Is the compacted stochastic depth in force for this drop-path module right now?"""
+    return (COMPACT_DROP_PATH and getattr(dp, "training", False) and float(getattr(dp, "drop_prob", 0.)) > 0.
+            and torch.is_grad_enabled())
 
 
 class DropoutD8(nn.Module):
@@ -573,6 +688,16 @@ def _branch(norm, fn, xs_packed, c, rs, cs, out_dtype, pre=None, next_norm=None)
     return out if next_norm is None else (out, None)
 
 
+def _branch_compact(norm, fn, xs_packed, c, dp, cs, out_dtype):
+    """_branch on the samples this branch's stochastic-depth mask keeps (COMPACT_DROP_PATH): the kept rows are gathered,
+    run through the same fused branch with the constant 1 / keep as their row scale, and written back."""
+    idx, n, scale = _compact_plan(xs_packed.shape[0], dp, xs_packed.device)
+    link = _RowLink()
+    xa = _GatherRowsFn.apply(xs_packed, idx, link)
+    out = _branch(norm, fn, xa, c, _const_scale(n, scale, xa.device), cs, out_dtype)
+    return Octic(_ScatterRowsFn.apply(xs_packed, idx, out.packed, link), c)
+
+
 class Layer_scale_init_BlockD8(nn.Module):
     """d8_layers.py:665-707 (DeiT-III block; gamma_{1,2} = AffineD8(bias=False), one drop_path module
     used twice = two independent per-sample masks)."""
@@ -599,6 +724,9 @@ class Layer_scale_init_BlockD8(nn.Module):
     def forward(self, xs):
         xp, c = as_packed(xs)
         dt = compute_dtype(xp)
+        if compact_active(self.drop_path) and xp.dtype == torch.float32:
+            x1 = _branch_compact(self.norm1, self.attn, xp, c, self.drop_path, self.gamma_1.alphas(), dt)
+            return _branch_compact(self.norm2, self.mlp, x1.packed, c, self.drop_path, self.gamma_2.alphas(), dt)
         if not (OF.OCTIC_NEXT_NORM and xp.is_cuda and dt == torch.bfloat16 and type(self.norm2) is LayerNormD8):
             x1 = _branch(self.norm1, self.attn, xp, c, self._mask(xp.shape[0], xp.device), self.gamma_1.alphas(), dt)
             return _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(), dt)

@@ -296,7 +296,20 @@ class FusedLamb:
             self.g_ptrs.copy_(host, non_blocking=True)
             self._g_key = None
         elif key != self._g_key:
-            self.g_ptrs.copy_(torch.tensor(key, dtype=torch.int64), non_blocking=False)
+            # gradient buffers moved (allocation pattern changed: first steps, varying batch shapes): upload the new table
+            # WITHOUT blocking the host - a pageable-memory copy would wait for the whole backward pass in front of it.
+            # Four pinned tables in rotation; a table is reused only after its upload has finished.
+            if getattr(self, "_g_ring", None) is None:
+                self._g_ring = [[torch.empty(len(key), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
+                self._g_ring_i = 0
+            slot = self._g_ring[self._g_ring_i]
+            self._g_ring_i = (self._g_ring_i + 1) % len(self._g_ring)
+            if slot[1] is not None:
+                slot[1].synchronize()
+            slot[0].copy_(torch.tensor(key, dtype=torch.int64))
+            self.g_ptrs.copy_(slot[0], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
             self._g_key = key
         self.step_count += 1
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None

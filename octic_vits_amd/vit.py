@@ -163,6 +163,17 @@ def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2, next_norm
         if not isinstance(dp, (DropPath, nn.Identity)):
             return None
     dt = torch.bfloat16
+    from . import d8_layers as _L
+    if _L.compact_active(dp1) and _L.compact_active(dp2):
+        # stochastic depth as batch compaction (d8_layers.COMPACT_DROP_PATH): each branch on the samples its mask keeps
+        for norm, branch, gamma, dp in ((norm1, attn, gamma1, dp1), (norm2, mlp, gamma2, dp2)):
+            idx, n, scale = _L._compact_plan(x.shape[0], dp, x.device)
+            link = _L._RowLink()
+            xa = _L._GatherRowsFn.apply(x, idx, link)
+            y, xres = _OF.DenseLayerNormFn.apply(xa, norm.weight, norm.bias, norm.eps, dt)
+            out = branch.forward_fused(y, xres, gamma, _L._const_scale(n, scale, x.device), dt)
+            x = _L._ScatterRowsFn.apply(x, idx, out, link)
+        return x
     fuse = _OF.NEXT_NORM_FUSED
     pre = getattr(x, "_octic_prenorm", None)
     # the carried norm is only valid for the stream exactly as the previous block returned it: an in-place edit in between

@@ -529,3 +529,53 @@ def test_segment_graphs_replay_like_the_eager_segmented_step_also_under_ddp_hook
     finally:
         if made:
             dist.destroy_process_group()
+
+
+def test_compacted_stochastic_depth_equals_the_masked_full_batch():
+    """d8_layers.COMPACT_DROP_PATH: every branch on the samples its per-sample Bernoulli mask keeps, against the reference
+    formulation (every branch on every sample, dropped ones multiplied by zero) with the SAME masks: same logits and the same
+    parameter gradients up to bf16 GEMM summation order (the kept rows see identical operands; weight gradients sum over fewer,
+    differently tiled rows).  Also covers a branch that keeps nobody and one that keeps everybody."""
+    import octic_vits_amd.d8_layers as L
+    from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.vit import Layer_scale_init_Block
+    torch.manual_seed(0)
+    net = OcticVisionTransformer(img_size=56, patch_size=14, num_classes=100, embed_dim=128, depth=4, num_heads=4,
+                                 qkv_bias=True, drop_path_rate=0.5, octic_block_layers=Layer_scale_init_BlockD8,
+                                 standard_block_layers=Layer_scale_init_Block).cuda().train()
+    with torch.no_grad():                   # layer scale 1e-4 would hide the branches below the bf16 noise of the stream
+        for n, p in net.named_parameters():
+            if "gamma" in n:
+                p.fill_(0.5)
+    B = 12
+    g = torch.Generator().manual_seed(5)
+    masks = [(torch.rand(B, generator=g) < 0.5).float() for _ in range(8)]
+    masks[2] = torch.zeros(B)               # nobody kept
+    masks[5] = torch.ones(B)                # everybody kept
+    x = torch.randn(B, 3, 56, 56, device="cuda")
+    cot = torch.randn(B, 100, device="cuda")
+    res = {}
+    for compact in (False, True):
+        it = iter(masks)
+        L.drop_path_mask_source = lambda Bn, keep, device: next(it).to(device)
+        L.compact_mask_source = lambda Bn, keep: next(it)
+        L.COMPACT_DROP_PATH = compact
+        try:
+            net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(x)
+            (out.float() * cot).sum().backward()
+        finally:
+            L.drop_path_mask_source = L.compact_mask_source = None
+            L.COMPACT_DROP_PATH = False
+        assert next(it, None) is None       # both formulations drew all eight masks
+        res[compact] = (out.detach().float(), {n: p.grad.detach().float().clone() for n, p in net.named_parameters()
+                                              if p.grad is not None})
+    out_f, g_f = res[False]
+    out_c, g_c = res[True]
+    scale = float(out_f.abs().max())
+    assert float((out_f - out_c).abs().max()) <= 2e-2 * scale
+    assert g_f.keys() == g_c.keys()
+    worst = max((float((g_c[n] - g_f[n]).norm() / g_f[n].norm().clamp_min(1e-6)), n) for n in g_f)
+    assert worst[0] <= 3e-2, worst
