@@ -200,9 +200,18 @@ class _ScatterRowsFn(torch.autograd.Function):
 
 
 def compact_active(dp):
-    """Is the compacted stochastic depth in force for this drop-path module right now?"""
-    return (COMPACT_DROP_PATH and getattr(dp, "training", False) and float(getattr(dp, "drop_prob", 0.)) > 0.
-            and torch.is_grad_enabled())
+    """Is the compacted stochastic depth in force for this drop-path module right now?  Not where something could replay the
+    block later (activation checkpointing: a recompute must see the masks of the forward - the rule of the pooled draw above):
+    there the block falls back to masks on the full batch, drawn per call from torch's generator."""
+    if not (COMPACT_DROP_PATH and getattr(dp, "training", False) and float(getattr(dp, "drop_prob", 0.)) > 0.
+            and torch.is_grad_enabled()):
+        return False
+    if compact_mask_source is not None:
+        return True
+    try:
+        return torch._C._autograd._top_saved_tensors_default_hooks(False) is None
+    except AttributeError:
+        return False
 
 
 class DropoutD8(nn.Module):

@@ -655,6 +655,10 @@ class Trainer:
         around the graphed slices."""
         if self.segmented is None:
             raise RuntimeError("Trainer.capture_segments: construct the trainer with segment_graphs=n")
+        from . import d8_layers as _L
+        if _L.COMPACT_DROP_PATH:
+            raise RuntimeError("Trainer.capture_segments: d8_layers.COMPACT_DROP_PATH changes the launch shapes from step to "
+                               "step; graphed slices need static shapes")
         if isinstance(self.optimizer, FusedLamb) and self.optimizer.step_count == 0:
             # no step yet: one forward (the weight caches record their operands), then the static weight buffers
             self.segmented.train()
@@ -738,6 +742,10 @@ class Trainer:
                                "(use segment_graphs=n + capture_segments)")
         if self.accum_steps != 1:
             raise RuntimeError("Trainer.capture: accum_steps > 1 is not captured")
+        from . import d8_layers as _L
+        if _L.COMPACT_DROP_PATH:
+            raise RuntimeError("Trainer.capture: d8_layers.COMPACT_DROP_PATH launches every branch on the samples its mask "
+                               "keeps - the shapes change from step to step and cannot be one captured graph; run eagerly")
         from . import ops
         if ops.KERNEL_TIMER.on:
             raise RuntimeError("Trainer.capture: disable the kernel timer first")
