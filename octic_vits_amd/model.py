@@ -136,10 +136,13 @@ class OcticVisionTransformer(nn.Module):
             x = blk(x)
         if self.global_pool:
             return self.norm(x).mean(dim=1)
-        # reference: self.norm(x) then x[:, 0] (octic_vits/model.py:204-211).  LayerNorm is row-wise, so normalising the cls rows alone
-        # gives the same numbers and the same parameter gradients without a forward / backward pass over the other
-        # B (T - 1) rows (three ATen launches, 0.16 ms per step at ViT-H)
-        return self.norm(x[:, 0])
+        from . import d8_layers as _L
+        if _L.COMPACT_DROP_PATH:
+            # (with the other opt-in elimination of discarded work, d8_layers.COMPACT_DROP_PATH: LayerNorm is row-wise, so
+            # normalising the cls rows alone gives the same numbers and the same parameter gradients as the reference's
+            # norm over all B T rows followed by x[:, 0], octic_vits/model.py:204-211)
+            return self.norm(x[:, 0])
+        return self.norm(x)[:, 0]
 
     def forward(self, x):
         x = self.forward_features(x)
