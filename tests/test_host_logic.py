@@ -293,3 +293,70 @@ def test_ring_dispatch_plan_at_vit_h_spreads_the_long_items():
         first_long = next(i for i, (g, _) in enumerate(mine) if g == 0)
         last_long = max(i for i, (g, _) in enumerate(mine) if g == 0)
         assert last_long - first_long + 1 == longs                # the long items of an XCD are one contiguous run
+
+
+# ------------------------------------------------------------------------------------------------ compacted stochastic depth
+def test_gather_scatter_pair_gives_the_gradients_of_the_plain_composition():
+    """d8_layers._GatherRowsFn / _ScatterRowsFn (in-place stream, one cotangent tensor edited in place on the way back) against
+    the same computation written with index_select / index_copy, in float64 on the CPU: a chain of four "blocks" whose
+    branches see random subsets of the samples, a parameter per branch, and a loss that reads only row 0 of every sample (the
+    cls-token situation: most rows of the last cotangent are zero)."""
+    import octic_vits_amd.d8_layers as L
+    torch.manual_seed(0)
+    B, T, D = 7, 3, 5
+    x0 = torch.randn(B, T, D, dtype=torch.float64)
+    ws = [torch.randn(D, D, dtype=torch.float64) * 0.3 for _ in range(4)]
+    subsets = [torch.tensor(s) for s in ([0, 2, 3, 6], [1], [0, 1, 2, 3, 4, 5, 6], [2, 5])]
+
+    def branch(xa, w):                      # residual inside, as the fused branch functions have it
+        return xa + torch.tanh(xa @ w) * 1.7
+
+    def run(pair):
+        x = x0.clone().requires_grad_(True)
+        params = [w.clone().requires_grad_(True) for w in ws]
+        s = x * 1.0                          # (the stream the blocks edit in place must not be a leaf)
+        for idx, w in zip(subsets, params):
+            if pair:
+                link = L._RowLink()
+                xa = L._GatherRowsFn.apply(s, idx, link)
+                s = L._ScatterRowsFn.apply(s, idx, branch(xa, w), link)
+            else:
+                s = s.index_copy(0, idx, branch(s.index_select(0, idx), w))
+        loss = (s[:, 0] ** 2).sum()
+        loss.backward()
+        return float(loss.detach()), x.grad.clone(), [p.grad.clone() for p in params]
+
+    la, gxa, gpa = run(False)
+    lb, gxb, gpb = run(True)
+    assert la == lb
+    assert torch.allclose(gxa, gxb, rtol=0, atol=1e-13)
+    for a, b in zip(gpa, gpb):
+        assert torch.allclose(a, b, rtol=0, atol=1e-13)
+
+
+def test_compact_index_pool_matches_its_masks():
+    """_compact_indices: a pool of host-drawn Bernoulli masks per forward; every branch gets the kept sample ids of the next mask
+    (ascending), the count on the host, and a fresh draw once the pool is used up or a new forward arms it."""
+    import octic_vits_amd.d8_layers as L
+    torch.manual_seed(3)
+    L._compact_pool.clear()
+    dev = torch.device("cpu")
+    L.arm_drop_path_pool(True)
+    try:
+        seen = []
+        for _ in range(L.DROP_PATH_POOL + 3):
+            idx, n = L._compact_indices(16, 0.5, dev)
+            assert idx.dtype == torch.int64 and idx.numel() == n and 0 <= n <= 16
+            assert torch.equal(idx, idx.sort().values) and len(set(idx.tolist())) == n
+            seen.append(n)
+        assert 4 < sum(seen) / len(seen) < 12                       # mean kept count 8
+        L.arm_drop_path_pool(True)                                   # a new forward starts a new pool
+        key = next(iter(L._compact_pool))
+        assert L._compact_pool[key][2] >= L.DROP_PATH_POOL
+        L._compact_indices(16, 0.5, dev)
+        assert L._compact_pool[key][2] == 1
+    finally:
+        L.arm_drop_path_pool(False)
+        L._compact_pool.clear()
+    idx, n, scale = L._compact_plan(4, type("DP", (), {"drop_prob": 1.0, "scale_by_keep": True})(), dev)
+    assert n == 1 and scale == 0.0 and idx.tolist() == [0]         # a mask that keeps nobody: one sample, scale 0
