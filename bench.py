@@ -108,6 +108,10 @@ def step_variants(trainer, model, samples, targets, args, n=8):
             out["compact_drop_path_ms_per_step"] = round(ms, 3)
             out["compact_drop_path_host_issue_ms_per_step"] = round(host, 2)
             out["compact_drop_path_images_per_s"] = round(samples.shape[0] / ms * 1e3, 2)
+            out["compact_drop_path_note"] = ("opt-in, NOT `value`: every branch on the samples its per-sample Bernoulli(0.5) "
+                                             "stochastic-depth mask keeps (d8_layers.COMPACT_DROP_PATH; same loss and gradients as "
+                                             "the masked full batch: tests/test_train_gpu.py::test_compacted_stochastic_depth_"
+                                             "equals_the_masked_full_batch); eager launches, DESIGN.md 3.7")
         finally:
             _L.COMPACT_DROP_PATH = False
     del trainer
