@@ -17,7 +17,7 @@ if COMPACT:
 else:
     run = tr.capture(*bs[0], warmup=2).replay
 out = []
-for i in range(120):
+for i in range(int(os.environ.get("SOAK_STEPS", "120"))):
     l = run(*bs[i % 4])
     if i % 10 == 9:
         out.append(round(float(l), 4))
