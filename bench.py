@@ -505,7 +505,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=real_stdout, flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
