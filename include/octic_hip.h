@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 10
+#define OCTIC_ABI_VERSION 11
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -94,6 +94,15 @@ int octic_layernorm_d8_bwd_cast(const octic_view* g, const octic_view* x, const 
                                 const float* rs, int64_t rows_per_sample, void* gcast, void* stream);
 int octic_layernorm_d8_bwd_finish(const float* partials, int nblk, int c, float* const dalpha[5], float* dbeta,
                                   void* stream);
+/* njobs of the reductions above in ceil(njobs / 48) launches, bit-identical to njobs calls (see octic_dense_finish_batch). */
+typedef struct octic_ln_finish_job {
+  const float* partials; /* [nblk][2][8c] */
+  float* dalpha[5];      /* each may be NULL */
+  float* dbeta;          /* may be NULL */
+  int nblk;
+  int c;
+} octic_ln_finish_job;
+int octic_layernorm_d8_bwd_finish_batch(const octic_ln_finish_job* jobs, int njobs, void* stream);
 
 /* ---- LinearD8 (irrep-blocked GEMM on MFMA) ----------------------------------------------------
  * Replaces LinearD8.forward (d8_layers.py:124-127) = five nn.Linear calls, as ONE launch:

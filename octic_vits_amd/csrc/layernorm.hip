@@ -279,8 +279,8 @@ __global__ __launch_bounds__(kLnBwdWaves * 64, PK ? OCTIC_LNBWD_OCC : 2) void ln
 // output are combined through LDS in a fixed order (bitwise reproducible).  Output j in [0,7c):
 //   j < 4c : dalpha of A1..B2 = plane0[j] ; 4c <= j < 6c : dalpha_E[o] = plane0[4c+o] + plane0[6c+o] (both E rows
 //   share alpha_E) ; j >= 6c : dbeta[o] = plane1[o]  (A1 columns of the sum-of-g plane).
-__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* partials, int nblk, int c, float* d0, float* d1,
-                                                            float* d2, float* d3, float* d4, float* dbeta) {
+__device__ __forceinline__ void ln_bwd_finish_body(const float* partials, int nblk, int c, float* d0, float* d1, float* d2,
+                                                   float* d3, float* d4, float* dbeta) {
   __shared__ float red[16][17];
   const int D = 8 * c;
   const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
@@ -319,6 +319,23 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* partial
       dbeta[j - 6 * c] = t;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* partials, int nblk, int c, float* d0, float* d1,
+                                                            float* d2, float* d3, float* d4, float* dbeta) {
+  ln_bwd_finish_body(partials, nblk, c, d0, d1, d2, d3, d4, dbeta);
+}
+
+// up to 48 of these reductions in one launch (blockIdx.y = job; see octic_dense_finish_batch in csrc/dense.hip): the backward
+// of an octic block ends in two of them, 32 five-microsecond launches per ViT-H step
+struct LnFinishPack {
+  octic_ln_finish_job j[48];
+};
+__global__ __launch_bounds__(256) void ln_bwd_finish_batch_kernel(LnFinishPack pack) {
+  const octic_ln_finish_job& job = pack.j[blockIdx.y];
+  if ((int)blockIdx.x * 16 >= 7 * job.c) return;
+  ln_bwd_finish_body(job.partials, job.nblk, job.c, job.dalpha[0], job.dalpha[1], job.dalpha[2], job.dalpha[3], job.dalpha[4],
+                     job.dbeta);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -690,6 +707,26 @@ int octic_layernorm_d8_bwd_finish(const float* partials, int nblk, int c, float*
   if (dalpha)
     for (int i = 0; i < 5; ++i) d[i] = dalpha[i];
   ln_bwd_finish_kernel<<<(7 * c + 15) / 16, 256, 0, (hipStream_t)stream>>>(partials, nblk, c, d[0], d[1], d[2], d[3], d[4], dbeta);
+  return launch_status();
+}
+
+int octic_layernorm_d8_bwd_finish_batch(const octic_ln_finish_job* jobs, int njobs, void* stream) {
+  if (!jobs) return OCTIC_ENULL;
+  if (njobs < 0) return OCTIC_ESHAPE;
+  for (int i = 0; i < njobs; ++i) {
+    if (!jobs[i].partials) return OCTIC_ENULL;
+    if (jobs[i].nblk <= 0 || check_c(jobs[i].c)) return OCTIC_ESHAPE;
+  }
+  for (int i0 = 0; i0 < njobs; i0 += 48) {
+    const int n = njobs - i0 < 48 ? njobs - i0 : 48;
+    LnFinishPack pack = {};
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+      pack.j[i] = jobs[i0 + i];
+      cmax = jobs[i0 + i].c > cmax ? jobs[i0 + i].c : cmax;
+    }
+    ln_bwd_finish_batch_kernel<<<dim3((7 * cmax + 15) / 16, n), 256, 0, (hipStream_t)stream>>>(pack);
+  }
   return launch_status();
 }
 

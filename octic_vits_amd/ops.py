@@ -213,8 +213,16 @@ def layernorm_bwd(g, x, stats, alpha5, dres, c, want_param_grads=True):
         return dx, None, None
     dal = [torch.empty_like(a) for a in alpha5]
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-    check(lib().octic_layernorm_d8_bwd_finish(_p(partials), nblk, c, _arr5(dal), _p(dbeta), _stream(x)))
+    _ln_finish(partials, nblk, c, dal, dbeta, _stream(x))
     return dx, dal, dbeta
+
+
+def _ln_finish(partials, nblk, c, dal, dbeta, stream):
+    """octic_layernorm_d8_bwd_finish now, or batched at the end of the running backward pass (DEFERRED_FINISHES)."""
+    if DEFERRED_FINISHES.enabled and _in_backward():
+        DEFERRED_FINISHES.add_ln(partials, nblk, c, dal, dbeta, stream)
+        return
+    check(lib().octic_layernorm_d8_bwd_finish(_p(partials), nblk, c, _arr5(dal), _p(dbeta), stream))
 
 
 def layernorm_bwd_cast_ok(g, x, c):
@@ -240,7 +248,7 @@ def layernorm_bwd_cast(g, x, stats, alpha5, dres, c, rs, rps, want_param_grads=T
         return dx, None, None, gc
     dal = [torch.empty_like(a) for a in alpha5]
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-    check(lib().octic_layernorm_d8_bwd_finish(_p(partials), nblk, c, _arr5(dal), _p(dbeta), _stream(x)))
+    _ln_finish(partials, nblk, c, dal, dbeta, _stream(x))
     return dx, dal, dbeta, gc
 
 
@@ -542,6 +550,11 @@ class _FinishJob(ctypes.Structure):
                 ("scale1", ctypes.c_void_p), ("nblocks", ctypes.c_int), ("d", ctypes.c_int)]
 
 
+class _LnFinishJob(ctypes.Structure):
+    _fields_ = [("partials", ctypes.c_void_p), ("dalpha", ctypes.c_void_p * 5), ("dbeta", ctypes.c_void_p),
+                ("nblk", ctypes.c_int), ("c", ctypes.c_int)]
+
+
 class _DeferredFinishes:
     """Parameter-gradient slab reductions (octic_dense_finish) postponed to the end of the running backward pass and issued
     as ONE batched launch (octic_dense_finish_batch: same summation order, bit-identical results).  Only the caller knows that
@@ -553,6 +566,7 @@ class _DeferredFinishes:
     def __init__(self):
         self.enabled = False
         self.jobs = []          # (partials, nblk, d, out0_ptr, out1_ptr, scale1, keep-alive tensors, stream)
+        self.ln_jobs = []       # (partials, nblk, c, [5 dalpha ptrs], dbeta_ptr, keep-alive storages, stream)
         self.armed = False
 
     def add(self, partials, nblk, d, out0_ptr, out1_ptr, scale1, keep, stream):
@@ -561,8 +575,28 @@ class _DeferredFinishes:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
+    def add_ln(self, partials, nblk, c, dal, dbeta, stream):
+        keep = tuple(t.untyped_storage() for t in list(dal) + [dbeta] if t is not None)
+        self.ln_jobs.append((partials, nblk, c, [t.data_ptr() if t is not None else None for t in dal],
+                             dbeta.data_ptr() if dbeta is not None else None, keep, stream))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
     def flush(self):
         jobs, self.jobs, self.armed = self.jobs, [], False
+        ln_jobs, self.ln_jobs = self.ln_jobs, []
+        if ln_jobs:
+            arr = (_LnFinishJob * len(ln_jobs))()
+            for i, (partials, nblk, c, dal, dbeta, _keep, _s) in enumerate(ln_jobs):
+                arr[i].partials = partials.data_ptr()
+                for k in range(5):
+                    arr[i].dalpha[k] = dal[k]
+                arr[i].dbeta = dbeta
+                arr[i].nblk, arr[i].c = nblk, c
+            t = KERNEL_TIMER.start()
+            check(lib().octic_layernorm_d8_bwd_finish_batch(ctypes.cast(arr, ctypes.c_void_p), len(ln_jobs), ln_jobs[0][6]))
+            KERNEL_TIMER.stop(t, "ln_bwd_finish_batch_kernel", sum(j[1] * 2 * 8 * j[2] * 4 for j in ln_jobs))
         if not jobs:
             return
         arr = (_FinishJob * len(jobs))()

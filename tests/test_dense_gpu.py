@@ -391,3 +391,30 @@ def test_deferred_finishes_give_bitwise_the_same_parameter_gradients():
         res[mode] = [xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+def test_deferred_octic_layernorm_finishes_are_bitwise_the_immediate_ones():
+    """Two octic blocks: the LayerNormD8 parameter-gradient reductions postponed to the end of the backward pass
+    (octic_layernorm_d8_bwd_finish_batch) against the immediate launches."""
+    from octic_vits_amd import ops as o
+    from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8, Octic
+    torch.manual_seed(0)
+    blk = torch.nn.Sequential(*[Layer_scale_init_BlockD8(256, 4, qkv_bias=True, init_values=0.5) for _ in range(2)]).cuda().train()
+    x = torch.randn(5, 33, 256, device=DEV)
+    cot = torch.randn(5, 33, 256, device=DEV)
+    res = {}
+    for mode in (False, True):
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(Octic(xi, 32))
+        o.DEFERRED_FINISHES.enabled = mode
+        try:
+            y.packed.backward(cot)
+        finally:
+            o.DEFERRED_FINISHES.enabled = False
+        assert not o.DEFERRED_FINISHES.ln_jobs and not o.DEFERRED_FINISHES.jobs and not o.DEFERRED_FINISHES.armed
+        res[mode] = [xi.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.grad is not None]
+    assert len(res[False]) == len(res[True]) > 20
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
