@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 11
+#define OCTIC_ABI_VERSION 12
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -103,6 +103,12 @@ typedef struct octic_ln_finish_job {
   int c;
 } octic_ln_finish_job;
 int octic_layernorm_d8_bwd_finish_batch(const octic_ln_finish_job* jobs, int njobs, void* stream);
+
+/* Sample blocks between a full batch and a compacted one (the opt-in batch compaction of stochastic depth, drop_path_d8 of
+ * d8_layers.py:249-270 computed on the kept samples only): scatter == 0: dst[i] = src[idx[i]], scatter != 0: dst[idx[i]] =
+ * src[i], i < n; a block = block_bytes (multiple of 16) = one sample's token rows; idx int64 on the device, distinct.        */
+int octic_sample_blocks(const void* src, void* dst, const int64_t* idx, int64_t n, int64_t block_bytes, int scatter,
+                        void* stream);
 
 /* ---- LinearD8 (irrep-blocked GEMM on MFMA) ----------------------------------------------------
  * Replaces LinearD8.forward (d8_layers.py:124-127) = five nn.Linear calls, as ONE launch:

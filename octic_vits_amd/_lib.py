@@ -36,6 +36,7 @@ _PROTOS = {
                                             c_void_p, c_void_p]),
     "octic_layernorm_d8_bwd_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "octic_layernorm_d8_bwd_finish_batch": (c_int, [c_void_p, c_int, c_void_p]),
+    "octic_sample_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "octic_linear_d8_fwd": (c_int, [VP, c_void_p, c_void_p, VP, VP, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int,
                                     c_int, c_int, c_void_p]),
     "octic_linear_d8_tile_n": (c_int, [c_i64, c_int, c_int]),
@@ -123,7 +124,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.octic_abi_version() != 11:
+        if L.octic_abi_version() != 12:
             raise RuntimeError("octic_vits_amd: ABI version mismatch between _lib.py and liboctic_hip.so")
         _LIB = L
     return _LIB

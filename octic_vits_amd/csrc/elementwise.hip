@@ -646,6 +646,21 @@ static int heads_check(const octic_view* v, void* const heads[3], int64_t B, int
   return OCTIC_OK;
 }
 
+// Sample blocks between a full batch and a compacted one (d8_layers.COMPACT_DROP_PATH: a branch runs on the samples its
+// stochastic-depth mask keeps):  gather  dst[i] = src[idx[i]]  or scatter  dst[idx[i]] = src[i]  for i < n, a block = the
+// `block_bytes` (a multiple of 16) of one sample's token rows.  16 bytes per lane, blockIdx.y = sample.
+template <int SCATTER>
+__global__ __launch_bounds__(256) void sample_blocks_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                            const int64_t* __restrict__ idx, int64_t block_bytes) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = idx[i];
+  const char* s = src + (SCATTER ? i : j) * block_bytes;
+  char* d = dst + (SCATTER ? j : i) * block_bytes;
+  const int64_t n16 = block_bytes >> 4;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (int64_t)gridDim.x * 256)
+    ((u32x4*)d)[k] = ((const u32x4*)s)[k];
+}
+
 }  // namespace octic
 
 using namespace octic;
@@ -835,6 +850,19 @@ int octic_colsum_a1(const octic_view* dy, int64_t M, int c, int dtype, float* pa
   else if (dtype == OCTIC_BF16) colsum_partial_kernel<bf16><<<nblk, 256, 0, s>>>((const bf16*)dy->ptr[0], dy->ld[0], M, c, partials);
   else return OCTIC_EDTYPE;
   colsum_finish_kernel<<<(c + 15) / 16, 256, 0, s>>>(partials, nblk, c, out);
+  return launch_status();
+}
+
+int octic_sample_blocks(const void* src, void* dst, const int64_t* idx, int64_t n, int64_t block_bytes, int scatter,
+                        void* stream) {
+  if (!src || !dst || !idx) return OCTIC_ENULL;
+  if (n <= 0 || block_bytes <= 0 || (block_bytes & 15) || n > 65535) return OCTIC_ESHAPE;
+  if ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) return OCTIC_EALIGN;
+  int64_t gx = (block_bytes / 16 + 255) / 256;
+  gx = gx > 64 ? 64 : gx;                      // 64 x n workgroups walk a block: enough to fill the chip at n >= 4
+  const dim3 grid((unsigned)gx, (unsigned)n);
+  if (scatter) sample_blocks_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>((const char*)src, (char*)dst, idx, block_bytes);
+  else sample_blocks_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>((const char*)src, (char*)dst, idx, block_bytes);
   return launch_status();
 }
 

@@ -150,6 +150,23 @@ def _const_scale(n, value, device):
     return t
 
 
+def _gather(full, idx):
+    if full.is_cuda:
+        from . import ops
+        if full.is_contiguous() and (full[0].numel() * full.element_size()) % 16 == 0 and 0 < idx.numel() <= 65535:
+            return ops.gather_samples(full, idx)
+    return full.index_select(0, idx)
+
+
+def _scatter_(full, idx, compact):
+    if full.is_cuda:
+        from . import ops
+        compact = compact if compact.is_contiguous() else compact.contiguous()
+        if ops.sample_blocks_ok(full, compact, idx):
+            return ops.scatter_samples_(full, idx, compact)
+    return full.index_copy_(0, idx, compact)
+
+
 class _RowLink:
     """Shared by the gather / scatter pair around one compacted branch (see _GatherRowsFn)."""
     __slots__ = ("g",)
@@ -170,14 +187,14 @@ class _GatherRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx, link):
         ctx.idx, ctx.link = idx, link
-        return x.index_select(0, idx)
+        return _gather(x, idx)
 
     @staticmethod
     def backward(ctx, g_xa):
         g, ctx.link.g = ctx.link.g, None
         if g is None:
             raise RuntimeError("_GatherRowsFn: the stream cotangent of the paired scatter is missing")
-        g.index_copy_(0, ctx.idx, g_xa.to(g.dtype))
+        _scatter_(g, ctx.idx, g_xa.to(g.dtype))
         return g, None, None
 
 
@@ -187,7 +204,7 @@ class _ScatterRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx, out, link):
         ctx.idx, ctx.link = idx, link
-        x.index_copy_(0, idx, out)
+        _scatter_(x, idx, out)
         ctx.mark_dirty(x)
         return x
 
@@ -196,7 +213,7 @@ class _ScatterRowsFn(torch.autograd.Function):
         if not g.is_contiguous():
             g = g.contiguous()
         ctx.link.g = g
-        return None, None, g.index_select(0, ctx.idx), None
+        return None, None, _gather(g, ctx.idx), None
 
 
 def compact_active(dp):

@@ -217,6 +217,27 @@ def layernorm_bwd(g, x, stats, alpha5, dres, c, want_param_grads=True):
     return dx, dal, dbeta
 
 
+def sample_blocks_ok(full, compact, idx):
+    return (full.is_cuda and full.is_contiguous() and compact.is_contiguous() and full.dtype == compact.dtype
+            and idx.dtype == torch.int64 and idx.is_cuda and full.dim() >= 2 and full.shape[1:] == compact.shape[1:]
+            and (full[0].numel() * full.element_size()) % 16 == 0 and 0 < idx.numel() == compact.shape[0] <= 65535)
+
+
+def gather_samples(full, idx):
+    """full[idx] for whole samples (leading dimension) on csrc/elementwise.hip sample_blocks_kernel."""
+    out = torch.empty((idx.numel(),) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    check(lib().octic_sample_blocks(_p(full), _p(out), _p(idx), idx.numel(), full[0].numel() * full.element_size(), 0,
+                                    _stream(full)))
+    return out
+
+
+def scatter_samples_(full, idx, compact):
+    """full[idx] = compact, in place (idx distinct)."""
+    check(lib().octic_sample_blocks(_p(compact), _p(full), _p(idx), idx.numel(), full[0].numel() * full.element_size(), 1,
+                                    _stream(full)))
+    return full
+
+
 def _ln_finish(partials, nblk, c, dal, dbeta, stream):
     """octic_layernorm_d8_bwd_finish now, or batched at the end of the running backward pass (DEFERRED_FINISHES)."""
     if DEFERRED_FINISHES.enabled and _in_backward():

@@ -410,3 +410,20 @@ def test_gelu_d8_is_a_dispatcher_op_that_torch_compile_traces_through():
         # and the module on the engine's native container runs through the same op
         y_o = mod(Octic(x, c))
         assert torch.equal(y_o.packed, torch.ops.octic.gelu_d8(x, c))
+
+
+def test_sample_blocks_gather_and_scatter():
+    """octic_sample_blocks against index_select / index_copy_ for whole samples (f32 and bf16 blocks, odd counts)."""
+    from octic_vits_amd import ops as o
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for dtype, shape in ((torch.float32, (13, 257, 1280)), (torch.bfloat16, (9, 33, 256)), (torch.float32, (5, 4))):
+        full = torch.randn(shape, device="cuda", generator=g).to(dtype)
+        idx = torch.randperm(shape[0], device="cuda", generator=g)[: max(1, shape[0] // 2 + 1)].sort().values
+        got = o.gather_samples(full, idx)
+        assert torch.equal(got, full.index_select(0, idx))
+        comp = torch.randn((idx.numel(),) + shape[1:], device="cuda", generator=g).to(dtype)
+        assert o.sample_blocks_ok(full, comp, idx)
+        want = full.clone().index_copy_(0, idx, comp)
+        assert torch.equal(o.scatter_samples_(full, idx, comp), want)
+    assert not o.sample_blocks_ok(torch.zeros(4, 3, device="cuda"), torch.zeros(2, 3, device="cuda"),
+                                  torch.tensor([0, 1], device="cuda"))            # 12-byte blocks: the ATen path
