@@ -150,8 +150,11 @@ def _const_scale(n, value, device):
     return t
 
 
+USE_SAMPLE_BLOCKS = True    # developer A/B: csrc sample_blocks_kernel (True) or ATen index_select / index_copy_ (False)
+
+
 def _gather(full, idx):
-    if full.is_cuda:
+    if full.is_cuda and USE_SAMPLE_BLOCKS:
         from . import ops
         if full.is_contiguous() and (full[0].numel() * full.element_size()) % 16 == 0 and 0 < idx.numel() <= 65535:
             return ops.gather_samples(full, idx)
@@ -159,7 +162,7 @@ def _gather(full, idx):
 
 
 def _scatter_(full, idx, compact):
-    if full.is_cuda:
+    if full.is_cuda and USE_SAMPLE_BLOCKS:
         from . import ops
         compact = compact if compact.is_contiguous() else compact.contiguous()
         if ops.sample_blocks_ok(full, compact, idx):

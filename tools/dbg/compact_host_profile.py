@@ -6,6 +6,7 @@ from octic_vits_amd import d8_layers as L
 from octic_vits_amd.deit_models import create_model
 from octic_vits_amd.train import Trainer, synthetic_batch
 L.COMPACT_DROP_PATH = "--full" not in sys.argv
+L.USE_SAMPLE_BLOCKS = "--aten" not in sys.argv
 m = create_model("hybrid_deit_huge_patch14", num_classes=1000, drop_path_rate=0.5, img_size=224).cuda()
 tr = Trainer(m, check_every=1000)
 x, y = synthetic_batch(64, 1000, "cuda", 1)
