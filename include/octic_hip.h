@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 12
+#define OCTIC_ABI_VERSION 13
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -172,6 +172,20 @@ int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, in
                                  const float* const w32[5], const float* const cs[5], const float* bias,
                                  const float* dysum, float* const dw[5], float* const dcs[5], float* dbias,
                                  void* stream);
+/* njobs of the finishes above in ceil(njobs / 8) launches, bit-identical to njobs calls (see octic_dense_finish_batch);
+ * has_cs = 0 stands for cs == NULL (w32, cs, dcs ignored).                                                          */
+typedef struct octic_wgrad_finish_job {
+  const float* workspace;
+  const float* w32[5];
+  const float* cs[5];
+  const float* bias;
+  const float* dysum;
+  float* dw[5];
+  float* dcs[5];
+  float* dbias;
+  int splits, cin, cout, has_cs;
+} octic_wgrad_finish_job;
+int octic_linear_d8_wgrad_finish_batch(const octic_wgrad_finish_job* jobs, int njobs, void* stream);
 
 /* Column sums of the A1 block of dy (bias gradient, bias exists on A1 only: d8_layers.py:117-122).
  * out[n] = sum_m dy_A1[m,n]; `partials` holds octic_colsum_blocks(M) * c floats.               */

@@ -46,6 +46,7 @@ _PROTOS = {
     "octic_linear_d8_wgrad": (c_int, [VP, VP, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "octic_linear_d8_wgrad_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "octic_linear_d8_wgrad_finish_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "octic_linear_d8_wgrad_has_colsum": (c_int, [c_int, c_int, c_int]),
     "octic_lamb_workspace_floats": (c_i64, [c_int, c_int]),
     "octic_lamb_step": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float,
@@ -124,7 +125,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.octic_abi_version() != 12:
+        if L.octic_abi_version() != 13:
             raise RuntimeError("octic_vits_amd: ABI version mismatch between _lib.py and liboctic_hip.so")
         _LIB = L
     return _LIB

@@ -381,7 +381,7 @@ struct FinArgs {
   float* dbias;
 };
 
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(FinArgs a) {
+__device__ __forceinline__ void wgrad_finish_body(const FinArgs& a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows_total) return;
@@ -431,6 +431,18 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinArgs a) {
     }
   }
   if (gi == 0 && lane == 0 && a.dbias && have_ysum) a.dbias[n] = s * ysum;
+}
+
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(FinArgs a) { wgrad_finish_body(a); }
+
+// up to 8 finishes in one launch (blockIdx.y = job; see octic_dense_finish_batch in csrc/dense.hip)
+struct FinPack {
+  FinArgs a[8];
+};
+__global__ __launch_bounds__(256) void wgrad_finish_batch_kernel(FinPack pack) {
+  const FinArgs& a = pack.a[blockIdx.y];
+  if ((int)blockIdx.x * 4 >= a.rows_total) return;
+  wgrad_finish_body(a);
 }
 
 inline int pick_tt(const WgArgs& a) {
@@ -601,13 +613,13 @@ int octic_linear_d8_wgrad(const octic_view* x, const octic_view* dy, int64_t M, 
   return OCTIC_EDTYPE;
 }
 
-int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, int cout, const float* const w32[5],
-                                 const float* const cs[5], const float* bias, const float* dysum, float* const dw[5],
-                                 float* const dcs[5], float* dbias, void* stream) {
+static int fin_args(FinArgs& a, const float* workspace, int splits, int cin, int cout, const float* const w32[5],
+                    const float* const cs[5], const float* bias, const float* dysum, float* const dw[5], float* const dcs[5],
+                    float* dbias) {
   if (!workspace || !dw) return OCTIC_ENULL;
   if (splits <= 0 || check_c_dt(cin, OCTIC_F32) || check_c_dt(cout, OCTIC_F32)) return OCTIC_ESHAPE;
   if (cs && (!w32 || !dcs)) return OCTIC_ENULL;
-  FinArgs a = {};
+  a = FinArgs{};
   a.ngroups = 5;
   a.slab_elems = linear_slab_elems(cin, cout);
   a.slabs = workspace;
@@ -634,7 +646,35 @@ int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, in
     if (cs && (!g.w32 || !g.cs || !g.dcs)) return OCTIC_ENULL;
   }
   a.rows_total = row;
-  wgrad_finish_kernel<<<(row + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+  return OCTIC_OK;
+}
+
+int octic_linear_d8_wgrad_finish(const float* workspace, int splits, int cin, int cout, const float* const w32[5],
+                                 const float* const cs[5], const float* bias, const float* dysum, float* const dw[5],
+                                 float* const dcs[5], float* dbias, void* stream) {
+  FinArgs a;
+  const int e = fin_args(a, workspace, splits, cin, cout, w32, cs, bias, dysum, dw, dcs, dbias);
+  if (e) return e;
+  wgrad_finish_kernel<<<(a.rows_total + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+int octic_linear_d8_wgrad_finish_batch(const octic_wgrad_finish_job* jobs, int njobs, void* stream) {
+  if (!jobs) return OCTIC_ENULL;
+  if (njobs < 0) return OCTIC_ESHAPE;
+  for (int i0 = 0; i0 < njobs; i0 += 8) {
+    const int n = njobs - i0 < 8 ? njobs - i0 : 8;
+    FinPack pack;
+    int rmax = 0;
+    for (int i = 0; i < n; ++i) {
+      const octic_wgrad_finish_job& j = jobs[i0 + i];
+      const int e = fin_args(pack.a[i], j.workspace, j.splits, j.cin, j.cout, j.has_cs ? j.w32 : nullptr,
+                             j.has_cs ? j.cs : nullptr, j.bias, j.dysum, j.dw, j.has_cs ? j.dcs : nullptr, j.dbias);
+      if (e) return e;
+      rmax = pack.a[i].rows_total > rmax ? pack.a[i].rows_total : rmax;
+    }
+    wgrad_finish_batch_kernel<<<dim3((rmax + 3) / 4, n), 256, 0, (hipStream_t)stream>>>(pack);
+  }
   return launch_status();
 }
 

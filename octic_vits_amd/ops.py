@@ -345,6 +345,9 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
         dcs = [torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(4)]
         dcs.append(torch.empty(2 * cout, dtype=torch.float32, device=dev))
     dbias = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+    if DEFERRED_FINISHES.enabled and _in_backward():
+        DEFERRED_FINISHES.add_wg(ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, _stream(ref))
+        return dw, dcs, dbias
     check(L.octic_linear_d8_wgrad_finish(_p(ws), splits, cin, cout, _arr5(w32) if cs5 is not None else None,
                                          _arr5(cs5) if cs5 is not None else None, _p(bias), _p(dysum), _arr5(dw),
                                          _arr5(dcs) if dcs is not None else None, _p(dbias), _stream(ref)))
@@ -576,6 +579,13 @@ class _LnFinishJob(ctypes.Structure):
                 ("nblk", ctypes.c_int), ("c", ctypes.c_int)]
 
 
+class _WgFinishJob(ctypes.Structure):
+    _fields_ = [("workspace", ctypes.c_void_p), ("w32", ctypes.c_void_p * 5), ("cs", ctypes.c_void_p * 5),
+                ("bias", ctypes.c_void_p), ("dysum", ctypes.c_void_p), ("dw", ctypes.c_void_p * 5),
+                ("dcs", ctypes.c_void_p * 5), ("dbias", ctypes.c_void_p),
+                ("splits", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("has_cs", ctypes.c_int)]
+
+
 class _DeferredFinishes:
     """Parameter-gradient slab reductions (octic_dense_finish) postponed to the end of the running backward pass and issued
     as ONE batched launch (octic_dense_finish_batch: same summation order, bit-identical results).  Only the caller knows that
@@ -588,6 +598,7 @@ class _DeferredFinishes:
         self.enabled = False
         self.jobs = []          # (partials, nblk, d, out0_ptr, out1_ptr, scale1, keep-alive tensors, stream)
         self.ln_jobs = []       # (partials, nblk, c, [5 dalpha ptrs], dbeta_ptr, keep-alive storages, stream)
+        self.wg_jobs = []       # (filled _WgFinishJob, keep-alive tensors / storages, stream)
         self.armed = False
 
     def add(self, partials, nblk, d, out0_ptr, out1_ptr, scale1, keep, stream):
@@ -604,9 +615,35 @@ class _DeferredFinishes:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
+    def add_wg(self, ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, stream):
+        j = _WgFinishJob()
+        j.workspace = ws.data_ptr()
+        j.has_cs = 1 if cs5 is not None else 0
+        for k in range(5):
+            j.w32[k] = w32[k].data_ptr() if cs5 is not None else None
+            j.cs[k] = cs5[k].data_ptr() if cs5 is not None else None
+            j.dw[k] = dw[k].data_ptr()
+            j.dcs[k] = dcs[k].data_ptr() if dcs is not None else None
+        j.bias = bias.data_ptr() if bias is not None else None
+        j.dysum = dysum.data_ptr() if dysum is not None else None
+        j.dbias = dbias.data_ptr() if dbias is not None else None
+        j.splits, j.cin, j.cout = splits, cin, cout
+        outs = list(dw) + (list(dcs) if dcs is not None else []) + ([dbias] if dbias is not None else [])
+        keep = (ws, w32 if cs5 is not None else None, cs5, bias, dysum, tuple(t.untyped_storage() for t in outs))
+        self.wg_jobs.append((j, keep, stream))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
     def flush(self):
         jobs, self.jobs, self.armed = self.jobs, [], False
         ln_jobs, self.ln_jobs = self.ln_jobs, []
+        wg_jobs, self.wg_jobs = self.wg_jobs, []
+        if wg_jobs:
+            arr = (_WgFinishJob * len(wg_jobs))(*[j for j, _k, _s in wg_jobs])
+            t = KERNEL_TIMER.start()
+            check(lib().octic_linear_d8_wgrad_finish_batch(ctypes.cast(arr, ctypes.c_void_p), len(wg_jobs), wg_jobs[0][2]))
+            KERNEL_TIMER.stop(t, "wgrad_finish_batch_kernel", 0)
         if ln_jobs:
             arr = (_LnFinishJob * len(ln_jobs))()
             for i, (partials, nblk, c, dal, dbeta, _keep, _s) in enumerate(ln_jobs):

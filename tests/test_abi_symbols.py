@@ -21,7 +21,7 @@ def test_library_builds_and_exports_header_symbols():
 
 def test_loader_checks_abi_version_and_errors_render():
     L = _lib.lib()
-    assert L.octic_abi_version() == 12
+    assert L.octic_abi_version() == 13
     assert b"shape" in L.octic_strerror(-1)
     assert b"align" in L.octic_strerror(-2)
 

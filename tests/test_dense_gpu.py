@@ -413,7 +413,8 @@ def test_deferred_octic_layernorm_finishes_are_bitwise_the_immediate_ones():
             y.packed.backward(cot)
         finally:
             o.DEFERRED_FINISHES.enabled = False
-        assert not o.DEFERRED_FINISHES.ln_jobs and not o.DEFERRED_FINISHES.jobs and not o.DEFERRED_FINISHES.armed
+        assert not o.DEFERRED_FINISHES.ln_jobs and not o.DEFERRED_FINISHES.wg_jobs and not o.DEFERRED_FINISHES.jobs
+        assert not o.DEFERRED_FINISHES.armed
         res[mode] = [xi.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.grad is not None]
     assert len(res[False]) == len(res[True]) > 20
     for a, b in zip(res[False], res[True]):
