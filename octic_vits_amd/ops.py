@@ -345,7 +345,7 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
         dcs = [torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(4)]
         dcs.append(torch.empty(2 * cout, dtype=torch.float32, device=dev))
     dbias = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
-    if DEFERRED_FINISHES.enabled and _in_backward():
+    if DEFERRED_FINISHES.enabled and DEFERRED_FINISHES.slabs_too and _in_backward():
         DEFERRED_FINISHES.add_wg(ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, _stream(ref))
         return dw, dcs, dbias
     check(L.octic_linear_d8_wgrad_finish(_p(ws), splits, cin, cout, _arr5(w32) if cs5 is not None else None,
@@ -596,6 +596,8 @@ class _DeferredFinishes:
 
     def __init__(self):
         self.enabled = False
+        self.slabs_too = True   # also postpone the octic weight-gradient slab reductions (their 50 MB slabs stay allocated
+                                # until the end of the pass: off when the launch shapes vary from step to step)
         self.jobs = []          # (partials, nblk, d, out0_ptr, out1_ptr, scale1, keep-alive tensors, stream)
         self.ln_jobs = []       # (partials, nblk, c, [5 dalpha ptrs], dbeta_ptr, keep-alive storages, stream)
         self.wg_jobs = []       # (filled _WgFinishJob, keep-alive tensors / storages, stream)

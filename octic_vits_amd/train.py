@@ -773,8 +773,12 @@ class _FinishScope:
         self.deferred, self.on = deferred, on
 
     def __enter__(self):
+        from . import d8_layers as _L
         self.prev = self.deferred.enabled
         self.deferred.enabled = self.on
+        # compacted stochastic depth: slab sizes change from step to step, and 3 GB of them held to the end of the backward
+        # pass turn the caching allocator's reuse into fresh allocations (measured: +10 ms of host time per step)
+        self.deferred.slabs_too = not _L.COMPACT_DROP_PATH
         return self
 
     def __exit__(self, *exc):
