@@ -711,6 +711,7 @@ static int g_ring_plan_off = 0;   // developer switch (octic_dbg_ring_plan): 1 =
 inline bool plan_ring(GemmArgs& a, int nwg, int slots_per_xcd) {
   a.plan_mode = 0;
   if (g_ring_plan_off || a.ngroups < 2 || nwg < 16) return false;
+  if (nwg > 16 * 8 * slots_per_xcd) return false;   // many rounds: a leftover item is noise, and the DP below is O(items^2)
   const int bke = 64;   // (cost model in K steps of the bf16 kernel; only ratios matter)
   auto items = [&](int g) { return a.g[g].n_chunks * a.g[g].m_tiles; };
   auto cost = [&](int g) { return (a.g[g].K + bke - 1) / bke + 2; };       // + prologue and epilogue, about two steps
