@@ -269,6 +269,7 @@ def _ring_order(items, ksteps, slots=64):
     ([40, 10, 10, 10, 10], [20, 10, 10, 10, 10]),             # fewer items than slots
     ([7, 3, 3], [4, 2, 2]),                                   # tiny launch: the even spread
     ([100, 30, 20], [20, 10, 10]),                            # unequal short groups: the even spread
+    ([9000, 2250, 2250, 2250, 2250], [20, 10, 10, 10, 10]),   # many rounds: no plan is computed, the even spread
     ([64], [10])])
 def test_ring_dispatch_plan_runs_every_item_exactly_once(items, ksteps):
     """Whatever order the planner picks, the workgroups of a launch cover every (group, item) once."""
