@@ -112,13 +112,18 @@ def step_variants(trainer, model, samples, targets, args, n=8):
                                              "stochastic-depth mask keeps (d8_layers.COMPACT_DROP_PATH; same loss and gradients as "
                                              "the masked full batch: tests/test_train_gpu.py::test_compacted_stochastic_depth_"
                                              "equals_the_masked_full_batch); eager launches, DESIGN.md 3.7")
+        except Exception as e:                        # a side figure must never cost the line its `value`
+            out["compact_drop_path_error"] = f"{type(e).__name__}: {e}"[:300]
         finally:
             _L.COMPACT_DROP_PATH = False
     del trainer
-    seg = Trainer(model, segment_graphs=8)           # (re-links the blocks inside the slices: keep this last)
-    seg.capture_segments(samples)
-    ms, host = timed(seg)
-    out["segment_graph_ms_per_step"], out["segment_graph_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
+    try:
+        seg = Trainer(model, segment_graphs=8)       # (re-links the blocks inside the slices: keep this last)
+        seg.capture_segments(samples)
+        ms, host = timed(seg)
+        out["segment_graph_ms_per_step"], out["segment_graph_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
+    except Exception as e:
+        out["segment_graph_error"] = f"{type(e).__name__}: {e}"[:300]
     return out
 
 
@@ -501,7 +506,10 @@ def main():
         if fwd_only is not None:
             line["extra"] = {"forward_only": fwd_only}
         if world == 1 and not ddp and graphed is not None and not args.no_step_variants:
-            line.update(step_variants(trainer, model, samples, targets, args))
+            try:
+                line.update(step_variants(trainer, model, samples, targets, args))
+            except Exception as e:                    # side figures only: the line and its `value` are complete without them
+                line["step_variants_error"] = f"{type(e).__name__}: {e}"[:300]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=real_stdout, flush=True)
