@@ -279,6 +279,8 @@ def main():
     trainer = Trainer(model, distributed=ddp, local_rank=local_rank, accum_steps=args.accum,
                       bf16_buckets=args.bf16_buckets, segment_graphs=nseg, **tkw)
     samples, targets = synthetic_batch(args.batch * args.accum, 1000, dev, 4242 + rank)
+    # the timed steps rotate over three resident batches (the graph replays copy each into their input buffers)
+    batches = [(samples, targets)] + [synthetic_batch(args.batch * args.accum, 1000, dev, 5000 + 17 * j + rank) for j in (1, 2)]
     n_ranks_seen = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
 
     def sync():
@@ -308,7 +310,9 @@ def main():
         except Exception as e:      # a failed capture can leave the stream unusable: measure eagerly in a fresh child
             log(f"graph capture failed ({type(e).__name__}: {e}); re-running eagerly in a child process")
             import subprocess
-            raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"]).returncode)
+            real_stdout.flush()     # fd 1 is stderr in this process (see above): hand the child the real stdout for its line
+            raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"],
+                                            stdout=real_stdout).returncode)
     sync()
     log("warm-up done, timing")
     # The timed region is `steps` full iterations and nothing else: graph replays at one GPU (eager DDP steps otherwise),
@@ -318,7 +322,10 @@ def main():
     w0 = trainer._watch.wait_s
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = graphed.replay() if graphed is not None else trainer.step(samples, targets)
+        # a new batch every step, as a loader would deliver it: the graph's static input buffers are refilled by a
+        # device-to-device copy (38.5 MB of images + targets) that is part of the timed step
+        bx, by = batches[i % len(batches)]
+        loss = graphed.replay(bx, by) if graphed is not None else trainer.step(bx, by)
     # host time to ENQUEUE the steps: wall time of the loop minus the time the loss watch spent waiting for the event of
     # the step two back (that wait only keeps the host from running more than two steps ahead).  Host-bound if ~ elapsed.
     issued = time.perf_counter() - t0 - (trainer._watch.wait_s - w0)

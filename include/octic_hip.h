@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 13
+#define OCTIC_ABI_VERSION 14
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -56,6 +56,25 @@ typedef struct {
 
 int octic_abi_version(void);
 const char* octic_strerror(int code);
+
+/* ---- routing overrides (measurement / tests) --------------------------------------------------
+ * Every entry point chooses its kernel and tiling from the shapes alone.  The alternatives it chooses between are all
+ * shipped and parity-tested; this ONE call forces a choice so that an A/B or a test can run the other kernel on the
+ * same operands.  It is the library's only process-global mutable state: not thread-safe against concurrent launches,
+ * value 0 = automatic (the default), returns the previous value (OCTIC_ESHAPE for an unknown knob).              */
+enum {
+  OCTIC_ROUTE_DENSE_TILE = 0,      /* octic_dense_gemm_nt plain mode: 4 = 256 x 256 tile, 5 = 256 x 320 tile              */
+  OCTIC_ROUTE_DENSE_SPLIT = 1,     /* octic_dense_gemm_nt: n = K-split of the last partial round (1 = unsplit, in front)  */
+  OCTIC_ROUTE_WGRAD_SLABS = 2,     /* octic_dense_wgrad_tn: number of row slabs                                           */
+  OCTIC_ROUTE_WGRAD_TILE = 3,      /* octic_dense_wgrad_tn: 256 | 320 = tile width along K                                */
+  OCTIC_ROUTE_LINEAR_RING = 4,     /* octic_linear_d8_fwd: 1 = ring kernel for every shape (no W-stationary kernel)       */
+  OCTIC_ROUTE_RING_EVEN = 5,       /* octic_linear_d8_fwd ring kernel: 1 = even item spread instead of the planned order  */
+  OCTIC_ROUTE_ATTN_LEGACY = 6,     /* octic_attn_*: 1 = the two-kernel online-softmax family for every shape              */
+  OCTIC_ROUTE_ATTN_ONLINE = 7,     /* octic_attn_fwd*: 1 = persistent online-softmax forward instead of the one-shot one  */
+  OCTIC_ROUTE_ATTN_BWD_PAIR = 8,   /* octic_attn_bwd*: 1 = the dq + dkv kernel pair instead of the single-pass backward   */
+  OCTIC_ROUTE_COUNT = 9
+};
+int octic_route_override(int knob, int value);
 
 /* ---- D8 GELU -------------------------------------------------------------------------------
  * Replaces d8_gelu_fwd / d8_gelu_bwd (Triton, d8_gelu.py:104-196, 210-331, 333-453) and the
@@ -149,6 +168,13 @@ int octic_linear_d8_prep_batch(const octic_prep_item* items_dev, int n_items, in
 /* Output-tile width (32*NT) the launcher picks for this problem; the kernel instantiation that runs is
  * linear_d8_kernel<TIN, TOUT, NT> — exposed so profilers/benchmarks can name it.                 */
 int octic_linear_d8_tile_n(int64_t M, int cin, int cout);
+/* Host-only query (no device call): the workgroup -> item order of a long-K ("ring") launch.  A launch is `ngroups` (<= 5)
+ * item classes, class g with items[g] items of ksteps[g] K-steps each (class 0 = the long one, the E irrep); workgroups are
+ * dispatched in blockIdx order round-robin over the 8 XCDs to slots_per_xcd slots each, so the order is a schedule.
+ * out_group / out_item (sum(items) entries each) receive, per workgroup, the item it runs.  Returns 1 if the planned order
+ * applies, 0 for the even spread, negative on bad arguments.                                                            */
+int octic_linear_d8_ring_order(int ngroups, const int* items, const int* ksteps, int slots_per_xcd, int* out_group,
+                               int* out_item);
 
 /* Weight gradient  G_g[n,k] = sum_rows dy_g[row,n] x_g[row,k]  (E: both rows).  Reduction over the
  * M (2M) rows is split over `splits` row ranges whose f32 partial slabs go to `workspace`

@@ -12,6 +12,10 @@ LIB_PATH = os.environ.get("OCTIC_LIB") or os.path.join(HERE, "liboctic_hip.so") 
 HEADER_PATH = os.path.join(HERE, "..", "include", "octic_hip.h")
 
 F32, BF16 = 0, 1
+ABI_VERSION = 14
+# knobs of octic_route_override (include/octic_hip.h)
+(ROUTE_DENSE_TILE, ROUTE_DENSE_SPLIT, ROUTE_WGRAD_SLABS, ROUTE_WGRAD_TILE, ROUTE_LINEAR_RING, ROUTE_RING_EVEN,
+ ROUTE_ATTN_LEGACY, ROUTE_ATTN_ONLINE, ROUTE_ATTN_BWD_PAIR) = range(9)
 
 c_i64, c_int, c_float, c_void_p = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -27,6 +31,7 @@ VP = ctypes.POINTER(OcticView)
 _PROTOS = {
     "octic_abi_version": (c_int, []),
     "octic_strerror": (ctypes.c_char_p, [c_int]),
+    "octic_route_override": (c_int, [c_int, c_int]),
     "octic_gelu_d8_fwd": (c_int, [VP, VP, c_i64, c_int, c_int, c_void_p]),
     "octic_gelu_d8_bwd": (c_int, [VP, VP, VP, c_i64, c_int, c_int, c_void_p]),
     "octic_layernorm_d8_fwd": (c_int, [VP, VP, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p]),
@@ -40,6 +45,7 @@ _PROTOS = {
     "octic_linear_d8_fwd": (c_int, [VP, c_void_p, c_void_p, VP, VP, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int,
                                     c_int, c_int, c_void_p]),
     "octic_linear_d8_tile_n": (c_int, [c_i64, c_int, c_int]),
+    "octic_linear_d8_ring_order": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "octic_linear_d8_wgrad_tile": (c_int, [c_i64, c_int, c_int]),
     "octic_linear_d8_wgrad_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "octic_linear_d8_wgrad_splits": (c_int, [c_i64, c_int, c_int]),
@@ -125,10 +131,18 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.octic_abi_version() != 13:
+        if L.octic_abi_version() != ABI_VERSION:
             raise RuntimeError("octic_vits_amd: ABI version mismatch between _lib.py and liboctic_hip.so")
         _LIB = L
     return _LIB
+
+
+def route_override(knob: int, value: int) -> int:
+    """Force a kernel / tiling choice for an A/B or a test (0 = automatic); returns the previous value."""
+    old = lib().octic_route_override(knob, value)
+    if old < 0:
+        raise ValueError(f"octic_route_override: unknown knob {knob}")
+    return old
 
 
 def check(code: int):

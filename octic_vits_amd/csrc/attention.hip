@@ -690,14 +690,14 @@ __global__ __launch_bounds__(512) void attn_fwd_persist_kernel(AttnArgs a, int r
   }
 }
 
-static int g_attn_legacy = 0;     // developer switch (octic_dbg_attn_legacy): 1 = round-2 kernels for every shape
+// routing override OCTIC_ROUTE_ATTN_LEGACY: 1 = round-2 kernels for every shape
 
 template <int KS, int DT>
 static int attn_fwd_launch(const AttnArgs& a, int64_t B, hipStream_t s) {
   // the forward is light on registers: one wave per tile even for nine tiles (three waves on one SIMD hide the
   // softmax latency better than the shared-tile split does: 78 vs 85 us at T = 257); the kernel supports both
   const int rsk = attn_rsk(a.hd), rsv = attn_rsv(DT * 32);
-  if (!g_attn_legacy && attn80_fwd_ok(a)) return attn80_fwd_launch(a, B, s);
+  if (!route(OCTIC_ROUTE_ATTN_LEGACY) && attn80_fwd_ok(a)) return attn80_fwd_launch(a, B, s);
   {
     const int nt = (a.T + 31) / 32, W = nt < 8 ? nt : 8;
     const int nrows = a.T - W * 32;
@@ -1103,7 +1103,7 @@ static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream
   // dkv (two accumulator sets) needs the 256-register budget of the eight-wave split (105 vs 156 us with spills);
   // dq runs the same either way (~106 us) and follows it
   // both gradients asked for at once: the single-pass kernel (csrc/attn80_bwd.hip) where its shape applies
-  if (phase == 3 && KS == 5 && !g_attn_legacy && attn80_bwd_ok(a)) return attn80_bwd_launch(a, B, s);
+  if (phase == 3 && KS == 5 && !route(OCTIC_ROUTE_ATTN_LEGACY) && attn80_bwd_ok(a)) return attn80_bwd_launch(a, B, s);
   const int nt = (a.T + 31) / 32, W = attn_waves(nt), Wq = W;
   // the row images are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16); rows are padded so the
   // b128 reads are conflict-free, the transposed reads then see at most 2-way conflicts.  The tr fragments reach
@@ -1141,12 +1141,6 @@ static int attn_bwd_launch(const AttnBwdArgs& a, int64_t B, int phase, hipStream
 using namespace octic;
 
 extern "C" {
-
-int octic_dbg_attn_legacy(int on) {
-  const int old = g_attn_legacy;
-  g_attn_legacy = on;
-  return old;
-}
 
 int octic_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int H, int T, int hd,
                    int64_t sB, int64_t sH, int64_t sT, int64_t oB, int64_t oH, int64_t oT, float scale, void* stream) {

@@ -595,16 +595,15 @@ static int cu_count() {
 
 }  // namespace a80
 
-static int g_a80_variant = 0;      // developer switch: 0 = one-shot softmax where it applies, 1 = online softmax everywhere;
-                                   // +16: K / V descriptors with zero records (timing probe)
-extern "C" int octic_dbg_a80_variant(int v) { const int o = g_a80_variant; g_a80_variant = v; return o; }
+// routing override OCTIC_ROUTE_ATTN_ONLINE: 0 = one-shot softmax where it applies, 1 = online softmax everywhere
+// (+16: K / V descriptors with zero records, a timing probe of developer runs)
 
 int attn80_fwd_ok(const AttnArgs& a) { return a80::shape_ok(a.T, a.hd, a.sT, a.oT) ? 1 : 0; }
 
 int attn80_fwd_launch(const AttnArgs& a_, int64_t B, hipStream_t s) {
   using namespace a80;
   AttnArgs a = a_;
-  a.dbg = g_a80_variant >> 4;
+  a.dbg = route(OCTIC_ROUTE_ATTN_ONLINE) >> 4;
   const int nt = (a.T + 31) / 32, W = nt < 8 ? nt : 8;
   const int units = (int)(B * a.H), cus = cu_count();
   static DeviceOnce once;
@@ -613,7 +612,7 @@ int attn80_fwd_launch(const AttnArgs& a_, int64_t B, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)fwd_os_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
   }
-  if ((g_a80_variant & 15) == 0 && nt == MAXNT) fwd_os_kernel<<<units < cus ? units : cus, 512, fwd_os_lds(nt), s>>>(a, units);
+  if ((route(OCTIC_ROUTE_ATTN_ONLINE) & 15) == 0 && nt == MAXNT) fwd_os_kernel<<<units < cus ? units : cus, 512, fwd_os_lds(nt), s>>>(a, units);
   else fwd_kernel<<<units < cus ? units : cus, W * 64, fwd_lds(nt), s>>>(a, nt, units);
   return launch_status();
 }

@@ -425,13 +425,12 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
 
 }  // namespace a80
 
-static int g_a80_bwd = 1;          // developer switch (octic_dbg_a80_bwd): 0 = the round-2 dq + dkv pair for every shape
-extern "C" int octic_dbg_a80_bwd(int on) { const int o = g_a80_bwd; g_a80_bwd = on; return o; }
+// routing override OCTIC_ROUTE_ATTN_BWD_PAIR: 1 = the round-2 dq + dkv pair for every shape
 
 // shapes of the single-pass backward: head_dim 80, exactly 257 tokens (8 key tiles + one extra row), 32-bit offsets
 int attn80_bwd_ok(const AttnBwdArgs& a) {
   using namespace a80;
-  return (g_a80_bwd && a.hd == HD && a.T == BW_T && (int64_t)a.T * a.sT * 2 < 0x7FFFFFF0ll && (int64_t)a.T * a.oT * 2 < 0x7FFFFFF0ll &&
+  return (!route(OCTIC_ROUTE_ATTN_BWD_PAIR) && a.hd == HD && a.T == BW_T && (int64_t)a.T * a.sT * 2 < 0x7FFFFFF0ll && (int64_t)a.T * a.oT * 2 < 0x7FFFFFF0ll &&
           (int64_t)a.T * a.gT * 2 < 0x7FFFFFF0ll) ? 1 : 0;
 }
 

@@ -844,16 +844,18 @@ inline DgPlan dense_plan_nt(int M, int N, int K, int cus, int nt, int force_spli
 // can land on another plan's tickets.
 constexpr int DG_TICKET_BYTES = 8192;
 
-static int g_dense_force_nt = 0;
-static int g_dense_force_split = 0;   // developer switch (octic_dbg_dense_split): 0 = plan's choice, n = split of the remaining tiles (1 = unsplit, kept in front)      // developer switch (octic_dbg_dense_tile): 0 = choose by the cost model, 4 / 5 = force
+// routing overrides (octic_route_override): OCTIC_ROUTE_DENSE_TILE 0 = choose by the cost model, 4 / 5 = force;
+// OCTIC_ROUTE_DENSE_SPLIT 0 = plan's choice, n = split of the remaining tiles (1 = unsplit, kept in front)
+static inline int dense_force_nt() { const int v = route(OCTIC_ROUTE_DENSE_TILE); return (v == 4 || v == 5) ? v : 0; }
+static inline int dense_force_split() { const int v = route(OCTIC_ROUTE_DENSE_SPLIT); return v > 0 ? v : 0; }
 
 // The 320-wide tile serves plain-epilogue problems whose N is a multiple of 320 when the model says its launch is shorter
 // (ViT-H: N = 1280 - one round of 256 tiles instead of 1.27 rounds of 325).
 inline DgPlan dense_plan(int M, int N, int K, int cus, int mode) {
-  const DgPlan p4 = dense_plan_nt(M, N, K, cus, 4, g_dense_force_split, g_dense_force_split == 1);
-  if (mode != DG_PLAIN || (N % 320) != 0 || g_dense_force_nt == 4) return p4;
-  const DgPlan p5 = dense_plan_nt(M, N, K, cus, 5, g_dense_force_split, g_dense_force_split == 1);
-  if (g_dense_force_nt == 5) return p5;
+  const DgPlan p4 = dense_plan_nt(M, N, K, cus, 4, dense_force_split(), dense_force_split() == 1);
+  if (mode != DG_PLAIN || (N % 320) != 0 || dense_force_nt() == 4) return p4;
+  const DgPlan p5 = dense_plan_nt(M, N, K, cus, 5, dense_force_split(), dense_force_split() == 1);
+  if (dense_force_nt() == 5) return p5;
   return p5.cost < p4.cost ? p5 : p4;
 }
 
@@ -873,7 +875,7 @@ int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K) {
   for (int nt = 4; nt <= 5; ++nt) {
     if (nt == 5 && (N % 320) != 0) continue;
     DgPlan p = dense_plan_nt(M, N, K, dense_cus(), nt);
-    if (g_dense_force_split > 1) p = dense_plan_nt(M, N, K, dense_cus(), nt, 8);     // developer switch: room for any split
+    if (dense_force_split() > 1) p = dense_plan_nt(M, N, K, dense_cus(), nt, 8);     // developer switch: room for any split
     if (p.split <= 1) continue;
     const int64_t b = (int64_t)p.rem * p.split * DG_BM * (64 * nt) * 4 + DG_TICKET_BYTES + 256;
     need = b > need ? b : need;
@@ -885,10 +887,6 @@ int octic_dense_gemm_tile(int M, int N, int K, int mode) {
   if (M <= 0 || N <= 0 || K < 2 * DG_BK) return 256;
   return dense_plan(M, N, K, dense_cus(), mode).nt == 5 ? 320 : 256;
 }
-
-// developer switch: force the tile width of the plain mode (0 = cost model, 4 = 256-wide, 5 = 320-wide where N % 320 == 0)
-void octic_dbg_dense_tile(int nt) { g_dense_force_nt = (nt == 4 || nt == 5) ? nt : 0; }
-void octic_dbg_dense_split(int s) { g_dense_force_split = s > 0 ? s : 0; }
 
 int octic_dense_gemm_colsum_rows(int M, int N, int K) {
   (void)N; (void)K;

@@ -496,10 +496,10 @@ extern "C" {
 
 // Row slabs: the items (tiles8 x S) run in ceil(items / CUs) rounds of ceil(steps / S) reduction steps each; every item
 // also pays a fixed prologue + slab epilogue (about 8 steps' worth).  Pick the S with the shortest estimate.
-static int g_tn_slabs_override = 0;
-static int g_tn_width_override = 0;    // developer knob: 256 | 320 forces the tile width where the shape allows it
+// routing overrides (octic_route_override): OCTIC_ROUTE_WGRAD_SLABS forces the number of row slabs, OCTIC_ROUTE_WGRAD_TILE
+// (256 | 320) the tile width where the shape allows it; 0 = automatic
 static int dw_slabs(int tiles, int steps) {
-  if (g_tn_slabs_override > 0) return g_tn_slabs_override <= steps / 2 ? g_tn_slabs_override : (steps / 2 > 0 ? steps / 2 : 1);
+  if (route(OCTIC_ROUTE_WGRAD_SLABS) > 0) return route(OCTIC_ROUTE_WGRAD_SLABS) <= steps / 2 ? route(OCTIC_ROUTE_WGRAD_SLABS) : (steps / 2 > 0 ? steps / 2 : 1);
   const int cus = device_cus();
   const int tiles8 = (tiles + 7) / 8 * 8;
   const int per_slab = DW_MAP == 1 ? tiles : tiles8;
@@ -539,20 +539,8 @@ static DwPlan dw_plan(int M, int N, int K) {
     return p;
   };
   const bool ok4 = K % 256 == 0, ok5 = K % 320 == 0;          // (the entry points refuse K that fits neither)
-  if (ok5 && (!ok4 || g_tn_width_override == 320)) return make(5);
+  if (ok5 && (!ok4 || route(OCTIC_ROUTE_WGRAD_TILE) == 320)) return make(5);
   return make(4);
-}
-
-int octic_dbg_dense_wgrad_slabs(int S) {      // developer knob: force the number of row slabs (0 = automatic)
-  const int old = g_tn_slabs_override;
-  g_tn_slabs_override = S;
-  return old;
-}
-
-int octic_dbg_dense_wgrad_tile(int width) {   // developer knob: force the tile width (256 | 320; 0 = automatic)
-  const int old = g_tn_width_override;
-  g_tn_width_override = width;
-  return old;
 }
 
 int octic_dense_wgrad_tile(int M, int N, int K) {      // tile width the launch uses (256 | 320)
@@ -567,7 +555,7 @@ int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K) {
   for (int kw = 4; kw <= 5; ++kw) {
     if (K % (64 * kw)) continue;
     const int tiles = (N / DW_T) * (K / (64 * kw));
-    const int S = g_tn_slabs_override > 0 ? 16 : dw_slabs(tiles, steps);
+    const int S = route(OCTIC_ROUTE_WGRAD_SLABS) > 0 ? 16 : dw_slabs(tiles, steps);
     const int64_t b = (int64_t)tiles * S * (DW_T * 64 * kw) * 4;
     need = b > need ? b : need;
   }

@@ -661,6 +661,8 @@ __global__ __launch_bounds__(256) void sample_blocks_kernel(const char* __restri
     ((u32x4*)d)[k] = ((const u32x4*)s)[k];
 }
 
+int g_route[OCTIC_ROUTE_COUNT] = {};
+
 }  // namespace octic
 
 using namespace octic;
@@ -668,6 +670,13 @@ using namespace octic;
 extern "C" {
 
 int octic_abi_version(void) { return OCTIC_ABI_VERSION; }
+
+int octic_route_override(int knob, int value) {
+  if (knob < 0 || knob >= OCTIC_ROUTE_COUNT) return OCTIC_ESHAPE;
+  const int old = octic::g_route[knob];
+  octic::g_route[knob] = value;
+  return old;
+}
 
 const char* octic_strerror(int code) {
   switch (code) {

@@ -707,10 +707,10 @@ inline int sim_xcd(int n, int a, int e, int slots, int c_short, int c_long) {
   }
   return mk;
 }
-static int g_ring_plan_off = 0;   // developer switch (octic_dbg_ring_plan): 1 = the even spread of round 3
+// routing override OCTIC_ROUTE_RING_EVEN: 1 = the even spread of round 3
 inline bool plan_ring(GemmArgs& a, int nwg, int slots_per_xcd) {
   a.plan_mode = 0;
-  if (g_ring_plan_off || a.ngroups < 2 || nwg < 16) return false;
+  if (route(OCTIC_ROUTE_RING_EVEN) || a.ngroups < 2 || nwg < 16) return false;
   if (nwg > 16 * 8 * slots_per_xcd) return false;   // many rounds: a leftover item is noise, and the DP below is O(items^2)
   const int bke = 64;   // (cost model in K steps of the bf16 kernel; only ratios matter)
   auto items = [&](int g) { return a.g[g].n_chunks * a.g[g].m_tiles; };
@@ -927,12 +927,10 @@ inline int dispatch_gemm(GemmArgs& a, int dtype, int out_dtype, hipStream_t s) {
 
 using namespace octic;
 
-extern "C" void octic_dbg_ring_plan(int off) { octic::g_ring_plan_off = off; }
-
-// Developer / test entry (host only, no device call): the item order of a ring launch.  items[g] / ksteps[g] describe
+// Host-only query (no device call): the item order of a ring launch.  items[g] / ksteps[g] describe
 // group g (group 0 = the long one); out_group / out_item receive, per workgroup in blockIdx order, the item it would run.
 // Returns the plan mode (1 = planned order, 0 = even spread) or a negative error.
-extern "C" int octic_dbg_ring_order(int ngroups, const int* items, const int* ksteps, int slots_per_xcd, int* out_group,
+extern "C" int octic_linear_d8_ring_order(int ngroups, const int* items, const int* ksteps, int slots_per_xcd, int* out_group,
                                     int* out_item) {
   if (ngroups < 1 || ngroups > 5 || !items || !ksteps || !out_group || !out_item) return OCTIC_ENULL;
   GemmArgs a = {};

@@ -66,7 +66,7 @@ __device__ unsigned long long g_trace[1024 * 4 * 128];
 #define WTRACE(slot) do {} while (0)
 #endif
 
-int g_off = 0;   // developer switch: 1 = never take this kernel (A/B against the ring kernel)
+// routing override OCTIC_ROUTE_LINEAR_RING: 1 = never take this kernel (A/B against the ring kernel)
 
 template <typename TOUT>
 __device__ __forceinline__ void stage_out4(char* p, f32x4 v);
@@ -423,7 +423,7 @@ static int cu_count() {
 template <typename TOUT>
 int launch_t(GemmArgs& a, hipStream_t s) {
   constexpr int ES = (int)sizeof(TOUT);
-  if (a.lift_np > 0 || g_off) return -100;
+  if (a.lift_np > 0 || route(OCTIC_ROUTE_LINEAR_RING)) return -100;
   int Kc = 0;
   bool fused = a.rs != nullptr;
   for (int i = 0; i < a.ngroups; ++i) {
@@ -519,4 +519,4 @@ extern "C" void* octic_dbg_wreg_trace(void) {
 #endif
 
 // developer switch (not part of the ABI contract): 1 = route the short-K problems to the ring kernel instead
-extern "C" void octic_dbg_wreg_off(int off) { octic::wr::g_off = off; }
+

@@ -6,6 +6,10 @@
 
 namespace octic {
 
+// routing overrides (octic_route_override, include/octic_hip.h): one table for the whole library, defined in elementwise.hip
+extern int g_route[OCTIC_ROUTE_COUNT];
+inline int route(int knob) { return g_route[knob]; }
+
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -286,9 +286,11 @@ class LinearD8Fn(torch.autograd.Function):
         # (one extra MFMA row); other paths run the column-sum kernel
         dysum = ops.colsum_a1(gv, M, cout, dtype, x) if (has_bias and not ops.wgrad_has_colsum(cin, cout, dtype)) else None
         w32 = [_c(w.detach().float()) for w in w5] if has_cs else None
+        f32_masters = all(w.dtype == torch.float32 for w in w5)      # else the casts below read dw at once: no deferral
         dw, dcs, dbias = ops.linear_wgrad(xv, gv, M, cin, cout, dtype, x, w32=w32, cs5=cs32, bias=b32, dysum=dysum,
-                                          want_bias=has_bias)
-        dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
+                                          want_bias=has_bias, may_defer=f32_masters)
+        if not f32_masters:
+            dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
         dcs = dcs if has_cs else [None] * 5
         return (dx, *dw, dbias, dy if fused else None, None, *dcs, None, None, None, None, None)
 
@@ -356,9 +358,11 @@ class LinearD8NormFn(torch.autograd.Function):
                 dx = dx.to(x_in_dtype)
         dysum = ops.colsum_a1(gv, M, cout, dtype, x) if (has_bias and not ops.wgrad_has_colsum(cin, cout, dtype)) else None
         w32 = [_c(w.detach().float()) for w in w5] if has_cs else None
+        f32_masters = all(w.dtype == torch.float32 for w in w5)      # else the casts below read dw at once: no deferral
         dw, dcs, dbias = ops.linear_wgrad(xv, gv, M, cin, cout, dtype, x, w32=w32, cs5=cs32, bias=b32, dysum=dysum,
-                                          want_bias=has_bias)
-        dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
+                                          want_bias=has_bias, may_defer=f32_masters)
+        if not f32_masters:
+            dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
         dcs = dcs if has_cs else [None] * 5
         return (dx, *dw, dbias, dy, None, *dcs, None, None, None, None, None, *dal, dbeta if has_beta else None, None)
 

@@ -321,8 +321,10 @@ def linear_kernel_name(cin, dtype, out_dtype, fused):
     return f"linear_d8_kernel<{_DTN[dtype]},{_DTN[out_dtype]}>"
 
 
-def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=None, dysum=None, want_bias=False):
-    """Returns (dw5 [f32], dcs5 or None, dbias or None)."""
+def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=None, dysum=None, want_bias=False,
+                 may_defer=True):
+    """Returns (dw5 [f32], dcs5 or None, dbias or None).  may_defer=False: the caller reads the results at once (e.g. casts
+    them for non-f32 master weights), so the slab reduction must not be postponed to the end of the backward pass."""
     L = lib()
     dev = ref.device
     splits = L.octic_linear_d8_wgrad_splits(M, cin, cout)
@@ -345,7 +347,7 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
         dcs = [torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(4)]
         dcs.append(torch.empty(2 * cout, dtype=torch.float32, device=dev))
     dbias = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
-    if DEFERRED_FINISHES.enabled and DEFERRED_FINISHES.slabs_too and _in_backward():
+    if may_defer and DEFERRED_FINISHES.enabled and DEFERRED_FINISHES.slabs_too and _in_backward():
         DEFERRED_FINISHES.add_wg(ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, _stream(ref))
         return dw, dcs, dbias
     check(L.octic_linear_d8_wgrad_finish(_p(ws), splits, cin, cout, _arr5(w32) if cs5 is not None else None,

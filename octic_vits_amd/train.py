@@ -456,9 +456,6 @@ class _Segment(nn.Module):
                 if isinstance(x, OF.Octic):
                     x = x.packed
                 if self.last:
-                    if m.dropout_rate:
-                        raise RuntimeError("SegmentedModel: dropout in front of the head is applied by the wrapper; "
-                                           "slice the model with the head outside or set dropout_rate = 0")
                     x = m.norm(x)
                     x = x.mean(dim=1) if m.global_pool else x[:, 0]
                     x = m.head(x)
@@ -485,6 +482,13 @@ class SegmentedModel(nn.Module):
         from .d8_layers import link_octic_blocks
         self.model = model
         nb, brk = len(model.blocks), model.octic_equi_break_layer
+        if brk < 1:
+            # (model._forward_features hands the lifted tokens to the standard half before any block; the slices only do
+            # the hand-off behind an octic block)
+            raise ValueError("SegmentedModel: octic_equi_break_layer must be >= 1 (a model without octic blocks has no "
+                             "octic -> standard hand-off inside a slice)")
+        if model.dropout_rate:
+            raise ValueError("SegmentedModel: dropout in front of the head (dropout_rate > 0) is not part of a slice")
         n_segments = max(1, min(int(n_segments), nb))
         # boundaries: evenly spaced, and the octic / standard hand-off is always one of them
         cuts = sorted(set([0, nb] + [round(i * nb / n_segments) for i in range(1, n_segments)] + ([brk] if 0 < brk < nb else [])))
@@ -510,8 +514,6 @@ class SegmentedModel(nn.Module):
     def forward(self, x):
         for sg in self._segments:
             x = sg(x)
-        if self.model.dropout_rate:
-            x = torch.nn.functional.dropout(x, p=float(self.model.dropout_rate), training=self.training)
         return x
 
     def capture(self, samples, warmup=3):
@@ -659,7 +661,12 @@ class Trainer:
         if _L.COMPACT_DROP_PATH:
             raise RuntimeError("Trainer.capture_segments: d8_layers.COMPACT_DROP_PATH changes the launch shapes from step to "
                                "step; graphed slices need static shapes")
-        if isinstance(self.optimizer, FusedLamb) and self.optimizer.step_count == 0:
+        if not isinstance(self.optimizer, FusedLamb):
+            # The graphs hold no weight casts: they read the static bf16 / prepared copies that only FusedLamb.step rewrites
+            # in place.  With another optimizer the replays would use the capture-time weights for ever.
+            raise RuntimeError("Trainer.capture_segments needs fused_optimizer=True: graphed slices read the compute-dtype "
+                               "weight copies that the fused optimizer step refreshes in place")
+        if self.optimizer.step_count == 0:
             # no step yet: one forward (the weight caches record their operands), then the static weight buffers
             self.segmented.train()
             with torch.no_grad():
@@ -668,7 +675,16 @@ class Trainer:
         self.segmented.capture(samples, warmup=warmup)
         if self._ddp_args is not None and self.model is self.segmented:
             self._wrap_ddp()
+            if self.optimizer.step_count == 0:
+                # the wrapper has just broadcast rank 0's parameters: ranks whose initial weights differed must not keep
+                # compute-dtype copies of their pre-broadcast values for the first step
+                self.optimizer.prime()
         return self
+
+    def finish(self):
+        """Look at every loss the two-steps-late watch has not checked yet (raises FloatingPointError like the reference's
+        per-iteration check, deit/engine.py:67-71).  Call at the end of an epoch and before writing a checkpoint."""
+        self._watch.drain()
 
     def _forward_loss(self, samples, targets):
         if self.autocast:

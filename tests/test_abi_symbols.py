@@ -17,11 +17,24 @@ def test_library_builds_and_exports_header_symbols():
     assert not missing, f"declared in octic_hip.h but not exported: {missing}"
     # the ctypes prototypes cover exactly the header
     assert sorted(_lib._PROTOS) == declared
+    # ... and the library exports nothing else under the octic_ prefix (no undeclared developer switches)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("octic_")})
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+
+
+def test_route_override_is_the_only_switch_and_round_trips():
+    L = _lib.lib()
+    assert L.octic_route_override(-1, 1) == -1 and L.octic_route_override(99, 1) == -1
+    for knob in range(9):
+        assert _lib.route_override(knob, 3) == 0
+        assert _lib.route_override(knob, 0) == 3
 
 
 def test_loader_checks_abi_version_and_errors_render():
     L = _lib.lib()
-    assert L.octic_abi_version() == 13
+    assert L.octic_abi_version() == _lib.ABI_VERSION == 14
     assert b"shape" in L.octic_strerror(-1)
     assert b"align" in L.octic_strerror(-2)
 

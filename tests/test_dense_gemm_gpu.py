@@ -57,14 +57,9 @@ def test_dense_nt_integer_operands_bit_exact(M, N, K):
 
 
 def _force_tile(nt):
-    """developer switch of csrc/dense_gemm.hip: tile width of the plain mode (0 = cost model, 4 = 256-wide, 5 = 320-wide)"""
-    import ctypes
+    """routing override of csrc/dense_gemm.hip: tile width of the plain mode (0 = cost model, 4 = 256-wide, 5 = 320-wide)"""
     from octic_vits_amd import _lib
-    _lib.lib()
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.octic_dbg_dense_tile.argtypes = [ctypes.c_int]
-    raw.octic_dbg_dense_tile.restype = None
-    raw.octic_dbg_dense_tile(nt)
+    _lib.route_override(_lib.ROUTE_DENSE_TILE, nt)
 
 
 # round 4: the 256 x 320 tile (one round of workgroups for the N = 1280 problems).  Shapes with N % 320 == 0: ViT-H's four
@@ -281,14 +276,9 @@ def test_dense_wgrad_tn_integer_operands_exact(M, N, K):
 
 # round 4: the 256 x 320 tile of the TN kernel (K % 320 == 0: 80 tiles x 3 slabs instead of 100 x 2 for the MLP weights)
 def _force_tn_tile(width):
-    """developer switch of csrc/dense_wgrad.hip: tile width along K (0 = launch estimate, 256, 320)"""
-    import ctypes
+    """routing override of csrc/dense_wgrad.hip: tile width along K (0 = launch estimate, 256, 320)"""
     from octic_vits_amd import _lib
-    _lib.lib()
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.octic_dbg_dense_wgrad_tile.argtypes = [ctypes.c_int]
-    raw.octic_dbg_dense_wgrad_tile.restype = ctypes.c_int
-    raw.octic_dbg_dense_wgrad_tile(width)
+    _lib.route_override(_lib.ROUTE_WGRAD_TILE, width)
 
 
 TN320_SHAPES = [(200, 256, 320), (64, 512, 640), (1, 256, 320), (130, 256, 960), (1000, 768, 1280), (16448, 1280, 1280),

@@ -249,16 +249,14 @@ def test_loss_watch_raises_two_steps_late_and_never_on_finite_losses():
 
 # ------------------------------------------------------------------------------------------------ ring dispatch plan
 def _ring_order(items, ksteps, slots=64):
-    """csrc/gemm.hip plan_ring + ring_item_of through the host-only developer entry (no device call)."""
+    """csrc/gemm.hip plan_ring + ring_item_of through the host-only query octic_linear_d8_ring_order (no device call)."""
     import ctypes
     from octic_vits_amd import _lib
-    _lib.lib()
-    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw = _lib.lib()
     n = sum(items)
     arr = lambda v: (ctypes.c_int * len(v))(*v)
     og, oi = (ctypes.c_int * n)(), (ctypes.c_int * n)()
-    raw.octic_dbg_ring_order.restype = ctypes.c_int
-    mode = raw.octic_dbg_ring_order(len(items), arr(items), arr(ksteps), slots, og, oi)
+    mode = raw.octic_linear_d8_ring_order(len(items), arr(items), arr(ksteps), slots, og, oi)
     return mode, list(zip(og, oi))
 
 
@@ -361,3 +359,38 @@ def test_compact_index_pool_matches_its_masks():
         L._compact_pool.clear()
     idx, n, scale = L._compact_plan(4, type("DP", (), {"drop_prob": 1.0, "scale_by_keep": True})(), dev)
     assert n == 1 and scale == 0.0 and idx.tolist() == [0]         # a mask that keeps nobody: one sample, scale 0
+
+
+# ------------------------------------------------------------------------------------------------ trainer guards (round 5)
+def _tiny_hybrid(**kw):
+    from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.vit import Layer_scale_init_Block
+    args = dict(img_size=32, patch_size=16, num_classes=5, embed_dim=64, depth=4, num_heads=2, qkv_bias=True, init_scale=0.1,
+                octic_block_layers=Layer_scale_init_BlockD8, standard_block_layers=Layer_scale_init_Block)
+    args.update(kw)
+    return OcticVisionTransformer(**args)
+
+
+def test_segment_graph_trainer_refuses_what_its_graphs_cannot_follow():
+    """Graphed slices read static compute-dtype weight copies that only FusedLamb refreshes (advisor, round 4): another
+    optimizer must be refused, as Trainer.capture does; a model without an octic block in front of the hand-off and head
+    dropout are rejected by the slicer instead of being computed differently from model.forward."""
+    from octic_vits_amd.train import SegmentedModel, Trainer
+    t = Trainer(_tiny_hybrid(), fused_optimizer=False, segment_graphs=2, tuned_gemms=False, device_type="cpu")
+    with pytest.raises(RuntimeError, match="fused_optimizer=True"):
+        t.capture_segments(torch.zeros(2, 3, 32, 32))
+    with pytest.raises(ValueError, match="octic_equi_break_layer"):
+        SegmentedModel(_tiny_hybrid(octic_equi_break_layer=0), 2)
+    with pytest.raises(ValueError, match="dropout"):
+        SegmentedModel(_tiny_hybrid(drop_rate=0.1), 2)
+
+
+def test_trainer_finish_checks_the_losses_the_late_watch_has_not_seen():
+    from octic_vits_amd.train import Trainer
+    t = Trainer(_tiny_hybrid(), fused_optimizer=False, tuned_gemms=False, device_type="cpu")
+    t._watch.push(torch.tensor(0.5))
+    t.finish()                                   # finite: nothing happens
+    t._watch.push(torch.tensor(float("inf")))    # the last step of a run: never reached by check()
+    with pytest.raises(FloatingPointError):
+        t.finish()

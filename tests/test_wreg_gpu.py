@@ -5,7 +5,7 @@ resid + rs[sample] * cs * (.) of the residual blocks (d8_layers.py:484-498), on 
 Shapes: ragged row tails (M % 32 != 0), column tails (cout % 16 != 0), every swizzle class of the staged X rows
 (cin / 8 = 4, 8, 12, 16, 20 chunks), both k-step paths (cin = 160: pipelined; cin < 160: guarded), ViT-H sizes.
 Tolerances: f32 output 2e-5 of the output scale (f32 accumulation of <= 320 bf16 products), bf16 output 1e-2 (one
-rounding to 8 mantissa bits).  The ring kernel (octic_dbg_wreg_off) must agree with it to the same tolerances, and
+rounding to 8 mantissa bits).  The ring kernel (octic_route_override, OCTIC_ROUTE_LINEAR_RING) must agree with it to the same tolerances, and
 exactly where no bias is folded into the accumulator."""
 import pytest
 import torch
@@ -57,14 +57,14 @@ def _case(M, cin, cout, out_dt, fused, bias_on, seed=0):
     L = _lib.lib()
     try:
         for off in (0, 1):
-            L.octic_dbg_wreg_off(off)
+            _lib.route_override(_lib.ROUTE_LINEAR_RING, off)
             y = torch.full((M, 8 * cout), float("nan"), device=DEV, dtype=out_dt)
             ops.linear_fwd(ops.pview(x, cin), w, bias, ops.pview(y, cout), M, cin, cout, bf, out_dt, x,
                            resid_v=ops.pview(resid, cout) if fused else None, rs=rs, rps=rps, cs5=cs)
             torch.cuda.synchronize()
             outs[off] = y
     finally:
-        L.octic_dbg_wreg_off(0)
+        _lib.route_override(_lib.ROUTE_LINEAR_RING, 0)
     return outs, want
 
 

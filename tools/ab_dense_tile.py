@@ -10,14 +10,11 @@ from octic_vits_amd import _lib, ops
 
 _lib.lib()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-for f in (raw.octic_dbg_dense_tile, raw.octic_dbg_dense_split):
-    f.argtypes = [ctypes.c_int]
-    f.restype = None
 
 
 def setv(nt, split):
-    raw.octic_dbg_dense_tile(nt)
-    raw.octic_dbg_dense_split(split)
+    raw.octic_route_override(0, nt)
+    raw.octic_route_override(1, split)
     ops._DG_WS.clear()          # the workspace size depends on the split
 
 

@@ -7,8 +7,6 @@ from octic_vits_amd import _lib, ops  # noqa: E402
 
 L = _lib.lib()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-raw.octic_dbg_dense_wgrad_tile.argtypes = [ctypes.c_int]
-raw.octic_dbg_dense_wgrad_slabs.argtypes = [ctypes.c_int]
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--slabs", type=int, nargs="*", default=[0])
@@ -41,10 +39,10 @@ for N, K in ((5120, 1280), (1280, 5120), (3840, 1280), (1280, 1280)):
         line = []
         for width in (256, 320):
             for S in a.slabs:
-                raw.octic_dbg_dense_wgrad_tile(width)
-                raw.octic_dbg_dense_wgrad_slabs(S)
+                raw.octic_route_override(3, width)
+                raw.octic_route_override(2, S)
                 t = timeit(lambda: ops.dense_wgrad_tn(dy, x))
                 line.append(f"{width}{'/S' + str(S) if S else ''}: {t:6.1f} us ({2.0 * M * N * K / t / 1e6:5.0f} TF)")
         print(f"{N}x{K} round {r}: " + "   ".join(line), flush=True)
-raw.octic_dbg_dense_wgrad_tile(0)
-raw.octic_dbg_dense_wgrad_slabs(0)
+raw.octic_route_override(3, 0)
+raw.octic_route_override(2, 0)

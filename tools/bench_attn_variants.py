@@ -1,5 +1,5 @@
 """Developer A/B: attention forward/backward at the ViT-H shape for several builds of the library (OCTIC_LIBS=path,path)
-and a80 kernel variants (octic_dbg_a80_variant), each in its own process section."""
+and a80 kernel variants (octic_route_override, OCTIC_ROUTE_ATTN_ONLINE), each in its own process section."""
 import ctypes, os, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,8 +23,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     pk = (torch.randn(B, T, 3 * 8 * c, device="cuda") * 0.7).bfloat16()
     out = []
     for var in [int(x) for x in sys.argv[3].split(",")]:
-        if hasattr(raw, "octic_dbg_a80_variant"):
-            raw.octic_dbg_a80_variant(var)
+        if hasattr(raw, "octic_route_override"):
+            raw.octic_route_override(7, var)
         tf = min(timeit(lambda: ops.attn_fwd(q, k, v, hd ** -0.5)) for _ in range(3))
         tp = min(timeit(lambda: ops.attn_fwd_packed(pk, H, c, hd ** -0.5)) for _ in range(3))
         out.append(f"var{var}: fused-qkv {tf:6.1f} us  packed {tp:6.1f} us")

@@ -25,9 +25,9 @@ for (N, K) in [(5120, 1280), (1280, 5120), (3840, 1280), (1280, 1280)]:
     t_slab = timeit(lambda: OF._wgrad_lib(dy, xx))
     line = f"dW {N:5d}x{K:5d}: lib {t_lib:6.1f} us ({fl / t_lib / 1e6:5.0f} TF) | lib slabs {t_slab:6.1f} us ({fl / t_slab / 1e6:5.0f} TF) | mine"
     for S in sweep:
-        raw.octic_dbg_dense_wgrad_slabs(S)
+        raw.octic_route_override(2, S)
         ops._DW_WS.clear()
         t = timeit(lambda: ops.dense_wgrad_tn(dy, xx))
         line += f"  S={S or 'auto'}: {t:6.1f} ({fl / t / 1e6:5.0f})"
-    raw.octic_dbg_dense_wgrad_slabs(0)
+    raw.octic_route_override(2, 0)
     print(line, flush=True)

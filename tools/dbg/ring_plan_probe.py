@@ -10,7 +10,7 @@ x = torch.randn(M, 8 * cin, device="cuda").to(bf)
 w = [(torch.randn(cout, cin, device="cuda") * cin ** -0.5).to(bf) for _ in range(4)] + [(torch.randn(2 * cout, 2 * cin, device="cuda") * (2 * cin) ** -0.5).to(bf)]
 outs = []
 for off in (1, 0):
-    L.octic_dbg_ring_plan(off)
+    L.octic_route_override(5, off)
     y = torch.full((M, 8 * cout), float("nan"), device="cuda", dtype=bf)
     ops.linear_fwd(ops.pview(x, cin), w, None, ops.pview(y, cout), M, cin, cout, bf, bf, x)
     torch.cuda.synchronize()

@@ -33,7 +33,7 @@ for (N, K) in shapes:
         res = {n: [] for n in names}
         ws, dw = {}, {}
         for n, L in libs.items():
-            L.octic_dbg_dense_wgrad_slabs(S)
+            L.octic_route_override(2, S)
             ws[n] = torch.zeros(int(L.octic_dense_wgrad_workspace_bytes(M, N, K)), dtype=torch.uint8, device="cuda")
             dw[n] = torch.empty(N, K, device="cuda")
         def run(n):

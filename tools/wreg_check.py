@@ -1,5 +1,5 @@
 """Developer check + A/B: the W-stationary LinearD8 kernel (csrc/gemm_wreg.hip) against a torch f32 restatement and
-against the ring kernel (octic_dbg_wreg_off), over shapes with ragged row / column tails and every epilogue."""
+against the ring kernel (octic_route_override), over shapes with ragged row / column tails and every epilogue."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -67,7 +67,7 @@ def run(M, cin, cout, out_dt, fused, bias_on=True, time_it=False):
     want = ref_linear(x, w, bias, cin, cout, resid, cs, rs, rps)
     res = {}
     for off in (0, 1):
-        L.octic_dbg_wreg_off(off)
+        L.octic_route_override(4, off)
         y = torch.full((M, 8 * cout), float("nan"), device="cuda", dtype=out_dt)
         call = lambda: ops.linear_fwd(ops.pview(x, cin), w, bias, ops.pview(y, cout), M, cin, cout, bf, out_dt, x,
                                       resid_v=ops.pview(resid, cout) if fused else None, rs=rs, rps=rps, cs5=cs)
@@ -76,7 +76,7 @@ def run(M, cin, cout, out_dt, fused, bias_on=True, time_it=False):
         err = (y.float() - want).abs().max().item()
         t = timeit(call) if time_it else 0.0
         res[off] = (err, t, y.clone())
-    L.octic_dbg_wreg_off(0)
+    L.octic_route_override(4, 0)
     scale = want.abs().max().item()
     same = (res[0][2].float() - res[1][2].float()).abs().max().item()
     tag = f"M={M:6d} cin={cin:4d} cout={cout:4d} out={'bf16' if out_dt == bf else 'f32 '} fused={int(fused)}"
@@ -96,7 +96,7 @@ SHORT = (("qkv", 160, 480, bf, False), ("fc1", 160, 640, bf, False), ("proj+res"
          ("dgrad fc2", 160, 640, bf, False), ("proj bf16 res", 160, 160, bf, True))
 LONG = (("fc2+res", 640, 160, f32, True), ("dgrad fc1", 640, 160, bf, False), ("dgrad qkv", 480, 160, bf, False))
 if "--no-plan" in sys.argv:
-    L.octic_dbg_ring_plan(1)
+    L.octic_route_override(5, 1)
 for name, cin, cout, out_dt, fused in (LONG if "--long" in sys.argv else SHORT):
     ok = run(M, cin, cout, out_dt, fused, bias_on=name != "dgrad fc2", time_it=True) and ok
 print("ALL OK" if ok else "FAILED")
