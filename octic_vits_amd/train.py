@@ -252,8 +252,11 @@ class FusedLamb:
         for (lin, cache, wb, bb, _), wt in zip(self._shadows, self._wt):
             cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16, wt_copy=wt)
         if self._prep_source is not None:
-            from .functional import PrepBatch
-            self._prep_batch = PrepBatch(self._prep_source())
+            if self._prep_batch is None or self._prep_batch.stale():
+                # (a second prime() - after DDP's parameter broadcast - must refill the SAME buffers: graphs captured in
+                # between read their addresses)
+                from .functional import PrepBatch
+                self._prep_batch = PrepBatch(self._prep_source())
             self._prep_batch.run()
 
     def prepare_capture(self):

@@ -164,7 +164,9 @@ def _bwd_raw(q, k, v, o, do, lse, scale, fused):
     return dq, dk, dv
 
 
-@pytest.mark.parametrize("B,H", [(2, 3), (5, 16)])
+# (17, 16) and (40, 16): more (batch, head) units than the chip has CUs - the round-5 kernel is persistent over heads: chunks of
+# 1-2 and 2-3 heads per workgroup (the next head's V behind the last tiles, its K image and first tile behind the row stores)
+@pytest.mark.parametrize("B,H", [(2, 3), (5, 16), (17, 16), (40, 16)])
 def test_single_pass_backward_matches_fp64_and_the_two_kernel_path(B, H):
     """csrc/attn80_bwd.hip (round 4: P and dS once per tile pair, dQ as a fixed-order sum of eight per-wave partials,
     key 256 on the vector unit) against (a) float64 autograd of softmax attention on the same bf16 inputs - 3e-2 of the
@@ -220,3 +222,29 @@ def test_single_pass_backward_on_strided_fused_qkv_rows_and_spiky_scores():
         sc = max(1.0, float(want.abs().max()))
         err = float((got.double() - want).abs().max())
         assert err <= 3e-2 * sc, f"{name}: max err {err:.3e} (scale {sc:.3g})"
+
+
+def test_single_pass_backward_on_packed_rows_over_several_heads_per_workgroup():
+    """Packed LinearD8 rows with more units than CUs (24 x 16 = 384 heads: one or two per workgroup): the persistent
+    single-pass kernel against the dq + dkv pair (itself held to float64 above) on the same operands, and bitwise repeatable."""
+    from octic_vits_amd import functional as OF
+    from octic_vits_amd import ops
+    B, T, H = 24, 257, 16
+    c = 10 * H
+    g = torch.Generator().manual_seed(3)
+    qkv = (torch.randn(B, T, 3 * 8 * c, generator=g) * 0.7).to(torch.bfloat16).cuda().requires_grad_(True)
+    do = torch.randn(B, T, 8 * c, generator=g).to(torch.bfloat16).cuda()
+    o = OF.AttnPackedFn.apply(qkv, H, c, 80 ** -0.5)
+    old = ops.ATTN_BWD_FUSED
+    try:
+        ops.ATTN_BWD_FUSED = True
+        (g1,) = torch.autograd.grad(o, qkv, do, retain_graph=True)
+        (g1b,) = torch.autograd.grad(o, qkv, do, retain_graph=True)
+        ops.ATTN_BWD_FUSED = False
+        (g2,) = torch.autograd.grad(o, qkv, do, retain_graph=True)
+    finally:
+        ops.ATTN_BWD_FUSED = old
+    assert torch.equal(g1, g1b)
+    sc = float(g2.float().abs().max())
+    assert float((g1.float() - g2.float()).abs().max()) <= 2e-2 * sc
+    assert float((g1.float() - g2.float()).norm() / g2.float().norm()) < 6e-3
