@@ -68,7 +68,7 @@ constexpr int BW_PX = 2 * 2 * 32 * 4;             // p and dS of key 256 for the
 constexpr int BW_ACC = 160 * 4;                   // dK[256] | dV[256] running sums
 constexpr int BW_LDS = BW_RING + BW_KIMG + BW_DS + BW_PQ + BW_STAT + BW_XK + BW_PX + BW_ACC;
 static_assert(BW_LDS <= 160 * 1024, "LDS budget");
-static_assert(11 * TILE_B <= BW_RING, "the V way station of the next head sits in ring slots 3 .. 10");
+static_assert(8 * TILE_B <= BW_DS + BW_PQ, "the V image borrows the dS / quarter buffers during the prologue");
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
@@ -101,12 +101,12 @@ __device__ __forceinline__ const char* tile_chunk(const char* tile, int row, int
   return j < 8 ? tile + row * 128 + ((j ^ swz(row)) << 4) : tile + TAIL_OFF + row * 32 + (j - 8) * 16;
 }
 
-__global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
+__global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   constexpr int nt = BW_NT, W = WAVES, T = BW_T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
   char* const kimg = smem + BW_RING;
-  char* const dsb = kimg + BW_KIMG;                  // [2][8 waves][2 KiB] dS tiles
+  char* const dsb = kimg + BW_KIMG;                  // [2][8 waves][2 KiB] dS tiles (prologue: the V image, with pq)
   char* const pq = dsb + BW_DS;                      // [2][2 blocks][4 quarters][64 lanes] f32x4
   float* const lse_s = (float*)(pq + BW_PQ);
   float* const del_s = lse_s + 288;
@@ -114,25 +114,14 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
   float* const px = (float*)(xk + BW_XK);            // [2][p 32 | dS 32]
   float* const acc256 = px + 128;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned ldsK = lds0 + BW_RING;
+  const unsigned ldsK = lds0 + BW_RING, ldsV = ldsK + BW_KIMG;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
-  // Persistent over heads (round 5): workgroup -> a contiguous run of (batch, head) units, whole batches per XCD (neighbouring
-  // heads share cache lines in both layouts: 20-byte pieces of packed rows, 160-byte pieces of the fused projection).
-  const int G = gridDim.x, chunk = unit_of(blockIdx.x, G, true);
-  const int u0 = (int)((int64_t)chunk * units / G), u1 = (int)((int64_t)(chunk + 1) * units / G);
-  int64_t in_off, o_off, g_off, stat_off;
-  HeadMaps hm;
-  auto head_of = [&](int u, int64_t& in_, int64_t& o_, int64_t& g_, int64_t& st_, HeadMaps& m_) {
-    const int b = u / a.H, h = u - b * a.H;
-    in_ = b * a.sB + h * a.sH;
-    o_ = b * a.oB + h * a.oH;
-    g_ = b * a.gB + h * a.gH;
-    st_ = ((int64_t)b * a.H + h) * T;
-    m_ = head_maps(a, h);
-  };
-  head_of(u0, in_off, o_off, g_off, stat_off, hm);
+  const int bh = unit_of(blockIdx.x, gridDim.x, a.sH < a.sT), b = bh / a.H, h = bh - b * a.H;
+  const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH, g_off = b * a.gB + h * a.gH;
+  const int64_t stat_off = ((int64_t)b * a.H + h) * T;
+  const HeadMaps hm = head_maps(a, h);
 
 #ifdef A80_TRACE
   unsigned long long bwt_ph[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -144,8 +133,9 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
   LeanStager stq, sto;                               // rows of q / k / v (stride sT, block width cv_in) and of dO / O (oT, cv_out)
   stq.setup(wid, W, lane, a.sT, a.cv_in, nt, T);
   sto.setup(wid, W, lane, a.oT, a.cv_out, nt, T);
-  i32x4 rq = make_rs(a.q, in_off, a.sT, T, a.cv_in), rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
-  i32x4 ro = make_rs(a.o, o_off, a.oT, T, a.cv_out);
+  const i32x4 rq = make_rs(a.q, in_off, a.sT, T, a.cv_in), rk = make_rs(a.k, in_off, a.sT, T, a.cv_in);
+  const i32x4 rv = make_rs(a.v, in_off, a.sT, T, a.cv_in), rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
+  const i32x4 ro = make_rs(a.o, o_off, a.oT, T, a.cv_out);
   auto issue_tile = [&](int t) {                     // Q, dO, O rows of query tile t -> ring stage t % 4
     const int s3 = 3 * (t % BW_NSTG);
     stq.issue(t, lds0, rq, hm.q.bs, s3);
@@ -157,7 +147,7 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
   const int qq = 4 * wid + (lane >> 4), j16 = lane & 15;
   const bool jon = j16 < 10;
   const int jc = jon ? j16 : 9;
-  float* dl = a.delta + stat_off;                    // uniform base, 32-bit per-lane index
+  float* const dl = a.delta + stat_off;              // uniform base, 32-bit per-lane index
   // delta of tile t for query qq from the ring's dO and O tiles
   auto delta_of = [&](int t) {
     const char* st_ = ring + (t % BW_NSTG) * BW_STG;
@@ -237,35 +227,43 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
   };
 
   // ---------------------------------------------------------------------------------------------------- prologue
-  // What a head needs before its first MFMA: the K image, the V rows (as fragments in registers: the V image is only a
-  // way station and sits in ring stages 1-3, slots 3 .. 10) and ring tile 0 (stage 0).  For the FIRST head of a workgroup
-  // all of that is requested here; for every later head V streams in behind the last three tiles of the head before
-  // (ring stages that carry no tile any more), K and tile 0 are requested right after that head's last barrier and land
-  // while its dK / dV rows are stored.  Tiles 1 and 2 follow when the V way station has been read.
-  auto issue_kv0 = [&](const i32x4 rk_, const i32x4 rv_, bool with_v) {
+  // K image, V image (borrowing the dS / quarter buffers) and the first three ring tiles by LDS-DMA; rows 256 of K and V
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt) {
-      stq.issue(jt, ldsK, rk_, hm.k.bs);
-      if (with_v) stq.issue(jt, lds0, rv_, hm.v.bs, 3 + jt);
-    }
-    issue_tile(0);
-  };
-  auto load_stats = [&]() {                          // lse of the head, rows 256 of K and V
-    int ln = lane;
-    asm volatile("" : "+v"(ln));                     // per-lane addresses of this once-per-head code stay out of the tile loop's registers
-    const int td = wid * 64 + ln;
+  for (int jt = 0; jt < 8; ++jt) {
+    stq.issue(jt, ldsK, rk, hm.k.bs);
+    stq.issue(jt, ldsV, rv, hm.v.bs);
+  }
+  issue_tile(0);
+  issue_tile(1);
+  issue_tile(2);
+  {
     u32x4 xrow = {0, 0, 0, 0};
-    if (wid == 1 && ln < 10) xrow = hm_load16(a.k + in_off + (int64_t)256 * a.sT, ln, hm.k);
-    if (wid == 2 && ln < 10) xrow = hm_load16(a.v + in_off + (int64_t)256 * a.sT, ln, hm.v);
-    if (td < 288) lse_s[td] = td < T ? a.lse[stat_off + td] : INFINITY;   // padded queries: P = 0
-    if ((wid == 1 || wid == 2) && ln < 10) *(u32x4*)(xk + (wid - 1) * 160 + ln * 16) = xrow;
-  };
-  issue_kv0(make_rs(a.k, in_off, a.sT, T, a.cv_in), make_rs(a.v, in_off, a.sT, T, a.cv_in), true);
-  load_stats();
-  if (tid < 160) acc256[tid] = 0.f;
+    if (wid == 1 && lane < 10) xrow = hm_load16(a.k + in_off + (int64_t)256 * a.sT, lane, hm.k);
+    if (wid == 2 && lane < 10) xrow = hm_load16(a.v + in_off + (int64_t)256 * a.sT, lane, hm.v);
+    for (int t = tid; t < 288; t += 512) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
+    if (tid < 160) acc256[tid] = 0.f;
+    if ((wid == 1 || wid == 2) && lane < 10) *(u32x4*)(xk + (wid - 1) * 160 + lane * 16) = xrow;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // The V rows of the own key tile (B operand of dP) live in registers; the K rows (B operand of S') are re-read from the
+  // resident K image every tile (both in registers: 13-96 spilled VGPRs, and every scratch reload inside the tile loop is
+  // an `s_waitcnt vmcnt(0)`, i.e. a drain of the DMA queue)
+  bf16x8 vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) vf[ks] = rowfrag(dsb + wid * TILE_B, fa, ks);
+  const char* const kt_ = kimg + wid * TILE_B;
+  delta_of(0);
+  delta_of(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // the V image is dead; delta of tiles 0, 1 is visible
+  if (wid < 2) key256_a(0, wid);                     // (visible after the first tile's barrier)
 
+  BWT(0);
   f32x16 dkt[DT], dvt[DT];
-  bf16* dqb = a.dq + g_off;
+  zero_acc<DT>(dkt);
+  zero_acc<DT>(dvt);
+  bf16* const dqb = a.dq + g_off;
   const int gT = (int)a.gT;
 
   // ---- dQ^T = K^T dS^T in ten blocks of 16 d x 16 queries (block bi: d-block bi % 5, query block bi / 5).  Wave w owns
@@ -312,27 +310,6 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
   // phase (MI355X guide, "Two waves per SIMD", item 4): one static s_setprio 1 for waves 4-7, no per-phase flips
   if (wid >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
-  for (int u = u0; u < u1; ++u) {
-  const bool has_next = u + 1 < u1;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                      // [P1] K image, V way station, ring tile 0, statistics have landed
-  // The V rows of the own key tile (B operand of dP) live in registers; the K rows (B operand of S') are re-read from the
-  // resident K image every tile (both in registers: 13-96 spilled VGPRs, and every scratch reload inside the tile loop is
-  // an `s_waitcnt vmcnt(0)`, i.e. a drain of the DMA queue)
-  bf16x8 vf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) vf[ks] = rowfrag(ring + (3 + wid) * TILE_B, fa, ks);
-  const char* const kt_ = kimg + wid * TILE_B;
-  delta_of(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                      // [P2] the V way station is dead; delta of tile 0 is visible
-  issue_tile(1);
-  issue_tile(2);
-  if (wid < 2) key256_a(0, wid);                     // (visible after the first tile's barrier)
-  BWT(0);
-  zero_acc<DT>(dkt);
-  zero_acc<DT>(dvt);
-  pend = u32x2{0, 0};
   for (int t = 0; t < nt; ++t) {
     const char* qt_ = ring + (t % BW_NSTG) * BW_STG;
     const char* dt_ = qt_ + TILE_B;
@@ -378,16 +355,6 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
     BWT(7);
     store_pending(t - 1);
     if (t + 3 < nt) issue_tile(t + 3);
-    else if (has_next) {                             // the stage tile t - 1 leaves carries no tile any more: V of the next head
-      const int j0 = 3 * (t - (nt - 3));             // t = 6, 7, 8 -> V tiles 0-2, 3-5, 6-7 -> ring slots 3 + j
-      // (the next head's terms are recomputed here, three times per head, rather than kept in scalar registers over the loop)
-      const int nb = (u + 1) / a.H, nh = (u + 1) - nb * a.H;
-      const i32x4 nrv = make_rs(a.v, nb * a.sB + nh * a.sH, a.sT, T, a.cv_in);
-      const int nvbs = a.cv_in > 0 ? 2 * a.c + nh * (a.c / a.H) : 0;
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (j0 + j < 8) stq.issue(j0 + j, lds0, nrv, nvbs, 3 + j0 + j);
-    }
     BWT(8);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
@@ -423,11 +390,6 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
     BWT(5);
     // ---- row-wise work for later tiles: delta two tiles ahead; key 256: part A one tile ahead, part B for this tile
     if (t + 2 < nt) delta_of(t + 2);
-    if (t == 0) {                                    // tile 1 landed behind this tile's barrier (the prologue waits for tile 0
-      delta_of(1);                                   // only): its delta is due before the NEXT barrier, and part A of key 256
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // below reads it - one extra barrier per head
-      __builtin_amdgcn_s_barrier();
-    }
     {
       const int role = (wid - 2 * t) & 7;            // rotates over the waves: 0, 1 = part A (query block), 2..6 = part B (d-block)
       if (role < 2) { if (t + 1 < nt) key256_a(t + 1, role); }
@@ -440,37 +402,19 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a, int units) {
   store_pending(nt - 1);
 
   // ---------------------------------------------------------------------------------------------------- epilogue
-  // (every wave is past its last read of the K image, ring stage 0, the statistics and the key-256 rows of this head: the
-  // next head's requests go out first and land while the dK / dV rows below are stored)
-  const int64_t g_cur = g_off;
-  const HeadMaps hm_cur = hm;
-  if (has_next) {
-    head_of(u + 1, in_off, o_off, g_off, stat_off, hm);
-    rq = make_rs(a.q, in_off, a.sT, T, a.cv_in);
-    rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
-    ro = make_rs(a.o, o_off, a.oT, T, a.cv_out);
-    dl = a.delta + stat_off;
-    dqb = a.dq + g_off;
-    issue_kv0(make_rs(a.k, in_off, a.sT, T, a.cv_in), rq, false);
-    load_stats();
-  }
   {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int ki = wid * 32 + (ln & 31), hf = ln >> 5, td = wid * 64 + ln;
-    store_rows16(a.dk + g_cur + (int64_t)ki * a.gT, dkt, a.scale, hf, hm_cur.k);
-    store_rows16(a.dv + g_cur + (int64_t)ki * a.gT, dvt, 1.0f, hf, hm_cur.v);
-    if (td < 160) {                                  // dK[256] | dV[256] (acc256: one wave per d-block and tile, in tile order)
-      const bool isv = td >= 80;
-      const int e = isv ? td - 80 : td;
-      bf16* row = (isv ? a.dv : a.dk) + g_cur + (int64_t)256 * a.gT;
-      row[hm_elem(e, isv ? hm_cur.v : hm_cur.k)] = (bf16)(isv ? acc256[td] : acc256[td] * a.scale);
-      acc256[td] = 0.f;
-    }
+    const int ki = wid * 32 + r;
+    store_rows16(a.dk + g_off + (int64_t)ki * a.gT, dkt, a.scale, half, hm.k);
+    store_rows16(a.dv + g_off + (int64_t)ki * a.gT, dvt, 1.0f, half, hm.v);
   }
-  BWT(9);
-  }   // heads of this workgroup
+  if (tid < 160) {                                   // dK[256] | dV[256] (acc256: one wave per d-block and tile, in tile order)
+    const bool isv = tid >= 80;
+    const int e = isv ? tid - 80 : tid;
+    bf16* row = (isv ? a.dv : a.dk) + g_off + (int64_t)256 * a.gT;
+    row[hm_elem(e, isv ? hm.v : hm.k)] = (bf16)(isv ? acc256[tid] : acc256[tid] * a.scale);
+  }
 #ifdef A80_TRACE
+  BWT(9);
   bwt_ph[10] = bwt_last - bwt_t0;
   if (lane == 0 && blockIdx.x < 1024) {
 #pragma unroll
@@ -497,8 +441,7 @@ int attn80_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
   }
-  const int units = (int)(B * a.H), cus = device_cus();
-  bwd_kernel<<<units < cus ? units : cus, 512, BW_LDS, s>>>(a, units);
+  bwd_kernel<<<(int)(B * a.H), 512, BW_LDS, s>>>(a);
   return launch_status();
 }
 
