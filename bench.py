@@ -116,6 +116,36 @@ def step_variants(trainer, model, samples, targets, args, n=8):
             out["compact_drop_path_error"] = f"{type(e).__name__}: {e}"[:300]
         finally:
             _L.COMPACT_DROP_PATH = False
+    # What a concurrent gradient all-reduce would do to this step, as far as ONE GPU can tell (train.DdpTrafficProxy): the eager
+    # step under DistributedDataParallel on a one-rank group, its bucket hooks (a) reporting the buckets as reduced at once and
+    # (b) first moving every bucket's bytes device-to-device on a side stream - 1.42 GB per step in 48 MB pieces (0.71 GB with
+    # --bf16-buckets), twice each (a ring all-reduce over 8 GPUs reads and writes ~1.75 x the payload per GPU).
+    try:
+        import torch.distributed as dist
+        from octic_vits_amd.train import DdpTrafficProxy
+        made = not dist.is_initialized()
+        if made:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        try:
+            for key, copies in (("ddp_hooks_ms_per_step", 0), ("ddp_proxy_ms_per_step", 2)):
+                proxy = DdpTrafficProxy(samples.device, copies=copies, halve=args.bf16_buckets)
+                tp = Trainer(model, distributed=True, local_rank=samples.device.index or 0, ddp_proxy=proxy,
+                             **({} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}))
+                ms, host = timed(tp)
+                out[key] = round(ms, 3)
+                if copies:
+                    out["ddp_proxy_gb_per_step"] = round(proxy.bytes / (n + 2) / 1e9, 3)
+                del tp, proxy
+            out["ddp_proxy_note"] = ("one GPU, one-rank group: DDP bucket hooks + a side stream copying each gradient bucket "
+                                     "device-to-device twice (ring all-reduce traffic per GPU); prices HBM / fabric contention "
+                                     "and the exposed last bucket only - no xGMI, no RCCL kernels, no rank skew")
+        finally:
+            if made:
+                dist.destroy_process_group()
+    except Exception as e:
+        out["ddp_proxy_error"] = f"{type(e).__name__}: {e}"[:300]
     del trainer
     try:
         seg = Trainer(model, segment_graphs=8)       # (re-links the blocks inside the slices: keep this last)

@@ -72,6 +72,9 @@ def _pool_usable():
 
 def _drop_path_mask(B, drop_prob, device, scale_by_keep=True):
     keep = 1.0 - drop_prob
+    if torch.compiler.is_compiling():                # traced (torch.compile): an in-graph draw, no Python-side pool
+        m = torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep)
+        return m / keep if (keep > 0.0 and scale_by_keep) else m
     if drop_path_mask_source is not None or not _pool_usable():
         if drop_path_mask_source is not None:
             m = drop_path_mask_source(B, keep, device)
@@ -306,6 +309,12 @@ class LinearD8(nn.Module):
         dtype = compute_dtype(xp)
         rps = xp.shape[-2] if xp.dim() >= 2 else 1
         cs5 = (None,) * 5 if cs is None else tuple(cs)
+        if torch.compiler.is_compiling():
+            # being traced: the same kernels through the dispatcher (dispatch.py), no Python-side weight cache
+            from . import dispatch as _D   # noqa: F401
+            xq = xp if xp.dtype == dtype else xp.to(dtype)
+            y = torch.ops.octic.linear_d8(xq, *self.weights(), self.lin_A1.bias, resid, rs, *cs5, cin, cout, rps)
+            return Octic(y, cout) if next_norm is None else (Octic(y, cout), None)
         if (next_norm is not None and resid is not None and OF.OCTIC_NEXT_NORM and xp.is_cuda and dtype == torch.bfloat16
                 and resid.dtype == torch.float32 and type(next_norm) is LayerNormD8):
             a, beta = next_norm.affine()
@@ -386,6 +395,10 @@ class LayerNormD8(nn.Module):
         xp, c = as_packed(xs)
         out_dtype = _out_dtype or xp.dtype
         a, beta = self.affine()
+        if torch.compiler.is_compiling():
+            from . import dispatch as _D   # noqa: F401
+            y = torch.ops.octic.layernorm_d8(xp, *a, beta, self.eps, c, out_dtype == torch.bfloat16)[0]
+            return (Octic(y, c), xp) if _with_resid else Octic(y, c)
         y, xres = OF.LayerNormD8Fn.apply(xp, *a, beta, self.eps, c, out_dtype)
         # _with_resid: also hand back the stream to take the residual from (its cotangent is then folded into this
         # node's backward kernel)
@@ -554,6 +567,10 @@ class LiftD8(nn.Module):
     def tokens(self, img, pos=None, cls_row=None):
         """Packed tokens [B, (1+)G*G, 8c] f32 (+ unfolded positional embedding and cls row, fused)."""
         p = self.conv_A1.kernel_size[0]
+        if torch.compiler.is_compiling():
+            from . import dispatch as _D   # noqa: F401
+            return torch.ops.octic.lift(img, self.packed_weight(), self.packed_bias(), pos, cls_row, p,
+                                        compute_dtype(img) == torch.bfloat16)[0]
         return OF.LiftFn.apply(img, self.packed_weight(), self.packed_bias(), pos, cls_row, p, compute_dtype(img))
 
     def forward(self, img):
@@ -679,7 +696,11 @@ class AttentionD8(nn.Module):
         if (OF.ATTN_PACKED and drop == 0. and qkv.packed.is_cuda
                 and OF.ops.attn_packed_ok(qkv.packed.shape[1], c, self.num_heads, qkv.packed.dtype)):
             # head split, softmax core and irrep re-assembly in the attention kernels themselves (head_dim 80)
-            on = Octic(OF.AttnPackedFn.apply(qkv.packed, self.num_heads, c, (8 * c // self.num_heads) ** -0.5), c)
+            if torch.compiler.is_compiling():
+                from . import dispatch as _D   # noqa: F401
+                on = Octic(torch.ops.octic.attn_packed(qkv.packed, self.num_heads, c, (8 * c // self.num_heads) ** -0.5)[0], c)
+            else:
+                on = Octic(OF.AttnPackedFn.apply(qkv.packed, self.num_heads, c, (8 * c // self.num_heads) ** -0.5), c)
         else:
             q, k, v = OF.PackHeadsFn.apply(qkv.packed, self.num_heads, c)
             # HIP attention core for the shapes it covers (bf16, T <= 320, no dropout); torch SDPA (== self.att) otherwise
@@ -756,7 +777,8 @@ class Layer_scale_init_BlockD8(nn.Module):
         if compact_active(self.drop_path) and xp.dtype == torch.float32:
             x1 = _branch_compact(self.norm1, self.attn, xp, c, self.drop_path, self.gamma_1.alphas(), dt)
             return _branch_compact(self.norm2, self.mlp, x1.packed, c, self.drop_path, self.gamma_2.alphas(), dt)
-        if not (OF.OCTIC_NEXT_NORM and xp.is_cuda and dt == torch.bfloat16 and type(self.norm2) is LayerNormD8):
+        if torch.compiler.is_compiling() or not (OF.OCTIC_NEXT_NORM and xp.is_cuda and dt == torch.bfloat16
+                                                 and type(self.norm2) is LayerNormD8):
             x1 = _branch(self.norm1, self.attn, xp, c, self._mask(xp.shape[0], xp.device), self.gamma_1.alphas(), dt)
             return _branch(self.norm2, self.mlp, x1.packed, c, self._mask(xp.shape[0], xp.device), self.gamma_2.alphas(), dt)
         # norm2 comes out of the attention branch's last layer, norm1 of the NEXT block (link_octic_blocks) out of the

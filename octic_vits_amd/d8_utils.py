@@ -258,6 +258,7 @@ def expand_lift_kernel(weight, irrep):
 _LIFT_BLOCKS = ((0, "A1", 0), (1, "A2", 0), (2, "B1", 0), (3, "B2", 0), (4, "E", 0), (5, "E", 0), (4, "E", 1), (5, "E", 1))
 
 
+@torch.compiler.disable          # index tables built once per shape with nonzero / bincount: not for Dynamo to trace
 @lru_cache(maxsize=None)
 def _lift_tables_on(O: int, Cin: int, h: int, device: str, dtype):
     with torch.inference_mode(False):
@@ -327,6 +328,7 @@ def isotypic_dim_interpolation(xs, dim: int = 0):
             el, el.rot90(dims=(d0, d1)), er, er.rot90(dims=(d0, d1)))
 
 
+@torch.compiler.disable          # index tables built once per shape with nonzero / bincount: not for Dynamo to trace
 @lru_cache(maxsize=None)
 def _pos_tables_on(h: int, device: str, dtype):
     """Row tables of packed_pos_embed: output row block b (A1|A2|B1|B2|E_left|E_right|rot E_left|rot E_right) x grid

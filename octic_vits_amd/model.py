@@ -131,7 +131,11 @@ class OcticVisionTransformer(nn.Module):
         if self.invariant:
             x = self.invariant_proj(self.invariantization(xs, _out_dtype=dt))
         else:
-            x = OF.HandoffCatFn.apply(xs.packed, c, xs.packed.dtype)
+            if torch.compiler.is_compiling():
+                from . import dispatch as _D   # noqa: F401
+                x = torch.ops.octic.handoff_cat(xs.packed, c, xs.packed.dtype == torch.bfloat16)
+            else:
+                x = OF.HandoffCatFn.apply(xs.packed, c, xs.packed.dtype)
         for blk in self.blocks[self.octic_equi_break_layer:]:
             x = blk(x)
         if self.global_pool:

@@ -538,6 +538,41 @@ class SegmentedModel(nn.Module):
         return self
 
 
+class DdpTrafficProxy:
+    """A one-GPU stand-in for what the gradient all-reduce of an N-GPU step does to the step (round-4 review item 5): a DDP
+    communication hook that, for every gradient bucket that becomes ready during the backward pass, moves the bucket's bytes
+    device-to-device on a SIDE stream (`copies` times; a ring all-reduce over 8 GPUs reads and writes about 1.75 x the bucket
+    on each GPU) and reports the bucket as reduced.  The optimizer waits for the side stream (`join`), as it would for the last
+    bucket's collective.  This prices two things a single GPU can measure - HBM / fabric contention between a concurrent
+    byte-moving stream and the backward kernels (the dense GEMMs re-read their operand panels 3.4-3.6 x through the fabric),
+    and the exposed tail of the last bucket - and nothing else: no xGMI link, no RCCL kernel occupancy, no cross-rank skew.
+    ``copies = 0`` gives the no-traffic baseline with the same hooks."""
+
+    def __init__(self, device, copies=1, halve=False):
+        self.stream = torch.cuda.Stream(device)
+        self.copies, self.halve = int(copies), bool(halve)
+        self.scratch = None
+        self.bytes = 0                                  # bytes read (= bytes written) by the side stream so far
+
+    def hook(self, state, bucket):
+        buf = bucket.buffer()
+        n = buf.numel() // 2 if self.halve else buf.numel()     # bf16 buckets: half the payload
+        if self.copies > 0 and n > 0:
+            if self.scratch is None or self.scratch.numel() < n:
+                self.scratch = torch.empty(n, dtype=buf.dtype, device=buf.device)
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for _ in range(self.copies):
+                    self.scratch[:n].copy_(buf[:n], non_blocking=True)
+            self.bytes += n * buf.element_size() * self.copies
+        fut = torch.futures.Future()
+        fut.set_result(buf)
+        return fut
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class _LossWatch:
     """The non-finite-loss check of deit/engine.py:67-71 without a per-step stream drain.
 
@@ -607,7 +642,7 @@ class Trainer:
 
     def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
                  fused_optimizer=True, tuned_gemms=True, opt_eps=1e-8, accum_steps=1, bf16_buckets=False,
-                 autocast=True, check_every=1, device_type=None, bucket_cap_mb=None, segment_graphs=0):
+                 autocast=True, check_every=1, device_type=None, bucket_cap_mb=None, segment_graphs=0, ddp_proxy=None):
         """segment_graphs = n > 0 (GPU only): forward and backward run as 2 n hipGraph replays (``SegmentedModel``), the
         loss, the gradient all-reduce hooks and the optimizer stay eager - the cheap-on-the-host step for N > 1 GPUs and
         for gradient accumulation, where the whole-step graph of ``capture`` does not apply."""
@@ -623,6 +658,7 @@ class Trainer:
         self.check_every = max(1, int(check_every))
         self._steps = 0
         self._ddp_args = None
+        self._proxy = ddp_proxy                         # a DdpTrafficProxy: its hook replaces the all-reduce (measurement only)
         if distributed:
             self._ddp_args = (local_rank, bucket_cap_mb, bf16_buckets)
             # With segment graphs the slices are captured FIRST and wrapped in DistributedDataParallel afterwards
@@ -650,7 +686,9 @@ class Trainer:
             self.model, device_ids=[local_rank] if self.device_type == "cuda" else None,
             bucket_cap_mb=bucket_cap_mb or DDP_BUCKET_MB,
             gradient_as_bucket_view=True, find_unused_parameters=False, static_graph=False)
-        if bf16_buckets:
+        if self._proxy is not None:
+            self.model.register_comm_hook(None, self._proxy.hook)
+        elif bf16_buckets:
             from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
             self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
 
@@ -739,6 +777,8 @@ class Trainer:
                     li = self._forward_loss(x, y) / len(xs)
                     li.backward()
                 loss = li.detach() if loss is None else loss + li.detach()
+        if self._proxy is not None:
+            self._proxy.join()                          # the optimizer reads the "reduced" buckets
         self.optimizer.step()
         if self.ema is not None:
             self.ema.update(self.raw_model)

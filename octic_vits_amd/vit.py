@@ -133,7 +133,7 @@ def _drop_path_scale(dp, x):
     if not isinstance(dp, DropPath) or dp.drop_prob == 0. or not dp.training:
         return None
     from . import d8_layers as _L
-    if x.dtype == torch.float32 and _L._pool_armed:       # the pooled draw (one launch pair per 64 masks)
+    if x.dtype == torch.float32 and _L._pool_armed and not torch.compiler.is_compiling():   # the pooled draw (one launch pair per 64 masks)
         return _L._drop_path_mask(x.shape[0], dp.drop_prob, x.device, dp.scale_by_keep)
     keep = 1 - dp.drop_prob
     mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
@@ -164,6 +164,8 @@ def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2, next_norm
             return None
     dt = torch.bfloat16
     from . import d8_layers as _L
+    if torch.compiler.is_compiling():
+        return _traced_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2)
     if _L.compact_active(dp1) and _L.compact_active(dp2):
         # stochastic depth as batch compaction (d8_layers.COMPACT_DROP_PATH): each branch on the samples its mask keeps
         for norm, branch, gamma, dp in ((norm1, attn, gamma1, dp1), (norm2, mlp, gamma2, dp2)):
@@ -197,6 +199,25 @@ def _fused_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2, next_norm
             out._octic_prenorm = (next_norm, yn, out._version)
         return out
     return mlp.forward_fused(y, xres, gamma2, _drop_path_scale(dp2, x), dt)
+
+
+def _traced_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2):
+    """The same block through the dispatcher ops of dispatch.py (torch.compile is tracing): eight custom ops + two in-graph
+    mask draws, no Python-side state (weight caches, carried next-norm) - one graph per block."""
+    from . import dispatch as _D   # noqa: F401
+    o = torch.ops.octic
+    B, N, C = x.shape
+    H = attn.num_heads
+    hd = C // H
+    y = o.dense_layernorm(x, norm1.weight, norm1.bias, norm1.eps, True)[0]
+    qkv = o.dense_linear(y, attn.qkv.weight, attn.qkv.bias, False)[0]
+    a = o.attn_qkv(qkv.view(B, N, 3, H, hd), hd ** -0.5)[0]
+    p = o.dense_linear(a, attn.proj.weight, attn.proj.bias, False)[0]
+    x = o.scale_residual(x, p, gamma1, _drop_path_scale(dp1, x), N)
+    y = o.dense_layernorm(x, norm2.weight, norm2.bias, norm2.eps, True)[0]
+    h = o.dense_linear(y, mlp.fc1.weight, mlp.fc1.bias, True)[0]
+    f = o.dense_linear(h, mlp.fc2.weight, mlp.fc2.bias, False)[0]
+    return o.scale_residual(x, f, gamma2, _drop_path_scale(dp2, x), N)
 
 
 def link_blocks(blocks):

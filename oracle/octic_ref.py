@@ -336,13 +336,25 @@ class MlpD8(nn.Module):
         return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(xs))))))
 
 
+# test hook: callable (B, keep_prob) -> 0/1 mask [B] (float).  None = the reference's own draw.  Lets a test run the oracle on
+# CHUNKS of a batch with the rows of the masks the whole batch would have drawn (tests/test_vith_gpu.py, batch 64).
+drop_path_mask_source = None
+
+
+def _draw_mask(x, keep):
+    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    if drop_path_mask_source is not None:
+        return drop_path_mask_source(x.shape[0], keep).to(x.dtype).reshape(shape).clone()
+    return x.new_empty(shape).bernoulli_(keep)
+
+
 def drop_path_d8(xs, drop_prob: float = 0.0, training: bool = False, scale_by_keep: bool = True):
     """d8_layers.py:249-271: ONE Bernoulli mask per sample shared by all five tensors.  The mask is
     drawn with the same call (``new_empty(B,1,1).bernoulli_``) so a seeded run reproduces the reference."""
     if drop_prob == 0.0 or not training:
         return xs
     keep = 1 - drop_prob
-    mask = xs[0].new_empty((xs[0].shape[0],) + (1,) * (xs[0].ndim - 1)).bernoulli_(keep)
+    mask = _draw_mask(xs[0], keep)
     if keep > 0.0 and scale_by_keep:
         mask.div_(keep)
     return tuple(x * mask for x in xs[:4]) + (xs[4] * mask.unsqueeze(-1),)
@@ -717,7 +729,7 @@ class DropPath(nn.Module):
         if self.drop_prob == 0.0 or not self.training:
             return x
         keep = 1 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        mask = _draw_mask(x, keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
         return x * mask

@@ -97,3 +97,126 @@ def test_hybrid_vit_forward_f32_and_bf16_gradients_match_the_oracle(name, drop_p
     bad = [w for w in worst if w[0] > 1.0]
     assert not bad, f"{name} (drop_path {drop_path}) bf16 gradients beyond max(3e-2, 2 x oracle-under-bf16): " + \
         "; ".join(f"{n}: {r:.4f} (oracle {ro:.4f})" for _, n, r, ro in bad[:8])
+
+
+# --------------------------------------------------------------------------------------- the bench's batch, as one model step
+def _predrawn_masks(n_masks, B, keep, seed):
+    """The masks a full-batch reference run would draw from the CPU stream: new_empty(B,1,1).bernoulli_(keep), one per
+    residual branch in block order (octic_vits/d8_layers.py:256-262, deit/vit.py DropPath)."""
+    torch.manual_seed(seed)
+    return [torch.empty((B, 1, 1)).bernoulli_(keep).flatten() for _ in range(n_masks)]
+
+
+@pytest.mark.timeout(2400)
+def test_hybrid_vit_huge_train_step_at_the_bench_batch_matches_the_oracle():
+    """BASELINE configs[1] as ONE model step (round-4 review item 7): hybrid_deit_huge_patch14, batch 64, drop_path 0.5 with
+    the reference's mask stream, bf16 autocast, BCE on multi-hot targets (deit/engine.py:43-66): the loss of the step and a
+    strided sample of the 982 parameter gradients against the CPU oracle.  The oracle runs the SAME 64 images in chunks of
+    eight (images are independent given their rows of the per-branch masks; the loss is a mean, so gradients add) - memory of
+    eight images instead of sixty-four.  Tolerance per tensor: max(3e-2, 2 x the oracle's own distance under CPU bf16 autocast),
+    that yardstick measured on the first chunk (eight images: relative rounding noise does not shrink when fewer images are
+    averaged, so the bound is not tighter than the 64-image one would be... and not needed beyond a handful of tensors)."""
+    import octic_vits_amd.d8_layers as L
+    from oracle import octic_ref as R
+    from octic_vits_amd.train import synthetic_batch
+    name, B, CH, keep = "hybrid_deit_huge_patch14", 64, 8, 0.5
+    ref, net = _models(name, 0.5)
+    img, tgt = synthetic_batch(B, 1000, "cpu", 4242)
+    masks = _predrawn_masks(64, B, keep, seed=99)            # 32 blocks x 2 branches
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    crit = torch.nn.BCEWithLogitsLoss(reduction="sum")
+    names = [n for n, p in ref.named_parameters() if p.requires_grad]
+    sample = sorted(set(names[::17] + [n for n in names if n.startswith(("pos_embed", "cls_token.0", "head.", "norm."))]))
+    params = dict(ref.named_parameters())
+
+    def oracle_pass(lo, hi, autocast):
+        it = iter(masks)
+        R.drop_path_mask_source = lambda b, k: next(it)[lo:hi]
+        try:
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    out = ref(img[lo:hi])
+            else:
+                out = ref(img[lo:hi])
+            loss = crit(out.float(), tgt[lo:hi]) / (B * 1000)
+            loss.backward()
+        finally:
+            R.drop_path_mask_source = None
+        return float(loss.detach())
+
+    grab = lambda: {n: params[n].grad.detach().double().numpy().copy() for n in sample}
+    ref.train()
+    # yardstick on the first chunk: f32 vs CPU bf16 autocast
+    oracle_pass(0, CH, True)
+    g_bf = grab()
+    for p in ref.parameters():
+        p.grad = None
+    loss_ref = oracle_pass(0, CH, False)
+    g_c0 = grab()
+    yard = {n: float(np.linalg.norm(g_bf[n] - g_c0[n])) / max(float(np.linalg.norm(g_c0[n])), 1e-12) for n in sample}
+    for lo in range(CH, B, CH):                              # gradients accumulate over the chunks
+        loss_ref += oracle_pass(lo, lo + CH, False)
+    g_ref = grab()
+
+    # the product: one bf16-autocast step on all 64 images with the same masks
+    it = iter(masks)
+    L.drop_path_mask_source = lambda b, k, device: next(it).to(device)
+    try:
+        net.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(img.cuda())
+        loss = torch.nn.BCEWithLogitsLoss()(out.float(), tgt.cuda())
+        loss.backward()
+    finally:
+        L.drop_path_mask_source = None
+    got = dict(net.named_parameters())
+    assert abs(float(loss.detach()) - loss_ref) <= 2e-3 * abs(loss_ref), (float(loss.detach()), loss_ref)
+    bad = []
+    for n in sample:
+        w = g_ref[n]
+        den = max(float(np.linalg.norm(w)), 1e-12)
+        rel = float(np.linalg.norm(got[n].grad.detach().float().cpu().double().numpy() - w)) / den
+        lim = max(3e-2, 2.0 * yard[n])
+        if rel > lim:
+            bad.append((rel / lim, n, rel, yard[n]))
+    bad.sort(reverse=True)
+    assert not bad, "batch-64 bf16 gradients beyond max(3e-2, 2 x oracle-under-bf16): " + \
+        "; ".join(f"{n}: {r:.4f} (yard {y:.4f})" for _, n, r, y in bad[:8])
+
+
+@pytest.mark.timeout(1200)
+def test_hybrid_vit_huge_captured_step_equals_eager_bitwise_at_the_bench_batch():
+    """The bench's timed object - Trainer.capture of the ViT-H step at batch 64, drop_path 0.5 - against eager launches of
+    the same steps: same losses, same weights, same EMA, bit for bit (fixed-order reductions everywhere; the drop-path masks
+    of both come from the device generator seeded alike)."""
+    from octic_vits_amd.deit_models import create_model
+    from octic_vits_amd.train import Trainer, synthetic_batch
+
+    def make():
+        torch.manual_seed(11)
+        return create_model("hybrid_deit_huge_patch14", num_classes=1000, drop_path_rate=0.5, img_size=224).cuda()
+
+    ta, tb = Trainer(make()), Trainer(make())
+    batches = [synthetic_batch(64, 1000, "cuda", 300 + i) for i in range(3)]
+    def seed(k):                                    # the drop-path masks come from the device generator
+        torch.manual_seed(k)
+        torch.cuda.manual_seed(k)
+
+    seed(3)
+    gs = tb.capture(*batches[0], warmup=1)          # one eager step on batch 0, then the capture
+    seed(3)
+    ta.step(*batches[0])                            # the same step (same masks) for the eager trainer
+    torch.cuda.synchronize()
+    # both trainers have taken one step on batch 0; from here the same seed drives the masks of both
+    la, lb = [], []
+    seed(5)
+    for x, y in batches[1:] + batches[:1]:
+        la.append(float(ta.step(x, y).detach()))
+    seed(5)
+    for x, y in batches[1:] + batches[:1]:
+        lb.append(float(gs.replay(x, y)))
+    assert la == lb, (la, lb)
+    for (n, pa), pb in zip(ta.raw_model.named_parameters(), tb.raw_model.parameters()):
+        assert torch.equal(pa, pb), n
+    for ea, eb in zip(ta.optimizer.ema_state(), tb.optimizer.ema_state()):
+        assert torch.equal(ea, eb)
