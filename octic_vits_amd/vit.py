@@ -294,6 +294,7 @@ class Block(nn.Module):
         return x
 
 
+SUBSET_FUSED = True             # developer A/B: False = the eager composition of drop_add_residual_stochastic_depth
 MemEffAttention = Attention     # dinov2.layers.MemEffAttention: same parameters; the HIP core replaces xformers
 
 
@@ -325,8 +326,49 @@ class NestedTensorBlock(Block):
             self.mlp.fc2.bias = None
         self.sample_drop_ratio = drop_path
 
+    def _subset_fused(self, x):
+        """Both branches of ``drop_add_residual_stochastic_depth`` on the engine (bf16 autocast, GPU): the residual branch runs
+        on the random batch subset through the same fused kernels as a full-batch block - rows gathered, LayerNorm -> qkv ->
+        attention -> proj (or fc1 + GELU -> fc2) with ``x_subset + (b / keep) * gamma * f`` in the branch's tail, rows written
+        back - instead of the eager composition (ATen LayerNorm, library GEMMs, layer-scale multiply, index_add).  The subsets
+        are drawn exactly like the reference draws them (one randperm per branch, dinov2/layers/block.py:121-123), so a
+        seeded run picks the same samples as the eager path.  None when the block is not in that regime."""
+        if not (x.is_cuda and x.ndim == 3 and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not torch.compiler.is_compiling()):
+            return None
+        d = x.shape[-1]
+        for n in (self.norm1, self.norm2):
+            if type(n) is not nn.LayerNorm or tuple(n.normalized_shape) != (d,) or d % 4 or d > 2048:
+                return None
+        if not (isinstance(self.attn, Attention) and isinstance(self.mlp, Mlp)
+                and self.attn.fusable(x.shape[1], torch.bfloat16) and self.mlp.fusable()):
+            return None
+        gammas = []
+        for ls in (self.ls1, self.ls2):
+            if isinstance(ls, nn.Identity):
+                gammas.append(None)
+            elif isinstance(ls, LayerScale) and not ls.inplace:
+                gammas.append(ls.gamma)
+            else:
+                return None
+        from . import d8_layers as _L
+        b = x.shape[0]
+        keep = max(int(b * (1 - self.sample_drop_ratio)), 1)
+        x = x.clone()               # the reference's index_add is out of place: the caller's tensor stays what it was
+        for norm, branch, gamma in ((self.norm1, self.attn, gammas[0]), (self.norm2, self.mlp, gammas[1])):
+            idx = torch.randperm(b, device=x.device)[:keep]
+            link = _L._RowLink()
+            xa = _L._GatherRowsFn.apply(x, idx, link)
+            y, xres = _OF.DenseLayerNormFn.apply(xa, norm.weight, norm.bias, norm.eps, torch.bfloat16)
+            out = branch.forward_fused(y, xres, gamma, _L._const_scale(keep, b / keep, x.device), torch.bfloat16)
+            x = _L._ScatterRowsFn.apply(x, idx, out, link)
+        return x
+
     def _one(self, x):
         if self.training and self.sample_drop_ratio > 0.1:
+            out = self._subset_fused(x) if SUBSET_FUSED else None
+            if out is not None:
+                return out
             x = drop_add_residual_stochastic_depth(x, lambda t: self.ls1(self.attn(self.norm1(t))), self.sample_drop_ratio)
             return drop_add_residual_stochastic_depth(x, lambda t: self.ls2(self.mlp(self.norm2(t))),
                                                       self.sample_drop_ratio)
