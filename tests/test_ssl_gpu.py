@@ -171,7 +171,12 @@ def test_ssl_step_hybrid_vit_huge_multicrop():
     from octic_vits_amd.dinov2_models import hybrid_dinov2_vit_huge_patch16
     torch.manual_seed(0)
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    ref = SR.SSLMetaArch(lambda: R.hybrid_dinov2_vit_huge_patch16(img_size=224, drop_path_rate=0.0), 1280)
+    def oracle_backbone():
+        m = R.hybrid_dinov2_vit_huge_patch16(img_size=224, drop_path_rate=0.0)
+        m.patch_embed.strict_img_size = False            # (the 96 x 96 local crops: see ssl.SSLMetaArch)
+        return m
+
+    ref = SR.SSLMetaArch(oracle_backbone, 1280)
     cases.fill_parameters(ref.student, salt="sslh.")
     for k in ref.student:
         ref.teacher[k].load_state_dict(ref.student[k].state_dict())
