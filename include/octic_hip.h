@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 14
+#define OCTIC_ABI_VERSION 15
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -317,6 +317,15 @@ int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const*
                     const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
                     float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
                     void* stream);
+/* The same fused step WITHOUT the layer-wise trust ratio: AdamW with decoupled weight decay, p -= lr (mhat / (sqrt(vhat) +
+ * eps) + wd p) - torch.optim.AdamW as the DINOv2 recipe builds it (dinov2/train/train.py:60-61), with clip_grad_norm_ of the
+ * tensors of this call to max_grad_norm (train.py:274-279: one call per sub-model) and the teacher's EMA (`ema` = the
+ * teacher's parameters, ema_decay = the momentum of the step: ssl_meta_arch.py:356-367) in the same two passes.           */
+int octic_adamw_step(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
+                     const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
+                     const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
+                     float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
+                     void* stream);
 
 /* ---- standard (non-equivariant) half of the hybrid: row kernels around the library GEMMs ----------------
  * The reference's standard blocks (deit/models_v2.py Layer_scale_init_Block, used for the second half of the

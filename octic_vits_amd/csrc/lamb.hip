@@ -138,9 +138,13 @@ __global__ __launch_bounds__(256) void lamb_stage1_kernel(LambTables t, const fl
 }
 
 __global__ __launch_bounds__(256) void lamb_ratio_kernel(LambTables t, int ntensors, const float* part_p2,
-                                                         const float* part_u2, float* ratio) {
+                                                         const float* part_u2, float* ratio, int adam) {
   const int ti = blockIdx.x * 256 + threadIdx.x;
   if (ti >= ntensors) return;
+  if (adam) {                                   // AdamW: no layer-wise trust ratio
+    ratio[ti] = 1.0f;
+    return;
+  }
   float sp = 0.f, su = 0.f;
   for (int c = t.tensor_chunk_begin[ti]; c < t.tensor_chunk_begin[ti + 1]; ++c) {
     sp += part_p2[c];
@@ -190,11 +194,11 @@ using namespace octic;
 
 extern "C" {
 
-int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
-                    const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
-                    const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
-                    float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
-                    void* stream) {
+static int lamb_impl(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
+                     const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
+                     const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
+                     float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
+                     void* stream, int adam) {
   if (!p || !g || !m || !v || !wd || !chunk_tensor || !chunk_off || !chunk_len || !tensor_chunk_begin || !workspace)
     return OCTIC_ENULL;
   if (ntensors <= 0 || nchunks <= 0 || step < 0) return OCTIC_ESHAPE;
@@ -213,9 +217,27 @@ int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const*
   lamb_gradsq_kernel<<<nchunks, 256, 0, s>>>(t, g2);
   lamb_scalars_kernel<<<1, 256, 0, s>>>(g2, nchunks, max_grad_norm, beta1, beta2, step, scal);
   lamb_stage1_kernel<<<nchunks, 256, 0, s>>>(t, scal, beta1, beta2, eps, p2, u2);
-  lamb_ratio_kernel<<<(ntensors + 255) / 256, 256, 0, s>>>(t, ntensors, p2, u2, ratio);
+  lamb_ratio_kernel<<<(ntensors + 255) / 256, 256, 0, s>>>(t, ntensors, p2, u2, ratio, adam);
   lamb_stage2_kernel<<<nchunks, 256, 0, s>>>(t, scal, ratio, lr, ema ? 1.0f - ema_decay : 0.f);
   return launch_status();
+}
+
+int octic_lamb_step(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
+                    const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
+                    const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
+                    float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
+                    void* stream) {
+  return lamb_impl(p, g, m, v, ema, wd, chunk_tensor, chunk_off, chunk_len, tensor_chunk_begin, ntensors, nchunks, workspace, lr,
+                   beta1, beta2, eps, max_grad_norm, step, ema_decay, bf16_shadow, stream, 0);
+}
+
+int octic_adamw_step(void* const* p, void* const* g, void* const* m, void* const* v, void* const* ema, const float* wd,
+                     const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_len,
+                     const int* tensor_chunk_begin, int ntensors, int nchunks, float* workspace, float lr, float beta1,
+                     float beta2, float eps, float max_grad_norm, int step, float ema_decay, void* const* bf16_shadow,
+                     void* stream) {
+  return lamb_impl(p, g, m, v, ema, wd, chunk_tensor, chunk_off, chunk_len, tensor_chunk_begin, ntensors, nchunks, workspace, lr,
+                   beta1, beta2, eps, max_grad_norm, step, ema_decay, bf16_shadow, stream, 1);
 }
 
 int64_t octic_lamb_workspace_floats(int ntensors, int nchunks) { return 8 + 3 * (int64_t)nchunks + ntensors; }

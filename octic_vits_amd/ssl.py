@@ -430,6 +430,11 @@ class SSLMetaArch(nn.Module):
         from .functional import invalidate_weight_caches
         invalidate_weight_caches(self.teacher)                    # raw writes: the teacher's bf16 weight copies are stale
 
+    @staticmethod
+    def _no_decay(name, p):
+        return (name.endswith(".bias") or "norm" in name or "gamma" in name or ".ls" in name or "alpha" in name
+                or "token" in name or "pos_embed" in name or p.ndim <= 1)
+
     def get_params_groups(self, weight_decay=0.04):
         """AdamW groups: no weight decay for biases, norms, layer scales (gamma / ls / alpha) and tokens
         (dinov2/utils/param_groups.py:68-94 without the layer-wise lr decay, which only rescales lr per group)."""
@@ -437,11 +442,7 @@ class SSLMetaArch(nn.Module):
         for name, p in self.student.named_parameters():
             if not p.requires_grad:
                 continue
-            if (name.endswith(".bias") or "norm" in name or "gamma" in name or ".ls" in name or "alpha" in name
-                    or "token" in name or "pos_embed" in name or p.ndim <= 1):
-                no_decay.append(p)
-            else:
-                decay.append(p)
+            (no_decay if self._no_decay(name, p) else decay).append(p)
         return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
@@ -450,12 +451,21 @@ class SSLTrainer:
     autocast student, ssl_default_config.yaml:25-31) -> clip_grad_norm_(3.0) per sub-model -> AdamW -> teacher EMA."""
 
     def __init__(self, arch: SSLMetaArch, lr=1e-3, weight_decay=0.04, betas=(0.9, 0.999), clip_grad=3.0, autocast=True,
-                 distributed=False, local_rank=0):
+                 distributed=False, local_rank=0, fused_optimizer=None):
+        """fused_optimizer (default: on the GPU): clip_grad_norm_ per sub-model, AdamW and the teacher's EMA as the fused
+        multi-tensor HIP step (train.FusedLamb(adam=True) = octic_adamw_step: two streaming passes per sub-model that also
+        leave the bf16 weight copies of the standard half and the prepared LinearD8 weights behind) instead of ~60 foreach
+        launches + two more passes over the teacher; False: torch.optim.AdamW + foreach EMA, as the reference runs it."""
         self.arch, self.clip_grad, self.autocast = arch, clip_grad, autocast
         self.device_type = next(arch.parameters()).device.type
-        self.optimizer = torch.optim.AdamW(arch.get_params_groups(weight_decay), lr=lr, betas=betas)
-        from .functional import track_optimizer
-        track_optimizer(arch.student, self.optimizer)             # AdamW's foreach path updates parameters in place
+        self.lr, self.weight_decay, self.betas = lr, weight_decay, betas
+        self.fused = (self.device_type == "cuda") if fused_optimizer is None else bool(fused_optimizer)
+        self._fused_opts = None                                   # built after the first backward (which tensors get gradients)
+        self.optimizer = None
+        if not self.fused:
+            self.optimizer = torch.optim.AdamW(arch.get_params_groups(weight_decay), lr=lr, betas=betas)
+            from .functional import track_optimizer
+            track_optimizer(arch.student, self.optimizer)         # AdamW's foreach path updates parameters in place
         if distributed:
             class _Fwd(nn.Module):
                 def __init__(s, a):
@@ -474,7 +484,11 @@ class SSLTrainer:
 
     def step(self, images, teacher_temp=0.07, momentum=0.992):
         self.arch.train()
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.optimizer is not None:
+            self.optimizer.zero_grad(set_to_none=True)
+        else:
+            for p in self.arch.student.parameters():
+                p.grad = None
         if self.autocast:
             with torch.autocast(self.device_type, dtype=torch.bfloat16):
                 loss_dict = self.arch.forward_backward(images, teacher_temp)
@@ -485,9 +499,43 @@ class SSLTrainer:
                 if p.grad is not None:
                     dist.all_reduce(p.grad)
                     p.grad.div_(_world())
+        if self.fused:
+            self._fused_step(momentum)
+            return loss_dict
         if self.clip_grad:
             for k in self.arch.student:
                 torch.nn.utils.clip_grad_norm_(self.arch.student[k].parameters(), self.clip_grad)
         self.optimizer.step()
         self.arch.update_teacher(momentum)
         return loss_dict
+
+    def _fused_step(self, momentum):
+        """One octic_adamw_step per sub-model (dinov2/train/train.py:274-296: clip per sub-model, optimizer step, teacher EMA).
+        Like torch.optim.AdamW, tensors that receive no gradient are left alone - the set is fixed by the first step."""
+        from .train import FusedLamb, library_gemm_layers, octic_weight_preps
+        arch = self.arch
+        if self._fused_opts is None:
+            self._fused_opts = {}
+            for k in arch.student:
+                sp = dict(arch.student[k].named_parameters())
+                tp = dict(arch.teacher[k].named_parameters())
+                live = [(n, p) for n, p in sp.items() if p.requires_grad and p.grad is not None]
+                if not live:
+                    continue
+                groups = [{"params": [p for n, p in live if not arch._no_decay(k + "." + n, p)], "weight_decay": self.weight_decay},
+                          {"params": [p for n, p in live if arch._no_decay(k + "." + n, p)], "weight_decay": 0.0}]
+                twin = {id(p): tp[n].data for n, p in live}
+                sub = arch.student[k]
+                self._fused_opts[k] = (FusedLamb(groups, lr=self.lr, betas=self.betas, eps=1e-8,
+                                                 max_grad_norm=self.clip_grad or 0.0, ema_decay=momentum, adam=True,
+                                                 ema_tensors=twin, shadow_layers=library_gemm_layers(sub),
+                                                 prep_source=(lambda s=sub: octic_weight_preps(s))), len(live))
+            # the teacher's tensors without a live student twin (frozen tokens) follow the plain EMA rule once here and stay
+        for k, (opt, nlive) in self._fused_opts.items():
+            have = sum(1 for p in arch.student[k].parameters() if p.requires_grad and p.grad is not None)
+            if have != nlive:
+                raise RuntimeError(f"SSLTrainer: the set of student tensors with gradients changed ({have} vs {nlive} in '{k}')")
+            opt.lr, opt.ema_decay = self.lr, momentum
+            opt.step()
+        from .functional import invalidate_weight_caches
+        invalidate_weight_caches(arch.teacher)                    # the kernel rewrote the teacher's parameters

@@ -92,11 +92,15 @@ class FusedLamb:
     CHUNK = 65536
 
     def __init__(self, param_groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, ema_decay=None,
-                 shadow_layers=(), prep_source=None):
+                 shadow_layers=(), prep_source=None, adam=False, ema_tensors=None):
         """shadow_layers: (nn.Linear, functional.DenseWeightCache) pairs; their weights/biases get a bf16 copy
-        written by the update kernel itself, handed to the cache after every step (no per-step cast launches)."""
+        written by the update kernel itself, handed to the cache after every step (no per-step cast launches).
+        adam=True: the same fused passes without the layer-wise trust ratio = AdamW with decoupled weight decay
+        (octic_adamw_step; the DINOv2 recipe's optimizer).  ema_tensors: {id(param): tensor} - the EMA is kept IN these tensors
+        (the DINOv2 teacher's parameters) instead of a flat buffer of this object; ema_decay is then the per-step momentum."""
         from . import _lib
         self._lib = _lib
+        self.adam = bool(adam)
         self.lr, self.betas, self.eps, self.max_grad_norm, self.ema_decay = lr, betas, eps, max_grad_norm, ema_decay
         self.params, wds = [], []
         for g in param_groups:
@@ -114,7 +118,13 @@ class FusedLamb:
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.ema = None
-        if ema_decay:
+        self._ema_ext = None
+        if ema_tensors is not None:
+            self._ema_ext = [ema_tensors[id(p)] for p in self.params]
+            for p, e in zip(self.params, self._ema_ext):
+                if e.shape != p.shape or e.dtype != torch.float32 or not e.is_contiguous() or e.device != p.device:
+                    raise ValueError("FusedLamb: an external EMA tensor must be a contiguous f32 twin of its parameter")
+        elif ema_decay:
             self.ema = torch.zeros(total, dtype=torch.float32, device=dev)
             for p, o in zip(self.params, offs):
                 self.ema[o:o + p.numel()].copy_(p.detach().flatten())
@@ -136,6 +146,8 @@ class FusedLamb:
         self.m_ptrs = torch.tensor(base(self.m), dtype=i64, device=dev)
         self.v_ptrs = torch.tensor(base(self.v), dtype=i64, device=dev)
         self.e_ptrs = torch.tensor(base(self.ema), dtype=i64, device=dev) if self.ema is not None else None
+        if self._ema_ext is not None:
+            self.e_ptrs = torch.tensor([e.data_ptr() for e in self._ema_ext], dtype=i64, device=dev)
         self.g_ptrs = torch.zeros(len(self.params), dtype=i64, device=dev)
         index = {id(p): i for i, p in enumerate(self.params)}
         sh_ptrs, self._shadows = [0] * len(self.params), []
@@ -199,6 +211,8 @@ class FusedLamb:
 
     def ema_state(self):
         """EMA weights as {param index: tensor view} (same order as the parameters)."""
+        if self._ema_ext is not None:
+            return list(self._ema_ext)
         return [self.ema[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self._offs)]
 
     # ---- checkpoint / resume (the reference saves optimizer.state_dict() every epoch, deit/main.py:414-423) ----------
@@ -317,7 +331,8 @@ class FusedLamb:
         self.step_count += 1
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.m.device).cuda_stream)
-        self._lib.check(self._lib.lib().octic_lamb_step(
+        fn = self._lib.lib().octic_adamw_step if self.adam else self._lib.lib().octic_lamb_step
+        self._lib.check(fn(
             vp(self.p_ptrs), vp(self.g_ptrs), vp(self.m_ptrs), vp(self.v_ptrs), vp(self.e_ptrs), vp(self.wd),
             vp(self.chunk_tensor), vp(self.chunk_off), vp(self.chunk_len), vp(self.tensor_chunk_begin),
             self.ntensors, self.nchunks, vp(self.ws), float(self.lr), float(self.betas[0]), float(self.betas[1]),
@@ -328,6 +343,9 @@ class FusedLamb:
         # cache keyed on them (the compute-dtype weight copies of functional.WeightPrep) is refreshed
         torch._C._autograd._unsafe_set_version_counter(
             tuple(self.params), tuple(p._version + 1 for p in self.params))
+        if self._ema_ext is not None:                 # the EMA twins (teacher parameters) were rewritten too
+            torch._C._autograd._unsafe_set_version_counter(
+                tuple(self._ema_ext), tuple(e._version + 1 for e in self._ema_ext))
         if self._wt_items is not None:
             self._lib.check(self._lib.lib().octic_dense_prep_batch(vp(self._wt_items), self._wt_count, self._wt_blocks,
                                                                    self._lib.BF16, stream))

@@ -120,6 +120,33 @@ def test_ssl_trainer_steps_bf16():
         assert nt == ns_ and t.shape == s_.shape
 
 
+def test_fused_adamw_and_teacher_ema_match_torch_adamw_and_the_foreach_ema():
+    """SSLTrainer(fused_optimizer=True): clip_grad_norm_ per sub-model + AdamW + the teacher's EMA as octic_adamw_step
+    (csrc/lamb.hip without the trust ratio; the EMA is kept in the teacher's own tensors) against torch.optim.AdamW +
+    clip_grad_norm_ + the foreach EMA on an identically initialised twin, three f32 steps: student, teacher and the losses."""
+    from octic_vits_amd import ssl as S
+    _, a = _pair()
+    _, b = _pair()
+    images = _to(_batch(), "cuda")
+    ta = S.SSLTrainer(a, lr=2e-3, autocast=False, fused_optimizer=True, clip_grad=0.5)      # (a clip that bites)
+    tb = S.SSLTrainer(b, lr=2e-3, autocast=False, fused_optimizer=False, clip_grad=0.5)
+    for i in range(3):
+        la = ta.step(images, teacher_temp=0.05, momentum=0.9)
+        lb = tb.step(images, teacher_temp=0.05, momentum=0.9)
+        for k in lb:
+            assert float(la[k].detach()) == pytest.approx(float(lb[k].detach()), rel=2e-4, abs=1e-5), (i, k)
+    moved = 0
+    # the K third of a qkv bias has an exactly-zero gradient (softmax is invariant to a per-query shift): Adam normalises its
+    # rounding noise to +-lr per step, so those tensors are held to 2 lr steps (the exception of the DeiT train fixture too)
+    tol = lambda n: 2 * 2e-3 * 3 if n.endswith(("qkv.lin_A1.bias", "qkv.bias")) else 2e-6
+    for (n, pa), (_, pb) in zip(a.student.named_parameters(), b.student.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=2e-4, atol=tol(n)), n
+    for (n, pa), (_, pb), (_, ps) in zip(a.teacher.named_parameters(), b.teacher.named_parameters(), a.student.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=2e-4, atol=tol(n)), n
+        moved += int(ps.requires_grad and not torch.equal(pa, ps))
+    assert moved > 40                                            # the teacher trails the student, it is not a copy
+
+
 def test_nested_block_subset_stochastic_depth_on_the_engine_equals_the_eager_composition():
     """vit.NestedTensorBlock in training with drop_path > 0.1 (dinov2/layers/block.py:113-140: the branch on a random batch
     subset, added back scaled by b / keep): the engine path (vit.SUBSET_FUSED: gathered rows through the fused LayerNorm /
