@@ -16,7 +16,8 @@ def _ref(q, k, v, scale):
 
 
 @pytest.mark.parametrize("B,H,T,hd", [(2, 3, 257, 80), (2, 2, 197, 64), (1, 2, 33, 16), (1, 1, 160, 128), (3, 4, 65, 32),
-                                      (1, 2, 5, 48)])
+                                      (1, 2, 5, 48), (2, 3, 197, 80), (3, 2, 37, 80), (2, 2, 37, 64), (2, 2, 256, 80),
+                                      (1, 3, 224, 80), (2, 2, 225, 80)])
 def test_attn_fwd_matches_reference(B, H, T, hd):
     from octic_vits_amd import ops
     g = torch.Generator().manual_seed(T * 131 + hd)
@@ -58,7 +59,9 @@ def _ref_grads(q, k, v, do, scale):
     return q.grad, k.grad, v.grad
 
 
-@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 257, 80), (2, 2, 197, 64), (1, 2, 33, 16), (3, 4, 65, 32), (1, 2, 5, 48)])
+@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 257, 80), (2, 2, 197, 64), (1, 2, 33, 16), (3, 4, 65, 32), (1, 2, 5, 48),
+                                      (2, 3, 197, 80), (3, 2, 37, 80), (2, 2, 37, 64), (2, 2, 256, 80), (1, 3, 224, 80),
+                                      (2, 2, 225, 80)])
 def test_attn_bwd_matches_reference(B, H, T, hd):
     """Gradients vs autograd of the fp32 reference on the same bf16 inputs: P and dS are rounded to bf16 before the
     gradient MFMAs -> 3e-2 of the gradient scale."""
@@ -248,3 +251,32 @@ def test_single_pass_backward_on_packed_rows_over_several_heads_per_workgroup():
     sc = float(g2.float().abs().max())
     assert float((g1.float() - g2.float()).abs().max()) <= 2e-2 * sc
     assert float((g1.float() - g2.float()).norm() / g2.float().norm()) < 6e-3
+
+
+@pytest.mark.parametrize("T,hd", [(197, 64), (197, 80), (37, 80), (37, 64), (257, 64)])
+def test_attention_of_the_other_model_shapes_matches_fp64(T, hd):
+    """The shapes beside ViT-H/14's (257, 80): ViT-L/16 (197, 64), the DINOv2 ViT-H/16 global crops (197, 80) and 96 x 96
+    local crops (37, 80) - forward, log-sum-exp and all three gradients against float64 softmax attention on the same bf16
+    inputs, on the standard half's strided fused-QKV layout, whatever kernel family the routing picks for the shape."""
+    from octic_vits_amd import ops
+    B, H = 5, 16
+    g = torch.Generator().manual_seed(T + hd)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g).to(torch.bfloat16).cuda()
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    do = torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda()
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, scale)
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ops.attn_bwd(q, k, v, o, do, lse, scale, dq, dk, dv)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = (qd @ kd.transpose(-1, -2)) * scale
+    ro = torch.softmax(s, dim=-1) @ vd
+    ro.backward(do.double())
+    assert float((o.double() - ro).abs().max()) <= 2e-2 * max(1.0, float(ro.abs().max()))
+    rl = torch.logsumexp(s.detach(), dim=-1) / math.log(2.0)
+    assert float((lse.double() - rl).abs().max()) <= 2e-3
+    for name, got, want in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        sc = max(1.0, float(want.abs().max()))
+        assert float((got.double() - want).abs().max()) <= 3e-2 * sc, name
+        assert float((got.double() - want).norm() / want.norm()) < 1.2e-2, name
