@@ -575,6 +575,187 @@ __global__ __launch_bounds__(512) void fwd_os_kernel(AttnArgs a, int units) {
   if (wid == 0 && p_ob != nullptr) merge_extra(p_ob, p_lse, p_hmo);
 }
 
+
+// ================================================================ forward, one-shot softmax, T <= 256 (round 5)
+// The same plan for the sequence lengths beside ViT-H/14's 257: NT = ceil(T / 32) <= 8 key tiles = NT waves, every token
+// inside a tile (no extra rows, no ninth tile); the last tile may be partial - its rows past T arrive as zeros (the DMA
+// reads outside the descriptor) and their scores are set to -inf before the row maximum.  DINOv2 ViT-H/16: T = 197
+// (NT = 7: chunks of 5 + 2 key tiles) and T = 37 (NT = 2: one chunk).  Three image buffers rotate as above.
+template <int NT>
+__global__ __launch_bounds__((NT < 4 ? 4 : NT) * 64) void fwd_oss_kernel(AttnArgs a, int units) {
+  // at least four waves: a tile's 5 (plain rows) or 8 (packed rows) DMA jobs are dealt two per wave; waves past NT only stage
+  constexpr int W = NT < 4 ? 4 : NT;
+  constexpr int C0 = NT < 5 ? NT : 5, C1 = NT - C0;               // key tiles of the two chunks (<= 80 score registers each)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, half = lane >> 5;
+  const bool active = wid < NT;                                   // owns a query tile
+  constexpr int IMG = NT * TILE_B;
+  char* const ones = smem + 3 * IMG;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int G = gridDim.x;
+  const bool shared_rows = a.sH < a.sT;
+  FragAddr fa;
+  fa.setup(lane);
+  LeanStager st;
+  st.setup(wid, W, lane, a.sT, a.cv_in, NT, T);
+  auto head_of = [&](int idx, int64_t& in_off, int64_t& o_off, int64_t& st_off, int& h) {
+    const int u = unit_of(idx, units, shared_rows);
+    const int b = u / a.H;
+    h = u - b * a.H;
+    in_off = b * a.sB + h * a.sH;
+    o_off = b * a.oB + h * a.oH;
+    st_off = ((int64_t)b * a.H + h) * T;
+  };
+  if (tid < 32) ((unsigned*)ones)[tid] = (tid & 7) == 0 ? 0x3F80u : 0u;
+  // scores of key tile j: rows past T (zeros from the DMA) must not enter the maximum or the sums
+  auto mask_last = [&](f32x16& x, int j) {
+    if (j == NT - 1 && (T & 31) != 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (j * 32 + acc_row(i, half) >= T) x[i] = -INFINITY;
+    }
+  };
+
+  int u = blockIdx.x;
+  int64_t in_off, o_off, st_off;
+  int hh;
+  head_of(u, in_off, o_off, st_off, hh);
+  HeadMaps hm = head_maps(a, hh);
+  int bK = 0, bV = 1, bS = 2;
+  {
+    const i32x4 rk = make_rs(a.k, in_off, a.sT, T, a.cv_in), rv = make_rs(a.v, in_off, a.sT, T, a.cv_in);
+    for (int j = 0; j < NT; ++j) {
+      st.issue(j, lds0 + bK * IMG, rk, hm.k.bs);
+      st.issue(j, lds0 + bV * IMG, rv, hm.v.bs);
+    }
+  }
+  bf16x8 qf[KS];
+  load_rows(qf, a.q + in_off, a.sT, active ? wid : 0, T, lane, hm.q);
+
+  for (; u < units; u += G) {
+    const int un = u + G;
+    const bool has_next = un < units;
+    int64_t n_in = 0, n_o = 0, n_st = 0;
+    int nh = 0;
+    HeadMaps nhm = hm;
+    if (has_next) {
+      head_of(un, n_in, n_o, n_st, nh);
+      nhm = head_maps(a, nh);
+    }
+    bf16* ob = a.o + o_off;
+    float* lseb = a.lse ? a.lse + st_off : nullptr;
+    const char* Kimg = smem + bK * IMG;
+    const char* Vimg = smem + bV * IMG;
+    const i32x4 nrk = make_rs(a.k, n_in, a.sT, T, a.cv_in), nrv = make_rs(a.v, n_in, a.sT, T, a.cv_in);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // K(n), V(n) and the query rows
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    __syncthreads();                                              // ... of every wave; everybody is done with V(n - 1)
+
+    f32x16 ot[DT];
+    zero_acc<DT>(ot);
+    float m;
+    auto pv_tile = [&](const f32x16& x, int j) {                  // P = exp2(scale x - m), O^T += V^T P (row 80 = row sums)
+      float ps[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ps[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], a.scale_log2, -m));
+      const bf16x8 pb0 = pack8(ps), pb1 = pack8(ps + 8);
+      const char* vt_ = Vimg + j * TILE_B;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(vt_, fa, d, 0), pb0, ot[d], 0, 0, 0);
+        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(vt_, fa, d, 1), pb1, ot[d], 0, 0, 0);
+      }
+      ot[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_ones(vt_, fa, 0, ones, lane), pb0, ot[2], 0, 0, 0);
+      ot[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_ones(vt_, fa, 1, ones, lane), pb1, ot[2], 0, 0, 0);
+    };
+    {
+      f32x16 x[C0];
+#pragma unroll
+      for (int j = 0; j < C0; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[j][i] = 0.f;
+        const char* kt_ = Kimg + j * TILE_B;
+        if (active) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) x[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kt_, fa, ks), qf[ks], x[j], 0, 0, 0);
+          mask_last(x[j], j);
+        }
+        if (has_next) st.issue(j, lds0 + bS * IMG, nrk, nhm.k.bs);                        // K(n+1) tiles 0 .. C0-1 -> spare
+      }
+      float mx = x[0][0];
+#pragma unroll
+      for (int j = 0; j < C0; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, x[j][i]), x[j][i + 1]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      m = mx * a.scale_log2;
+      __syncthreads();                                            // every wave is done with K(n) tiles 0 .. C0-1
+      if (C1 == 0 && has_next && active) load_rows(qf, a.q + n_in, a.sT, wid, T, lane, nhm.q);      // (single chunk: the fragments are dead)
+#pragma unroll
+      for (int j = 0; j < C0; ++j) {
+        if (active) pv_tile(x[j], j);
+        if (has_next && j + C0 < NT) st.issue(j + C0, lds0 + bS * IMG, nrk, nhm.k.bs);   // K(n+1) tiles C0 ..
+        if (has_next) st.issue(j, lds0 + bK * IMG, nrv, nhm.v.bs);                        // V(n+1) tiles 0 .. C0-1 -> K(n)'s buffer
+      }
+    }
+    if constexpr (C1 > 0) {
+      f32x16 x[C1];
+#pragma unroll
+      for (int j = 0; j < C1; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[j][i] = 0.f;
+        const char* kt_ = Kimg + (C0 + j) * TILE_B;
+        if (active) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) x[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kt_, fa, ks), qf[ks], x[j], 0, 0, 0);
+          mask_last(x[j], C0 + j);
+        }
+      }
+      float mx = x[0][0];
+#pragma unroll
+      for (int j = 0; j < C1; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, x[j][i]), x[j][i + 1]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m1 = fmaxf(m, mx * a.scale_log2);
+      const float alpha = __builtin_amdgcn_exp2f(m - m1);
+      m = m1;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+      __syncthreads();                                            // every wave is done with K(n)
+      if (has_next && active) load_rows(qf, a.q + n_in, a.sT, wid, T, lane, nhm.q);
+#pragma unroll
+      for (int j = 0; j < C1; ++j) {
+        if (active) pv_tile(x[j], C0 + j);
+        if (has_next) st.issue(C0 + j, lds0 + bK * IMG, nrv, nhm.v.bs);                   // V(n+1) tiles C0 ..
+      }
+    }
+    float l = ot[2][8];                                           // row 80 of O^T: the row sum of P
+    l = __shfl(l, r, 64);
+    {
+      const int qi = wid * 32 + r;
+      if (active && qi < T) {
+        if (half == 0 && lseb) lseb[qi] = m + log2f(l);
+        store_rows16(ob + (int64_t)qi * a.oT, ot, 1.0f / l, half, hm.o);
+      }
+    }
+    in_off = n_in; o_off = n_o; st_off = n_st;
+    hm = nhm;
+    const int t = bK;                                             // K(n+1) is in the spare, V(n+1) in K(n)'s buffer
+    bK = bS; bS = bV; bV = t;
+  }
+}
+
+inline size_t fwd_oss_lds(int nt) { return (size_t)3 * nt * TILE_B + 128; }
+
 inline size_t fwd_os_lds(int nt) {
   return (size_t)3 * nt * TILE_B + 2 * HD * 2 + 128 + (WAVES * 2048 + 1024) + (size_t)(WAVES * 2 * (DT * 32 + kPartPad) + 2 * WAVES * 2) * sizeof(float);
 }
@@ -612,8 +793,19 @@ int attn80_fwd_launch(const AttnArgs& a_, int64_t B, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)fwd_os_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
   }
-  if ((route(OCTIC_ROUTE_ATTN_ONLINE) & 15) == 0 && nt == MAXNT) fwd_os_kernel<<<units < cus ? units : cus, 512, fwd_os_lds(nt), s>>>(a, units);
-  else fwd_kernel<<<units < cus ? units : cus, W * 64, fwd_lds(nt), s>>>(a, nt, units);
+  const int grid = units < cus ? units : cus;
+  const bool one_shot = (route(OCTIC_ROUTE_ATTN_ONLINE) & 15) == 0;
+  if (one_shot && nt == MAXNT) fwd_os_kernel<<<grid, 512, fwd_os_lds(nt), s>>>(a, units);
+  else if (one_shot && a.T <= 32 * nt && nt <= 8) {               // every token inside a tile: the T <= 256 one-shot kernels
+    switch (nt) {
+#define OSS(n) case n: { static DeviceOnce o##n; if (o##n.first()) { (void)hipFuncSetAttribute((const void*)fwd_oss_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); } \
+                 constexpr int wv = n < 4 ? 4 : n;                   /* waves per workgroup */ \
+                 const int wgs = cus * (8 / wv);                     /* short sequences: two workgroups per CU (8 waves) */ \
+                 fwd_oss_kernel<n><<<units < wgs ? units : wgs, wv * 64, fwd_oss_lds(n), s>>>(a, units); break; }
+      OSS(1) OSS(2) OSS(3) OSS(4) OSS(5) OSS(6) OSS(7) OSS(8)
+#undef OSS
+    }
+  } else fwd_kernel<<<grid, W * 64, fwd_lds(nt), s>>>(a, nt, units);
   return launch_status();
 }
 

@@ -13,7 +13,8 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-B, H, T, hd = 64, 16, 257, 80
+B, H, T, hd = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (64, 16, 257, 80)))
+from octic_vits_amd import _lib
 for layout in ("contiguous", "fused-qkv"):
     if layout == "contiguous":
         q, k, v = (torch.randn(B, H, T, hd, device="cuda").bfloat16() for _ in range(3))
@@ -28,4 +29,8 @@ for layout in ("contiguous", "fused-qkv"):
     tf = timeit(lambda: ops.attn_fwd(q, k, v, hd ** -0.5))
     tb = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, hd ** -0.5, dq, dk, dv))
     fl = 4.0 * B * H * T * T * hd
+    _lib.route_override(_lib.ROUTE_ATTN_ONLINE, 1)
+    tfo = timeit(lambda: ops.attn_fwd(q, k, v, hd ** -0.5))
+    _lib.route_override(_lib.ROUTE_ATTN_ONLINE, 0)
+    print(f"(B {B} H {H} T {T} hd {hd}) forward with the online-softmax kernel forced: {tfo:6.1f} us")
     print(f"{layout:11s} fwd {tf:6.1f} us ({fl / tf / 1e6:5.0f} TF)   bwd dq+dkv {tb:6.1f} us ({3.5 * fl / tb / 1e6:5.0f} TF)")
