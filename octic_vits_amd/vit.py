@@ -295,6 +295,7 @@ class Block(nn.Module):
 
 
 SUBSET_FUSED = True             # developer A/B: False = the eager composition of drop_add_residual_stochastic_depth
+STREAM_OWNED = [False]          # set by a model's block loop: the tensors handed from block to block belong to the loop
 MemEffAttention = Attention     # dinov2.layers.MemEffAttention: same parameters; the HIP core replaces xformers
 
 
@@ -354,7 +355,9 @@ class NestedTensorBlock(Block):
         from . import d8_layers as _L
         b = x.shape[0]
         keep = max(int(b * (1 - self.sample_drop_ratio)), 1)
-        x = x.clone()               # the reference's index_add is out of place: the caller's tensor stays what it was
+        if not STREAM_OWNED[0]:
+            x = x.clone()           # the reference's index_add is out of place: the caller's tensor stays what it was.  A model
+                                    # loop that owns the stream between its blocks (dinov2_models.forward_features*) says so.
         for norm, branch, gamma in ((self.norm1, self.attn, gammas[0]), (self.norm2, self.mlp, gammas[1])):
             idx = torch.randperm(b, device=x.device)[:keep]
             link = _L._RowLink()
