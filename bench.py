@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--no-batched-finishes", action="store_true",
                     help="developer A/B: the parameter-gradient slab reductions of the backward pass as immediate launches "
                          "instead of one batched launch at its end (ops._DeferredFinishes)")
+    ap.add_argument("--no-paired-wgrad", action="store_true",
+                    help="developer A/B: the qkv and proj weight gradients of a standard block as two launches instead of one "
+                         "(functional.WGRAD_PAIRED)")
     ap.add_argument("--no-packed-attn", action="store_true",
                     help="developer A/B: AttentionD8 through the pack / unpack kernels instead of the packed-row attention")
     ap.add_argument("--wgrad-f32-out", action="store_true",
@@ -272,6 +275,9 @@ def main():
     if args.lib_wgrad:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_HIP = False
+    if args.no_paired_wgrad:
+        from octic_vits_amd import functional as _OF
+        _OF.WGRAD_PAIRED = False
     if args.no_packed_attn:
         from octic_vits_amd import functional as _OF
         _OF.ATTN_PACKED = False

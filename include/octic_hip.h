@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 15
+#define OCTIC_ABI_VERSION 16
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -444,6 +444,14 @@ int64_t octic_dense_wgrad_workspace_bytes(int M, int N, int K);
 int octic_dense_wgrad_tile(int M, int N, int K);
 int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int64_t ldy, int64_t ldx, float* dW,
                          void* workspace, void* stream);
+/* Two weight gradients that share the token rows M and K as ONE launch (tile list = [problem 0 | problem 1], row slabs chosen
+ * for the sum): the qkv and proj weight gradients of a standard block (deit/vit.py:33-45).  Results bit-identical to two
+ * octic_dense_wgrad_tn calls whenever the joint launch picks the slab counts those would (each tile sums its slabs in slab
+ * order); workspace: octic_dense_wgrad_pair_workspace_bytes.                                                            */
+int64_t octic_dense_wgrad_pair_workspace_bytes(int M, int N0, int N1, int K);
+int octic_dense_wgrad_tn_pair(const void* dY0, const void* X0, int N0, int64_t ldy0, int64_t ldx0, float* dW0,
+                              const void* dY1, const void* X1, int N1, int64_t ldy1, int64_t ldx1, float* dW1, int M, int K,
+                              void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,14 @@ struct DwArgs {
   int S;              // row slabs: slab s covers steps [steps s / S, steps (s + 1) / S)
   float* slabs;       // [tiles][S] x 256 x (256 | 320) f32 partial tiles
   int* tickets;       // [tiles], zero when the workspace is created; the last arriver of a tile re-arms its ticket
+  // A SECOND problem with the same M and K in the same launch (round 5: octic_dense_wgrad_tn_pair): tiles [tiles0, tiles) of
+  // the tile list belong to it.  tiles0 = 0: one problem.  (1280 x 1280 alone is 25 tiles x 8 slabs and runs at 0.6 PF; next
+  // to the 75 tiles of 3840 x 1280 the pair is the 100-tile, two-slab shape of the MLP weights.)
+  const bf16* Y1; const bf16* X1;
+  int64_t ldy1, ldx1;
+  int N1;
+  float* W1;
+  int tiles0;
 };
 
 __device__ inline void dw_wait_vmcnt(int n) {
@@ -116,7 +124,6 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
     const uint64_t q = (uint64_t)base;
     return i32x4{(int)(uint32_t)q, (int)(uint32_t)((q >> 32) & 0xFFFF), (int)bytes, 0x27000};
   };
-  const i32x4 rsY = make_rs(a.Y, (int64_t)a.M * a.ldy * 2), rsX = make_rs(a.X, (int64_t)a.M * a.ldx * 2);
   // LDS-DMA as inline asm: hipcc tracks the buffer_load_lds BUILTIN as a pending LDS write and drains the whole ring with
   // `s_waitcnt vmcnt(0)` in front of every transposing read (that is what held this kernel at 0.45-0.61 PFLOP/s in
   // round 3's first attempt; see dma16_to_lds in octic_common.hpp)
@@ -127,45 +134,6 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
   };
   const unsigned lds0 = lds_offset(lds);
-
-  // ---- DMA lane constants.  A wave-instruction fills 4 unit rows (256 B each): lane -> row (lane >> 4), 16-byte chunk
-  // position (lane & 15) = 32-byte slot (lane >> 1) & 7, half (lane & 1); the slot holds source slot ^ f(row), with
-  // f(row) = (row & 3) | ((row >> 3) & 1) << 2 and row = 8 * wid + 4 * j + (lane >> 4) for instruction j of the wave.
-  // Unit column c (0..127) of dY-units = tile column (c >> 6) * 128 + (c & 63) (+64 for the second halves); of X-units =
-  // (c >> 5) * WK + (c & 31) (+32): the first two 16-column k-tiles of every wave, then the next two.
-  // KW = 5: the fifth k-tile of the four waves is a third X piece of 64 rows x 64 columns (128-byte rows, 8 per
-  // wave-instruction: lane -> row (lane >> 3), slot (lane >> 1) & 3, f(row) = ((row >> 1) & 1) | ((row >> 3) & 1) << 1),
-  // column c (0..63) = tile column (c >> 4) * 80 + 64 + (c & 15).
-  const int drow = lane >> 4;                 // 0..3
-  const int dpos = lane & 15;
-  unsigned voY[2], voX[2], voX2 = 0;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = 8 * wid + 4 * j + drow;                         // unit row 0..63
-    const int f = (row & 3) | (((row >> 3) & 1) << 2);
-    const int src_slot = ((dpos >> 1) & 7) ^ f;
-    const int c = src_slot * 16 + (dpos & 1) * 8;                    // first unit column of this lane's 8 bf16
-    voY[j] = (unsigned)(((int64_t)row * a.ldy + (c >> 6) * 128 + (c & 63)) * 2);
-    voX[j] = (unsigned)(((int64_t)row * a.ldx + (c >> 5) * G::WK + (c & 31)) * 2);
-  }
-  if constexpr (KW == 5) {
-    const int row = 8 * wid + (lane >> 3);
-    const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
-    const int src_slot = ((lane >> 1) & 3) ^ f;
-    const int c = src_slot * 16 + (lane & 1) * 8;
-    voX2 = (unsigned)(((int64_t)row * a.ldx + (c >> 4) * 80 + 64 + (c & 15)) * 2);
-  }
-
-  // ---- fragment read constants (transposing reads): lane fr = 4 q + p of a 16-lane group addresses row q, columns
-  // 4 p .. 4 p + 3 of a 4 x 16 block and receives column fr of its 4 rows
-  const int frow = kg * 8 + (fr >> 2);
-  const int ff = ((fr >> 2) & 3) | ((kg & 1) << 2);                  // f(row) for rows frow (+4) (+32 ks)
-  int offY[4], offX[2], offX2 = 0;                                   // byte offsets inside a unit, k-step 0, "lo" rows
-#pragma unroll
-  for (int j = 0; j < 4; ++j) offY[j] = frow * 256 + (((wr * 4 + j) ^ ff) << 5) + (fr & 3) * 8;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) offX[i] = frow * 256 + (((wc * 2 + i) ^ ff) << 5) + (fr & 3) * 8;
-  if constexpr (KW == 5) offX2 = frow * 128 + ((wc ^ (((fr >> 3) & 1) | ((kg & 1) << 1))) << 5) + (fr & 3) * 8;
 
   // ---- this workgroup's (slab, tile) item.  Items of a slab are consecutive; item j of a slab runs on XCD j % 8
   // (workgroups are dealt round-robin over the XCDs), which owns a contiguous chunk of the tn-major tile list: the
@@ -193,10 +161,59 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
     tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + l;
   }
 #endif
+  // which problem (wave-uniform selects; the tile list is [problem 0 | problem 1])
+  const bool second = a.tiles0 > 0 && tile >= a.tiles0;
+  const bf16* const Yp = second ? a.Y1 : a.Y;
+  const bf16* const Xp = second ? a.X1 : a.X;
+  const int64_t ldy_ = second ? a.ldy1 : a.ldy, ldx_ = second ? a.ldx1 : a.ldx;
+  const int N_ = second ? a.N1 : a.N;
+  float* const W_ = second ? a.W1 : a.W;
+  const int tile_l = second ? tile - a.tiles0 : tile;
+  const i32x4 rsY = make_rs(Yp, (int64_t)a.M * ldy_ * 2), rsX = make_rs(Xp, (int64_t)a.M * ldx_ * 2);
+
+  // ---- DMA lane constants.  A wave-instruction fills 4 unit rows (256 B each): lane -> row (lane >> 4), 16-byte chunk
+  // position (lane & 15) = 32-byte slot (lane >> 1) & 7, half (lane & 1); the slot holds source slot ^ f(row), with
+  // f(row) = (row & 3) | ((row >> 3) & 1) << 2 and row = 8 * wid + 4 * j + (lane >> 4) for instruction j of the wave.
+  // Unit column c (0..127) of dY-units = tile column (c >> 6) * 128 + (c & 63) (+64 for the second halves); of X-units =
+  // (c >> 5) * WK + (c & 31) (+32): the first two 16-column k-tiles of every wave, then the next two.
+  // KW = 5: the fifth k-tile of the four waves is a third X piece of 64 rows x 64 columns (128-byte rows, 8 per
+  // wave-instruction: lane -> row (lane >> 3), slot (lane >> 1) & 3, f(row) = ((row >> 1) & 1) | ((row >> 3) & 1) << 1),
+  // column c (0..63) = tile column (c >> 4) * 80 + 64 + (c & 15).
+  const int drow = lane >> 4;                 // 0..3
+  const int dpos = lane & 15;
+  unsigned voY[2], voX[2], voX2 = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * wid + 4 * j + drow;                         // unit row 0..63
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    const int src_slot = ((dpos >> 1) & 7) ^ f;
+    const int c = src_slot * 16 + (dpos & 1) * 8;                    // first unit column of this lane's 8 bf16
+    voY[j] = (unsigned)(((int64_t)row * ldy_ + (c >> 6) * 128 + (c & 63)) * 2);
+    voX[j] = (unsigned)(((int64_t)row * ldx_ + (c >> 5) * G::WK + (c & 31)) * 2);
+  }
+  if constexpr (KW == 5) {
+    const int row = 8 * wid + (lane >> 3);
+    const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    const int src_slot = ((lane >> 1) & 3) ^ f;
+    const int c = src_slot * 16 + (lane & 1) * 8;
+    voX2 = (unsigned)(((int64_t)row * ldx_ + (c >> 4) * 80 + 64 + (c & 15)) * 2);
+  }
+
+  // ---- fragment read constants (transposing reads): lane fr = 4 q + p of a 16-lane group addresses row q, columns
+  // 4 p .. 4 p + 3 of a 4 x 16 block and receives column fr of its 4 rows
+  const int frow = kg * 8 + (fr >> 2);
+  const int ff = ((fr >> 2) & 3) | ((kg & 1) << 2);                  // f(row) for rows frow (+4) (+32 ks)
+  int offY[4], offX[2], offX2 = 0;                                   // byte offsets inside a unit, k-step 0, "lo" rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offY[j] = frow * 256 + (((wr * 4 + j) ^ ff) << 5) + (fr & 3) * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offX[i] = frow * 256 + (((wc * 2 + i) ^ ff) << 5) + (fr & 3) * 8;
+  if constexpr (KW == 5) offX2 = frow * 128 + ((wc ^ (((fr >> 3) & 1) | ((kg & 1) << 1))) << 5) + (fr & 3) * 8;
+
   {
     const int s0 = (int)((int64_t)a.steps * slab_i / a.S);
     const int s1 = (int)((int64_t)a.steps * (slab_i + 1) / a.S);
-    const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+    const int tn = tile_l / a.tiles_k, tk = tile_l - tn * a.tiles_k;
     const int n0 = tn * DW_T, k0 = tk * G::BK;
     const int nkt = s1 - s0;                                 // >= 1 (the launcher keeps S <= max(1, steps / 2))
     const int nunits = 4 * nkt;
@@ -210,9 +227,9 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
         for (int p = 0; p < 4; ++p) acc[i][q][p] = f32x4{0, 0, 0, 0};
 
     // scalar offsets of this segment: first token row, tile columns
-    const int sbY = (int)(((int64_t)s0 * DW_BR * a.ldy + n0) * 2);
-    const int sbX = (int)(((int64_t)s0 * DW_BR * a.ldx + k0) * 2);
-    const int stepY = (int)(a.ldy * DW_BR * 2), stepX = (int)(a.ldx * DW_BR * 2);
+    const int sbY = (int)(((int64_t)s0 * DW_BR * ldy_ + n0) * 2);
+    const int sbX = (int)(((int64_t)s0 * DW_BR * ldx_ + k0) * 2);
+    const int stepY = (int)(ldy_ * DW_BR * 2), stepX = (int)(ldx_ * DW_BR * 2);
 
     int u_issue = 0;
     // KIND 0 / 3: first / second 64-column halves of the dY tile halves; KIND 1 / 2: first / second k-sets of X
@@ -398,7 +415,7 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
 #pragma unroll
           for (int q = 0; q < KW; ++q) {
             const int k = k0 + wc * G::WK + q * 16 + kg * 4;
-            if (n < a.N && k < a.K) *(f32x4*)(a.W + (int64_t)n * a.K + k) = acc[nh][q][j];
+            if (n < N_ && k < a.K) *(f32x4*)(W_ + (int64_t)n * a.K + k) = acc[nh][q][j];
           }
         }
     } else {
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(512, 1) void dense_tn_kernel(DwArgs a) {
 #pragma unroll
               for (int q = 0; q < KW; ++q) {
                 const int k = k0 + wc * G::WK + q * 16 + kg * 4;
-                if (n < a.N && k < a.K) *(f32x4*)(a.W + (int64_t)n * a.K + k) = t[q][j];
+                if (n < N_ && k < a.K) *(f32x4*)(W_ + (int64_t)n * a.K + k) = t[q][j];
               }
             }
           }
@@ -581,6 +598,43 @@ int octic_dense_wgrad_tn(const void* dY, const void* X, int M, int N, int K, int
   a.tickets = (int*)workspace;
   char* p = (char*)workspace + 4096;         // fixed ticket region: a workspace shared by several shapes keeps its zeros
   a.slabs = (float*)p;
+  hipStream_t s = (hipStream_t)stream;
+  return pl.kw == 5 ? dw_launch<5>(a, s) : dw_launch<4>(a, s);
+}
+
+
+// Two weight gradients with the same token rows M and the same K as ONE launch: dW0[N0,K] = dY0^T X0, dW1[N1,K] = dY1^T X1.
+// The tile list is [tiles of problem 0 | tiles of problem 1], row slabs chosen for the sum: the qkv and proj weight gradients
+// of a standard block (3840 x 1280 and 1280 x 1280 at ViT-H) become one 100-tile, two-slab launch - the shape of an MLP
+// weight gradient - instead of a 75-tile one and a 25-tile one that needs eight slabs to fill the chip.
+int64_t octic_dense_wgrad_pair_workspace_bytes(int M, int N0, int N1, int K) {
+  return octic_dense_wgrad_workspace_bytes(M, N0 + N1, K);
+}
+
+int octic_dense_wgrad_tn_pair(const void* dY0, const void* X0, int N0, int64_t ldy0, int64_t ldx0, float* dW0,
+                              const void* dY1, const void* X1, int N1, int64_t ldy1, int64_t ldx1, float* dW1, int M, int K,
+                              void* workspace, void* stream) {
+  if (!dY0 || !X0 || !dW0 || !dY1 || !X1 || !dW1 || !workspace) return OCTIC_ENULL;
+  if (M <= 0 || N0 <= 0 || N1 <= 0 || K <= 0 || (N0 % DW_T) || (N1 % DW_T) || ((K % 256) && (K % 320)) || (ldy0 % 8) ||
+      (ldx0 % 8) || (ldy1 % 8) || (ldx1 % 8))
+    return OCTIC_ESHAPE;
+  const int64_t lim = 1ll << 31;
+  if ((int64_t)M * ldy0 * 2 >= lim || (int64_t)M * ldx0 * 2 >= lim || (int64_t)M * ldy1 * 2 >= lim || (int64_t)M * ldx1 * 2 >= lim)
+    return OCTIC_ESHAPE;
+  if ((((uintptr_t)dY0) | ((uintptr_t)X0) | ((uintptr_t)dW0) | ((uintptr_t)dY1) | ((uintptr_t)X1) | ((uintptr_t)dW1)) & 15) return OCTIC_EALIGN;
+  const DwPlan pl = dw_plan(M, N0 + N1, K);                   // tiles and slabs of the joint tile list
+  if (pl.tiles > 1024) return OCTIC_ESHAPE;
+  DwArgs a = {};
+  a.Y = (const bf16*)dY0; a.X = (const bf16*)X0; a.ldy = ldy0; a.ldx = ldx0; a.M = M; a.N = N0; a.K = K; a.W = dW0;
+  a.Y1 = (const bf16*)dY1; a.X1 = (const bf16*)X1; a.ldy1 = ldy1; a.ldx1 = ldx1; a.N1 = N1; a.W1 = dW1;
+  a.tiles_k = pl.tiles_k;
+  a.tiles = pl.tiles;
+  a.tiles0 = (N0 / DW_T) * pl.tiles_k;
+  a.tiles8 = (a.tiles + 7) / 8 * 8;
+  a.steps = (M + DW_BR - 1) / DW_BR;
+  a.S = pl.S;
+  a.tickets = (int*)workspace;
+  a.slabs = (float*)((char*)workspace + 4096);
   hipStream_t s = (hipStream_t)stream;
   return pl.kw == 5 ? dw_launch<5>(a, s) : dw_launch<4>(a, s);
 }

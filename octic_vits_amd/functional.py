@@ -779,12 +779,58 @@ def _linear_lib(x2, wb, bias):
         return _timed_lib("fwd", lambda: torch.nn.functional.linear(x2, wb, bias), x2.shape[0], wb.shape[0], wb.shape[1])
 
 
+# The qkv and proj weight gradients of a standard block as ONE launch (ops.dense_wgrad_tn_pair): proj's backward runs first and
+# parks its operands in the Attention module's WgradPair; qkv's backward, one attention backward later, launches both.  The
+# parked gradient tensor is handed to autograd UNWRITTEN in between - only where nothing can read it before the end of the
+# backward pass, i.e. under the same condition as ops.DEFERRED_FINISHES (train.Trainer: one micro-batch into .grad = None, no
+# DDP hooks); elsewhere both run at once as before.  1280 x 1280 alone is 25 tiles x 8 row slabs at 0.6 PFLOP/s (90 us); beside
+# the 75 tiles of 3840 x 1280 the pair is a 100-tile, two-slab launch like the MLP weights.
+WGRAD_PAIRED = True
+
+
+class WgradPair:
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None
+
+    def park(self, g2, x2):
+        """Postpone dW = g2^T x2; returns the (not yet written) result tensor."""
+        dw = torch.empty((g2.shape[1], x2.shape[1]), dtype=torch.float32, device=g2.device)
+        # (storage, not tensor: a second tensor reference would make AccumulateGrad clone the unwritten gradient)
+        self.pending = (g2, x2, dw.untyped_storage(), dw.data_ptr(), tuple(dw.shape))
+        ops.DEFERRED_FINISHES.add_pair(self)
+        return dw
+
+    def take(self):
+        p, self.pending = self.pending, None
+        if p is None:
+            return None
+        g2, x2, storage, ptr, shape = p
+        dw = torch.empty(0, dtype=torch.float32, device=g2.device).set_(storage, 0, shape)
+        assert dw.data_ptr() == ptr
+        return g2, x2, dw
+
+    def flush(self):
+        p = self.take()
+        if p is not None:
+            g2, x2, dw = p
+            dw.copy_(_wgrad_lib(g2, x2))
+
+
+def _pair_ready(pair, g2, x2):
+    return (pair is not None and WGRAD_PAIRED and WGRAD_HIP and ops.DEFERRED_FINISHES.enabled and ops._in_backward()
+            and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and g2.stride(1) == 1
+            and x2.stride(1) == 1)
+
+
 class DenseLinearNTFn(torch.autograd.Function):
     """nn.Linear (bf16 operands, f32 accumulate, f32 bias added before the one rounding to bf16): forward and input
     gradient on csrc/dense_gemm.hip.  deit/vit.py:33 (``self.qkv(x)``)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, cache, tag):
+    def forward(ctx, x, w, b, cache, tag, pair=None):
+        ctx.pair = pair
         xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
         wb, wt = cache.get_nt(w, b, ("d" + tag) in DENSE_HIP)
         x2 = xb.reshape(-1, wb.shape[1])
@@ -809,7 +855,16 @@ class DenseLinearNTFn(torch.autograd.Function):
         if has_b:
             gb = (ops.dense_colsum(g2) if g2.is_cuda and g2.dtype == torch.bfloat16 and g2.shape[1] % 8 == 0
                   else g2.sum(0, dtype=torch.float32))
-        return gx, _wgrad_lib(g2, x2), gb, None, None
+        pair = ctx.pair
+        if pair is not None and pair.pending is not None:
+            pg, px, _s, _p, pshape = pair.pending
+            if (_pair_ready(pair, g2, x2) and pg.shape[0] == g2.shape[0] and px.shape[1] == x2.shape[1]
+                    and ops.dense_wgrad_pair_ok(g2.shape[0], g2.shape[1], pg.shape[1], x2.shape[1])):
+                pg, px, pdw = pair.take()
+                dw, _ = ops.dense_wgrad_tn_pair(g2, x2, pg, px, dw1=pdw)
+                return gx, dw, gb, None, None, None
+            pair.flush()
+        return gx, _wgrad_lib(g2, x2), gb, None, None, None
 
 
 class DenseProjResidFn(torch.autograd.Function):
@@ -817,9 +872,10 @@ class DenseProjResidFn(torch.autograd.Function):
     fused epilogue; backward = one HIP row pass (gy, d gamma, bias gradient) + the input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, a, w, b, gamma, rs, rps, cache, nw=None, nb=None, neps=None):
+    def forward(ctx, x, a, w, b, gamma, rs, rps, cache, nw=None, nb=None, neps=None, pair=None):
         """neps is not None: also return LayerNorm(out; nw, nb, neps) in bf16 - the norm that opens the next branch - from
         the same row pass that adds the residual (NEXT_NORM_FUSED)."""
+        ctx.pair = pair
         x = _c(x)
         ab = _c(a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16))
         wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP)
@@ -876,7 +932,11 @@ class DenseProjResidFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
                   else _mm_lib(gy, wb)).view(a_shape).to(a_dtype)
-        return gout.view(ctx.x_shape), ga, _wgrad_lib(gy, a2), colsum, dgamma, None, None, None, dnw, dnb, None
+        if _pair_ready(ctx.pair, gy, a2) and ops.dense_wgrad_ok(gy.shape[0], gy.shape[1], a2.shape[1]):
+            dw = ctx.pair.park(gy, a2)           # written by the qkv weight gradient's launch (or at the end of the pass)
+        else:
+            dw = _wgrad_lib(gy, a2)
+        return gout.view(ctx.x_shape), ga, dw, colsum, dgamma, None, None, None, dnw, dnb, None, None
 
 
 class DenseMlpFn(torch.autograd.Function):

@@ -298,6 +298,33 @@ def dense_wgrad_tn(dy, x, name=None):
     return dw
 
 
+def dense_wgrad_pair_ok(M, N0, N1, K):
+    return (N0 % 256 == 0 and N1 % 256 == 0 and (K % 256 == 0 or K % 320 == 0) and M > 0
+            and ((N0 + N1) // 256) * (K // 256) <= 256)
+
+
+def dense_wgrad_tn_pair(dy0, x0, dy1, x1, dw1=None):
+    """(dW0 [N0,K], dW1 [N1,K]) = (dy0^T x0, dy1^T x1) as ONE launch of csrc/dense_wgrad.hip (same M, same K): the qkv and proj
+    weight gradients of a standard block.  dw1: write the second result into this (already handed-out) tensor."""
+    _require_cuda(dy0)
+    M, N0 = dy0.shape
+    N1, K = dy1.shape[1], x0.shape[1]
+    if not (dy1.shape[0] == M and x0.shape[0] == M and x1.shape == (M, K) and all(t.stride(1) == 1 for t in (dy0, x0, dy1, x1))):
+        raise ValueError("dense_wgrad_tn_pair: operands must be [M,N0] / [M,K] / [M,N1] / [M,K] row-major")
+    need = int(lib().octic_dense_wgrad_pair_workspace_bytes(M, N0, N1, K))
+    ws = _DW_WS.get(dy0.device)
+    if ws is None or ws.numel() < need:
+        ws = _DW_WS[dy0.device] = torch.zeros(need, dtype=torch.uint8, device=dy0.device)
+    dw0 = torch.empty((N0, K), dtype=torch.float32, device=dy0.device)
+    if dw1 is None:
+        dw1 = torch.empty((N1, K), dtype=torch.float32, device=dy0.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_wgrad_tn_pair(_p(dy0), _p(x0), N0, dy0.stride(0), x0.stride(0), _p(dw0), _p(dy1), _p(x1), N1,
+                                          dy1.stride(0), x1.stride(0), _p(dw1), M, K, _p(ws), _stream(dy0)))
+    KERNEL_TIMER.stop(t, f"dense_tn_kernel<{N0}+{N1}x{K}>", 2 * M * (N0 + N1 + 2 * K) + 4 * (N0 + N1) * K, 2.0 * M * (N0 + N1) * K)
+    return dw0, dw1
+
+
 def linear_fwd(xv, w5, bias, yv, M, cin, cout, dtype, out_dtype, ref, resid_v=None, rs=None, rps=1, cs5=None):
     t = KERNEL_TIMER.start()
     check(lib().octic_linear_d8_fwd(ctypes.byref(xv), _arr5(w5), _p(bias), ctypes.byref(yv),
@@ -603,7 +630,14 @@ class _DeferredFinishes:
         self.jobs = []          # (partials, nblk, d, out0_ptr, out1_ptr, scale1, keep-alive tensors, stream)
         self.ln_jobs = []       # (partials, nblk, c, [5 dalpha ptrs], dbeta_ptr, keep-alive storages, stream)
         self.wg_jobs = []       # (filled _WgFinishJob, keep-alive tensors / storages, stream)
+        self.pairs = []         # functional.WgradPair objects holding a postponed weight gradient (see there)
         self.armed = False
+
+    def add_pair(self, pair):
+        self.pairs.append(pair)
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
     def add(self, partials, nblk, d, out0_ptr, out1_ptr, scale1, keep, stream):
         self.jobs.append((partials, nblk, d, out0_ptr, out1_ptr, scale1, keep, stream))
@@ -640,6 +674,9 @@ class _DeferredFinishes:
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
     def flush(self):
+        pairs, self.pairs = self.pairs, []
+        for pr in pairs:                                # a postponed weight gradient whose partner never came: on its own now
+            pr.flush()
         jobs, self.jobs, self.armed = self.jobs, [], False
         ln_jobs, self.ln_jobs = self.ln_jobs, []
         wg_jobs, self.wg_jobs = self.wg_jobs, []

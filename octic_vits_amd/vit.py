@@ -84,6 +84,7 @@ class Attention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.fused_attn = fused_attn
         self._c1, self._c2 = _OF.DenseWeightCache(), _OF.DenseWeightCache()
+        self._wgpair = _OF.WgradPair()            # qkv + proj weight gradients as one launch (functional.WGRAD_PAIRED)
 
     def fusable(self, N, dtype):
         drop = self.training and (self.attn_drop.p > 0. or self.proj_drop.p > 0.)
@@ -97,15 +98,16 @@ class Attention(nn.Module):
         hd = C // self.num_heads
         bf = dtype == torch.bfloat16
         if bf and _OF.dense_hip_ok(y, self.qkv.weight) and ({"qkv", "dqkv"} & _OF.DENSE_HIP):
-            qkv = _OF.DenseLinearNTFn.apply(y, self.qkv.weight, self.qkv.bias, self._c1, "qkv")
+            qkv = _OF.DenseLinearNTFn.apply(y, self.qkv.weight, self.qkv.bias, self._c1, "qkv", self._wgpair)
         else:
             qkv = _OF.DenseLinearFn.apply(y, self.qkv.weight, self.qkv.bias, dtype, self._c1)
         a = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
         if bf and _OF.dense_hip_ok(y, self.proj.weight, "proj"):
             if next_norm is not None:
                 return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2,
-                                                  next_norm.weight, next_norm.bias, next_norm.eps)
-            return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2)
+                                                  next_norm.weight, next_norm.bias, next_norm.eps, self._wgpair)
+            return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2,
+                                              None, None, None, self._wgpair)
         out = _OF.LinearScaleResidualFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, dtype, self._c2)
         return out if next_norm is None else (out, None)
 

@@ -343,3 +343,69 @@ def test_dense_wgrad_tn_default_width():
         assert lib_tile(o, 16448, N, K) == 256, (N, K)
     assert lib_tile(o, 16448, 1280, 960) == 320
     assert lib_tile(o, 16448, 1280, 200) == 0
+
+
+# round 5: two weight gradients (same token rows, same K) as one launch - the qkv and proj weight gradients of a block
+@pytest.mark.parametrize("M,N0,N1,K", [(16448, 3840, 1280, 1280), (390, 768, 256, 256), (12608, 3072, 1024, 1024), (1, 256, 256, 320),
+                                       (700, 512, 1280, 640), (4112, 1280, 3840, 1280)])
+def test_dense_wgrad_pair_integer_exact_and_equal_to_two_launches(M, N0, N1, K):
+    """octic_dense_wgrad_tn_pair: the joint tile list [problem 0 | problem 1] with row slabs chosen for the sum.  Small-integer
+    operands make every partial sum exact, so the pair, the two single launches and the fp64 products agree bit for bit
+    whatever slab counts each launch picks; the second result lands in a tensor handed in by the caller."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(M + N0)
+    mk = lambda r, c, lo, hi: torch.randint(lo, hi, (r, c), generator=g, device=DEV).to(torch.bfloat16)
+    dy0, x0, dy1, x1 = mk(M, N0, -2, 3), mk(M, K, -3, 4), mk(M, N1, -2, 3), mk(M, K, -3, 4)
+    out1 = torch.full((N1, K), float("nan"), device=DEV)
+    dw0, dw1 = o.dense_wgrad_tn_pair(dy0, x0, dy1, x1, dw1=out1)
+    assert dw1.data_ptr() == out1.data_ptr()
+    assert torch.equal(dw0.double(), dy0.double().t() @ x0.double())
+    assert torch.equal(dw1.double(), dy1.double().t() @ x1.double())
+    assert torch.equal(dw0, o.dense_wgrad_tn(dy0, x0)) and torch.equal(dw1, o.dense_wgrad_tn(dy1, x1))
+    # operands that are column slices of wider tensors (row strides), as the fused-QKV gradient hands them over
+    wide = mk(M, N0 + 64, -2, 3)
+    dw0s, _ = o.dense_wgrad_tn_pair(wide[:, :N0], x0, dy1, x1)
+    assert torch.equal(dw0s.double(), wide[:, :N0].double().t() @ x0.double())
+
+
+def test_paired_qkv_proj_weight_gradients_in_a_block_backward():
+    """functional.WGRAD_PAIRED: inside a backward pass that allows postponed parameter gradients (ops.DEFERRED_FINISHES, as
+    train.Trainer switches it on) proj's weight gradient is parked and written by the qkv weight gradient's launch of the same
+    block.  Against the unpaired backward: every other gradient bitwise, the two weight gradients to f32 summation order (and
+    bitwise here: both launches pick the same slab count at this size); nothing is left parked."""
+    from octic_vits_amd import functional as OF
+    from octic_vits_amd import ops as o
+    from octic_vits_amd.vit import Layer_scale_init_Block
+    torch.manual_seed(0)
+    blk = torch.nn.Sequential(*[Layer_scale_init_Block(dim=256, num_heads=4, qkv_bias=True, init_values=0.5, drop_path=0.0)
+                                for _ in range(2)]).cuda().train()
+    x = torch.randn(6, 65, 256, device=DEV)
+    cot = torch.randn(6, 65, 256, device=DEV)
+    res, launches = {}, {}
+    for paired in (False, True):
+        OF.WGRAD_PAIRED = paired
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(xi)
+        o.DEFERRED_FINISHES.enabled = True
+        o.KERNEL_TIMER.enable()
+        try:
+            y.backward(cot)
+        finally:
+            o.DEFERRED_FINISHES.enabled = False
+            OF.WGRAD_PAIRED = True
+        torch.cuda.synchronize()
+        launches[paired] = sorted(k for k in o.KERNEL_TIMER.summary() if k.startswith("dense_tn_kernel"))
+        o.KERNEL_TIMER.disable()
+        assert not o.DEFERRED_FINISHES.pairs and all(b.attn._wgpair.pending is None for b in blk)
+        res[paired] = {n: p.grad.clone() for n, p in blk.named_parameters()}
+        res[paired]["x"] = xi.grad.clone()
+    assert any("+" in k for k in launches[True]) and not any("+" in k for k in launches[False]), launches
+    for n in res[False]:
+        a_, b_ = res[False][n], res[True][n]
+        assert torch.isfinite(b_).all(), n
+        if n.endswith(("qkv.weight", "proj.weight")):
+            assert float((a_ - b_).norm()) <= 1e-5 * float(a_.norm()), n
+        else:
+            assert torch.equal(a_, b_), n
