@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--no-batched-finishes", action="store_true",
                     help="developer A/B: the parameter-gradient slab reductions of the backward pass as immediate launches "
                          "instead of one batched launch at its end (ops._DeferredFinishes)")
+    ap.add_argument("--no-gelu-factor", action="store_true",
+                    help="developer A/B: the standard MLP keeps h between fc1 and fc2's input gradient (GELU' evaluated in the "
+                         "backward epilogue) instead of the bf16 gelu'(h) factor (functional.GELU_FACTOR)")
     ap.add_argument("--no-paired-wgrad", action="store_true",
                     help="developer A/B: the qkv and proj weight gradients of a standard block as two launches instead of one "
                          "(functional.WGRAD_PAIRED)")
@@ -275,6 +278,9 @@ def main():
     if args.lib_wgrad:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_HIP = False
+    if args.no_gelu_factor:
+        from octic_vits_amd import functional as _OF
+        _OF.GELU_FACTOR = False
     if args.no_paired_wgrad:
         from octic_vits_amd import functional as _OF
         _OF.WGRAD_PAIRED = False

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 16
+#define OCTIC_ABI_VERSION 17
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -417,6 +417,10 @@ int octic_dense_prep_batch(const octic_dense_prep_item* items_dev, int n_items, 
  *   3 DGELU : C = gelu'(H) * acc   with H the saved pre-activation (fc2 input gradient fused with GELU backward);
  *             colsum (may be NULL): octic_dense_gemm_colsum_rows(M,N,K) slabs [N] f32 whose sum over slabs is the column
  *             sum of C (= fc1's bias gradient), every element written by each launch, fixed order -> octic_dense_finish
+ *   4 GELUF : like 1, but C = gelu'(acc + bias) rounded to bf16 - the factor the backward multiplies by - instead of the
+ *             pre-activation itself (gelu and gelu' share one erf evaluation in the epilogue);  C2 = gelu(acc + bias)
+ *   5 DFACT : like 3 with H = the factor stored by mode 4: C = H * acc, no transcendental in the epilogue (one more bf16
+ *             rounding of the factor than mode 1 + 3; same column sums)
  * C / C2 / H are bf16 [M,N] with row stride ldc.  bias, gamma [N] f32 and rs f32 may be NULL.  workspace:
  * octic_dense_gemm_workspace_bytes(M,N,K) bytes (split-K slabs of the last partial round of tiles + counters), ZEROED once
  * by the caller when it is allocated (the kernels re-arm their counters; calls sharing a workspace must be stream-ordered). */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("OCTIC_LIB") or os.path.join(HERE, "liboctic_hip.so") 
 HEADER_PATH = os.path.join(HERE, "..", "include", "octic_hip.h")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 # knobs of octic_route_override (include/octic_hip.h)
 (ROUTE_DENSE_TILE, ROUTE_DENSE_SPLIT, ROUTE_WGRAD_SLABS, ROUTE_WGRAD_TILE, ROUTE_LINEAR_RING, ROUTE_RING_EVEN,
  ROUTE_ATTN_LEGACY, ROUTE_ATTN_ONLINE, ROUTE_ATTN_BWD_PAIR) = range(9)

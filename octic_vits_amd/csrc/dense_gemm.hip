@@ -112,7 +112,9 @@ struct DgArgs {
   int* tickets;       // [(tiles - full_tiles)] arrival counters (zeroed by the host per launch)
 };
 
-enum DgMode { DG_PLAIN = 0, DG_GELU = 1, DG_RESID = 2, DG_DGELU = 3 };
+enum DgMode { DG_PLAIN = 0, DG_GELU = 1, DG_RESID = 2, DG_DGELU = 3,
+              DG_GELUF = 4,    // like GELU, but C = gelu'(pre-activation) in bf16 (the factor the backward multiplies by) instead of it
+              DG_DFACT = 5 };  // like DGELU with H = that stored factor: C = H * acc, no transcendental in the epilogue
 
 __device__ inline void dg_wait_vmcnt(int n) {      // n even, wave-uniform; anything unexpected drains (always safe)
   switch (n) {
@@ -190,6 +192,17 @@ __device__ inline float dg_gelu_grad(float x) {
   return 0.5f * (1.0f + dg_erf(x * kSqrt1Over2)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
 }
 #endif
+// gelu(x) and gelu'(x) from ONE erf evaluation: Phi(x) = (1 + erf(x / sqrt 2)) / 2, and the exp(-x^2 / 2) inside the erf
+// approximation is the density term of the derivative (DG_GELUF: the fc1 epilogue that also leaves the backward's factor)
+__device__ inline void dg_gelu_both(float x, float& g, float& d) {
+  const float ax = fabsf(x) * kSqrt1Over2;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-ax * ax);                     // exp(-x^2 / 2)
+  const float phi = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+  g = x * phi;
+  d = phi + x * kInvSqrt2Pi * e;
+}
 
 template <int N>
 __device__ inline void dg_wait_imm() {
@@ -694,9 +707,9 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   // the accumulators are dead now: every global operand of the row-wise pass is requested up front (16 rows x 32 B of x
   // or 16 B of h per lane in flight), so the pass pays the memory latency once instead of once per row
   f32x4 xin[MODE == DG_RESID ? 16 : 1][2];
-  bf16x8 hin[MODE == DG_DGELU ? 16 : 1];
+  bf16x8 hin[(MODE == DG_DGELU || MODE == DG_DFACT) ? 16 : 1];
   float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DGELU: column sums of this lane's rows (bias gradient of fc1)
-  if (MODE == DG_RESID || MODE == DG_DGELU) {
+  if (MODE == DG_RESID || MODE == DG_DGELU || MODE == DG_DFACT) {
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int m = m0 + wr * 128 + it * 8 + srow;
@@ -726,6 +739,17 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) y[e] = (bf16)dg_gelu((float)cb[e]);           // F.gelu of the bf16-rounded h
       *(bf16x8*)(a.C2 + (int64_t)m * a.ldc + n) = y;
+    } else if (MODE == DG_GELUF) {
+      bf16x8 y, f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float gv, dv;
+        dg_gelu_both((float)cb[e], gv, dv);    // of the bf16-rounded pre-activation, as the two-pass form sees it
+        y[e] = (bf16)gv;
+        f[e] = (bf16)dv;
+      }
+      *(bf16x8*)cp = f;                      // gelu'(h): what the fc2 input gradient multiplies by (DG_DFACT)
+      *(bf16x8*)(a.C2 + (int64_t)m * a.ldc + n) = y;
     } else if (MODE == DG_RESID) {
       *(u32x4*)cp = raw;                     // branch output, needed for d gamma
       const float rsv = a.rs ? a.rs[m / a.rps] : 1.0f;
@@ -738,12 +762,12 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
       float* op = a.OUT + (int64_t)m * a.N + n;
       *(f32x4*)op = x0;
       *(f32x4*)(op + 4) = x1;
-    } else {                                 // DG_DGELU: dh = gelu'(h) * g
+    } else {                                 // DG_DGELU: dh = gelu'(h) * g;  DG_DFACT: dh = factor * g
       const bf16x8 h = hin[it];
       bf16x8 d;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        d[e] = (bf16)(dg_gelu_grad((float)h[e]) * (float)cb[e]);
+        d[e] = (bf16)((MODE == DG_DFACT ? (float)h[e] : dg_gelu_grad((float)h[e])) * (float)cb[e]);
         csum[e] += (float)d[e];                // sum what the GEMMs downstream actually see
       }
       *(bf16x8*)cp = d;
@@ -751,7 +775,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   }
   // DGELU column sums: slab row 2 tm + wr holds the sums over this wave's rows (the tile's epilogue runs in exactly one
   // workgroup): every element of the [tiles_m * 2, N] buffer is written once per launch, octic_dense_finish adds the rows
-  if (MODE == DG_DGELU && a.colsum != nullptr) {
+  if ((MODE == DG_DGELU || MODE == DG_DFACT) && a.colsum != nullptr) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = csum[e];
@@ -894,7 +918,8 @@ int octic_dense_gemm_colsum_rows(int M, int N, int K) {
 }
 
 // mode: 0 plain (C = A B^T + bias), 1 GELU (C = pre-activation, C2 = gelu(C)), 2 RESID (C = branch, OUT = X + rs*gamma*C),
-// 3 DGELU (C = gelu'(H) * (A B^T); colsum != NULL: octic_dense_gemm_colsum_rows() slabs [N] of column sums of C).
+// 3 DGELU (C = gelu'(H) * (A B^T); colsum != NULL: octic_dense_gemm_colsum_rows() slabs [N] of column sums of C),
+// 4 GELUF (C = gelu'(pre-activation), C2 = gelu(pre-activation)), 5 DFACT (C = H * (A B^T), H = the factor of mode 4).
 int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs, int64_t rps,
                         const float* X, float* OUT, const void* H, float* colsum, void* workspace, void* stream) {
@@ -904,13 +929,13 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
   // the BLAS library) instead of wrapping
   if ((int64_t)M * lda * 2 >= (1ll << 31) || (int64_t)N * ldb * 2 >= (1ll << 31)) return OCTIC_ESHAPE;
   if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return OCTIC_EALIGN;
-  if (mode == DG_GELU && !C2) return OCTIC_ENULL;
+  if ((mode == DG_GELU || mode == DG_GELUF) && !C2) return OCTIC_ENULL;
   if (mode == DG_RESID && (!X || !OUT || (rs && rps <= 0))) return OCTIC_ENULL;
-  if (mode == DG_DGELU && !H) return OCTIC_ENULL;
+  if ((mode == DG_DGELU || mode == DG_DFACT) && !H) return OCTIC_ENULL;
   DgArgs a = {};
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.lda = lda; a.ldb = ldb; a.M = M; a.N = N; a.K = K;
   a.C = (bf16*)C; a.C2 = (bf16*)C2; a.ldc = ldc; a.bias = bias; a.gamma = gamma; a.rs = rs; a.rps = rs ? rps : 1;
-  a.X = X; a.OUT = OUT; a.H = (const bf16*)H; a.colsum = mode == DG_DGELU ? colsum : nullptr;
+  a.X = X; a.OUT = OUT; a.H = (const bf16*)H; a.colsum = (mode == DG_DGELU || mode == DG_DFACT) ? colsum : nullptr;
   const DgPlan p = dense_plan(M, N, K, dense_cus(), mode);
   a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.full_tiles = p.full; a.split = p.split; a.tail_pad = p.tail_pad;
   hipStream_t s = (hipStream_t)stream;
@@ -928,6 +953,8 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_DGELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_GELUF, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_DFACT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipGetLastError();
   }
   switch (mode) {
@@ -938,6 +965,8 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
     case DG_GELU: dense_nt_kernel<DG_GELU, 4><<<p.grid, 512, smem, s>>>(a); break;
     case DG_RESID: dense_nt_kernel<DG_RESID, 4><<<p.grid, 512, smem, s>>>(a); break;
     case DG_DGELU: dense_nt_kernel<DG_DGELU, 4><<<p.grid, 512, smem, s>>>(a); break;
+    case DG_GELUF: dense_nt_kernel<DG_GELUF, 4><<<p.grid, 512, smem, s>>>(a); break;
+    case DG_DFACT: dense_nt_kernel<DG_DFACT, 4><<<p.grid, 512, smem, s>>>(a); break;
     default: return OCTIC_ESHAPE;
   }
   return launch_status();

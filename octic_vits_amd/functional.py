@@ -786,6 +786,7 @@ def _linear_lib(x2, wb, bias):
 # DDP hooks); elsewhere both run at once as before.  1280 x 1280 alone is 25 tiles x 8 row slabs at 0.6 PFLOP/s (90 us); beside
 # the 75 tiles of 3840 x 1280 the pair is a 100-tile, two-slab launch like the MLP weights.
 WGRAD_PAIRED = True
+GELU_FACTOR = True     # standard MLP: keep gelu'(h) instead of h between fc1's forward and fc2's input gradient (bench --no-gelu-factor)
 
 
 class WgradPair:
@@ -956,8 +957,12 @@ class DenseMlpFn(torch.autograd.Function):
         w2b, w2t = c2.get_nt(w2, b2, "dfc2" in DENSE_HIP)
         y2 = yb.reshape(-1, w1b.shape[1])
         g32, rs32 = _f32(gamma), _f32(rs)
+        # GELU_FACTOR: fc1's epilogue leaves gelu'(h) (bf16) instead of h; fc2's input gradient multiplies by it (modes 4 / 5 of
+        # octic_dense_gemm_nt) - the erf of the backward epilogue is computed once, in the forward, beside gelu's
+        factor = GELU_FACTOR and "fc1" in DENSE_HIP and w2t is not None
+        ctx.factor = factor
         if "fc1" in DENSE_HIP:
-            h, a = ops.dense_gemm_nt(y2, w1b, 1, bias=_f32(b1), name="dense_nt_kernel<gelu>")
+            h, a = ops.dense_gemm_nt(y2, w1b, 4 if factor else 1, bias=_f32(b1), name="dense_nt_kernel<gelu>")
         else:
             h = _linear_lib(y2, w1b, None if b1 is None else c1.b)
             a = torch.nn.functional.gelu(h)
@@ -1013,10 +1018,11 @@ class DenseMlpFn(torch.autograd.Function):
             gbr, dgamma, db2 = ops.scale_residual_bwd(gout.view(br.shape), br, g32, rs32, rps, want_gamma=has_gamma,
                                                       want_colsum=has_b2)
         if w2t is not None:
+            md = 5 if ctx.factor else 3
             if has_b1:                                                                  # gelu'(h) * (gbr W2), + db1
-                dh, db1 = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>", want_colsum=True)
+                dh, db1 = ops.dense_gemm_nt(gbr, w2t, md, h=h, name="dense_nt_kernel<dgelu>", want_colsum=True)
             else:
-                dh, db1 = ops.dense_gemm_nt(gbr, w2t, 3, h=h, name="dense_nt_kernel<dgelu>"), None
+                dh, db1 = ops.dense_gemm_nt(gbr, w2t, md, h=h, name="dense_nt_kernel<dgelu>"), None
         else:
             dh, db1 = ops.dense_gelu_bwd(h, _mm_lib(gbr, w2b), want_colsum=has_b1)
         gw2 = _wgrad_lib(gbr, a)

@@ -903,27 +903,28 @@ def dense_colsum(g):
 def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None, want_colsum=False):
     """C[M,N] = a[M,K] @ b[N,K]^T on the hand-written MFMA kernel (csrc/dense_gemm.hip) with a fused tail:
     mode 0 -> c ; 1 -> (c, gelu(c)) ; 2 -> (c, x + rs*gamma*c) ; 3 -> gelu'(h) * c (want_colsum: also the f32 column
-    sums of that result).  a, b bf16 2-D, K contiguous."""
+    sums of that result) ; 4 -> (gelu'(c), gelu(c)) ; 5 -> h * c with h = the factor of mode 4 (want_colsum as 3).
+    a, b bf16 2-D, K contiguous."""
     _require_cuda(a)
     M, K = a.shape
     N = b.shape[0]
     if a.stride(1) != 1 or b.stride(1) != 1 or b.shape[1] != K:
         raise ValueError("dense_gemm_nt: operands must be [M,K] / [N,K] with contiguous K")
     c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    c2 = torch.empty_like(c) if mode == 1 else None
+    c2 = torch.empty_like(c) if mode in (1, 4) else None
     out = torch.empty((M, N), dtype=torch.float32, device=a.device) if mode == 2 else None
     ws = _dense_ws(M, N, K, a.device)
-    cs_rows = lib().octic_dense_gemm_colsum_rows(M, N, K) if (mode == 3 and want_colsum) else 0
+    cs_rows = lib().octic_dense_gemm_colsum_rows(M, N, K) if (mode in (3, 5) and want_colsum) else 0
     cs = torch.empty((cs_rows, N), dtype=torch.float32, device=a.device) if cs_rows else None
     t = KERNEL_TIMER.start()
     check(lib().octic_dense_gemm_nt(_p(a), _p(b), M, N, K, a.stride(0), b.stride(0), mode, _p(c), _p(c2), N, _p(bias),
                                     _p(gamma), _p(rs), int(rps), _p(x), _p(out), _p(h), _p(cs), _p(ws), _stream(a)))
     if t is not None:
-        nb = 2 * (M * K + N * K + M * N * (2 if mode in (1, 3) else 1)) + (8 * M * N if mode == 2 else 0)
+        nb = 2 * (M * K + N * K + M * N * (2 if mode in (1, 3, 4, 5) else 1)) + (8 * M * N if mode == 2 else 0)
         # "@320": the launch ran the 256 x 320 tile (kernel symbol dense_nt_kernel<0, 5>), else <mode, 4>
         wide = "@320" if lib().octic_dense_gemm_tile(M, N, K, mode) == 320 else ""
         KERNEL_TIMER.stop(t, (name or f"dense_nt_kernel<{mode}>") + wide, nb, 2.0 * M * N * K)
-    if mode == 1:
+    if mode in (1, 4):
         return c, c2
     if mode == 2:
         return c, out

@@ -165,6 +165,42 @@ def test_dense_nt_dgelu(M, N, K):
     assert torch.equal(o.dense_gemm_nt(a, b, 3, h=h, want_colsum=True)[1], cs)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 264, 256), (16448, 5120, 1280)])
+def test_dense_nt_gelu_factor_pair(M, N, K):
+    """Modes 4 / 5 (round 5): fc1's epilogue leaves gelu'(h) in bf16 beside gelu(h), fc2's input gradient multiplies by the
+    stored factor.  (a) mode 4's gelu output = mode 1's to one bf16 ulp, its factor = gelu' of the bf16-rounded pre-activation;
+    (b) mode 5 = bf16(factor * acc) EXACTLY on integer operands, with the same column sums protocol as mode 3; (c) the chain
+    4 -> 5 against the chain 1 -> 3: within the one extra bf16 rounding of the factor."""
+    o = ops()
+    a, b = rnd((M, K), 11), rnd((N, K), 12, K ** -0.5)
+    bias = rnd((N,), 13, dtype=torch.float32)
+    h, y1 = o.dense_gemm_nt(a, b, 1, bias=bias)
+    f, y4 = o.dense_gemm_nt(a, b, 4, bias=bias)
+    assert float((y4.float() - y1.float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(y1.float().abs().max()))
+    assert float(((y4.float() - y1.float()).abs() > 0).float().mean()) < 0.02          # (a last-bit difference is rare)
+    hf = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(hf).sum().backward()
+    assert float((f.double() - hf.grad).abs().max()) <= 2.0 ** -8 * 1.2                  # |gelu'| <= 1.13: half a bf16 ulp + erf error
+    # (b) exact arithmetic of mode 5
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ai = torch.randint(-3, 4, (M, K), generator=g, device=DEV).to(torch.bfloat16)
+    bi = torch.randint(-2, 3, (N, K), generator=g, device=DEV).to(torch.bfloat16)
+    d5, cs = o.dense_gemm_nt(ai, bi, 5, h=f, want_colsum=True)
+    # (the accumulator is rounded to bf16 when it is staged for the row-wise pass, as in modes 1 - 3: two roundings)
+    want = (f.float() * (ai.float() @ bi.float().t()).to(torch.bfloat16).float()).to(torch.bfloat16)
+    assert torch.equal(d5, want)
+    assert float((cs.double() - d5.double().sum(0)).abs().max()) <= 1e-5 * max(1.0, float(d5.double().abs().sum(0).max()))
+    assert torch.equal(o.dense_gemm_nt(ai, bi, 5, h=f, want_colsum=True)[1], cs)
+    # (c) the two chains
+    up = rnd((M, N), 41, 0.5)            # stands for gbr W2: any bf16 cotangent reaching the epilogue through the GEMM
+    eye = torch.eye(N, device=DEV, dtype=torch.bfloat16) if N <= 512 else None
+    if eye is not None:                   # small case: drive the epilogues with an identity B so that acc == up exactly
+        d3 = o.dense_gemm_nt(up[:, :256].contiguous(), eye[:N, :256].contiguous(), 3, h=h)
+        d5b = o.dense_gemm_nt(up[:, :256].contiguous(), eye[:N, :256].contiguous(), 5, h=f)
+        sc = max(1.0, float(d3.float().abs().max()))
+        assert float((d3.float() - d5b.float()).abs().max()) <= 2.0 ** -7 * sc
+
+
 @pytest.mark.parametrize("M,N,K", [(16448, 1280, 1280), (16448, 1280, 5120), (16448, 5120, 1280), (3000, 520, 4096),
                                    (2100, 264, 2048)])
 def test_dense_nt_split_tail_is_bitwise_repeatable(M, N, K):
