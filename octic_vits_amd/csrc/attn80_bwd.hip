@@ -96,13 +96,20 @@ __device__ __forceinline__ void hm_store8_at(bf16* base, int row_off, int g, int
   }
   *(u32x2_u*)(base + (row_off + (4 + 2 * sub) * m.cv + 2 * m.bs + 16)) = u32x2_u{v[0], v[1]};
 }
+__device__ __forceinline__ int wid_of() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 // chunk j (16 bytes = elements 8 j .. 8 j + 7) of row `row` of a tile image
 __device__ __forceinline__ const char* tile_chunk(const char* tile, int row, int j) {
   return j < 8 ? tile + row * 128 + ((j ^ swz(row)) << 4) : tile + TAIL_OFF + row * 32 + (j - 8) * 16;
 }
 
+// NKT = key tiles (= waves that own one); XKEY: one more key / query row past them (T = 32 NKT + 1: ViT-H/14's 257).  Round 5:
+// T <= 256 runs the same kernel with XKEY = false - every token inside a tile, the last tile possibly partial (its keys past T
+// are masked out of P and dS, their rows arrive as zeros), waves past NKT own no key tile and only stage, reduce and compute dQ.
+template <int NKT, bool XKEY>
 __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
-  constexpr int nt = BW_NT, W = WAVES, T = BW_T;
+  constexpr int nt = XKEY ? NKT + 1 : NKT, W = WAVES;
+  const int T = a.T;
+  const bool owner = wid_of() < NKT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
   char* const kimg = smem + BW_RING;
@@ -229,20 +236,24 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   // ---------------------------------------------------------------------------------------------------- prologue
   // K image, V image (borrowing the dS / quarter buffers) and the first three ring tiles by LDS-DMA; rows 256 of K and V
 #pragma unroll
-  for (int jt = 0; jt < 8; ++jt) {
+  for (int jt = 0; jt < NKT; ++jt) {
     stq.issue(jt, ldsK, rk, hm.k.bs);
     stq.issue(jt, ldsV, rv, hm.v.bs);
   }
   issue_tile(0);
-  issue_tile(1);
-  issue_tile(2);
+  if (1 < nt) issue_tile(1);
+  if (2 < nt) issue_tile(2);
   {
     u32x4 xrow = {0, 0, 0, 0};
-    if (wid == 1 && lane < 10) xrow = hm_load16(a.k + in_off + (int64_t)256 * a.sT, lane, hm.k);
-    if (wid == 2 && lane < 10) xrow = hm_load16(a.v + in_off + (int64_t)256 * a.sT, lane, hm.v);
+    if constexpr (XKEY) {
+      if (wid == 1 && lane < 10) xrow = hm_load16(a.k + in_off + (int64_t)(32 * NKT) * a.sT, lane, hm.k);
+      if (wid == 2 && lane < 10) xrow = hm_load16(a.v + in_off + (int64_t)(32 * NKT) * a.sT, lane, hm.v);
+    }
     for (int t = tid; t < 288; t += 512) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
-    if (tid < 160) acc256[tid] = 0.f;
-    if ((wid == 1 || wid == 2) && lane < 10) *(u32x4*)(xk + (wid - 1) * 160 + lane * 16) = xrow;
+    if constexpr (XKEY) {
+      if (tid < 160) acc256[tid] = 0.f;
+      if ((wid == 1 || wid == 2) && lane < 10) *(u32x4*)(xk + (wid - 1) * 160 + lane * 16) = xrow;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -254,10 +265,14 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   for (int ks = 0; ks < KS; ++ks) vf[ks] = rowfrag(dsb + wid * TILE_B, fa, ks);
   const char* const kt_ = kimg + wid * TILE_B;
   delta_of(0);
-  delta_of(1);
+  if (1 < nt) delta_of(1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // the V image is dead; delta of tiles 0, 1 is visible
-  if (wid < 2) key256_a(0, wid);                     // (visible after the first tile's barrier)
+  if constexpr (XKEY) {
+    if (wid < 2) key256_a(0, wid);                   // (visible after the first tile's barrier)
+  }
+  // keys of this wave's tile past T (partial last tile, XKEY = false): out of P and dS
+  const float kmask = (XKEY || wid * 32 + r < T) ? 1.0f : 0.0f;
 
   BWT(0);
   f32x16 dkt[DT], dvt[DT];
@@ -316,6 +331,8 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
     char* const mydst = dsb + (t & 1) * (WAVES * BW_DST) + wid * BW_DST;
 
     // ---- S' and dP (query on the accumulator row, key on the lane)
+    bf16x8 p0, p1, s0, s1;
+    if (owner) {
     f32x16 x, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { x[i] = 0.f; dp[i] = 0.f; }
@@ -333,18 +350,20 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g4 + e;
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], a.scale_log2, -l4[e]));
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], a.scale_log2, -l4[e]));
+        if constexpr (!XKEY) p *= kmask;
         ps[i] = p;
         ds[i] = p * (dp[i] - d4[e]);
       }
     }
-    const bf16x8 p0 = pack8(ps), p1 = pack8(ps + 8), s0 = pack8(ds), s1 = pack8(ds + 8);
+    p0 = pack8(ps); p1 = pack8(ps + 8); s0 = pack8(ds); s1 = pack8(ds + 8);
     // dS tile of this wave: row = key (lane r); its 32-byte half s (queries 16 s + {4 half + 0..3, + 8}) sits at half
     // s ^ (r >> 3 & 1), so that the transposing reads of rows 0-3 and 8-11 hit disjoint banks
     {
       const int sw = (r >> 3) & 1;
       *(bf16x8*)(mydst + r * 64 + (sw * 32) + half * 16) = s0;
       *(bf16x8*)(mydst + r * 64 + ((sw ^ 1) * 32) + half * 16) = s1;
+    }
     }
     BWT(3);
     // ---- [b_t] the ONE barrier of a tile.  Before it: this wave's dS tile, its share of tile t + 2 (DMA issued a tile
@@ -356,6 +375,7 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
     store_pending(t - 1);
     if (t + 3 < nt) issue_tile(t + 3);
     BWT(8);
+    if (owner) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dt_, fa, d, 0), p0, dvt[d], 0, 0, 0);
@@ -363,34 +383,40 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
       dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_, fa, d, 0), s0, dkt[d], 0, 0, 0);
       dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_, fa, d, 1), s1, dkt[d], 0, 0, 0);
     }
+    }
     BWT(4);
     // ---- dQ^T: the own block over all keys (two accumulation chains), a key quarter of block 8 / 9
     {
       const char* dsr = dsb + (t & 1) * (WAVES * BW_DST);
       f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
 #pragma unroll 2
-      for (int k = 0; k < 8; k += 2) {
+      for (int k = 0; k < NKT; k += 2) {
         const char* kp = kimg + k * TILE_B;
         const char* sp = dsr + k * BW_DST + kb0;
         e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + ka_lo0, kp + ka_hi0), tr8(sp, sp + 256), e0, 0, 0, 0);
-        e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + TILE_B + ka_lo0, kp + TILE_B + ka_hi0), tr8(sp + BW_DST, sp + BW_DST + 256), e1, 0, 0, 0);
+        if (k + 1 < NKT)
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + TILE_B + ka_lo0, kp + TILE_B + ka_hi0), tr8(sp + BW_DST, sp + BW_DST + 256), e1, 0, 0, 0);
       }
       f32x4 own = e0 + e1;
-      rank1(own, t, bi0 % 5, bi0 / 5);
+      if constexpr (XKEY) rank1(own, t, bi0 % 5, bi0 / 5);
       pend = pack_scaled(own);
       const int k2 = 2 * (wid >> 1);
       const char* kp = kimg + k2 * TILE_B;
       const char* sp = dsr + k2 * BW_DST + kb1;
       const f32x4 z = {0, 0, 0, 0};
-      f32x4 part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + ka_lo1, kp + ka_hi1), tr8(sp, sp + 256), z, 0, 0, 0);
-      part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + TILE_B + ka_lo1, kp + TILE_B + ka_hi1), tr8(sp + BW_DST, sp + BW_DST + 256), part, 0, 0, 0);
-      if (wid < 2) rank1(part, t, bi1 % 5, 1);
+      f32x4 part = z;
+      if (k2 < NKT) part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + ka_lo1, kp + ka_hi1), tr8(sp, sp + 256), z, 0, 0, 0);
+      if (k2 + 1 < NKT)
+        part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + TILE_B + ka_lo1, kp + TILE_B + ka_hi1), tr8(sp + BW_DST, sp + BW_DST + 256), part, 0, 0, 0);
+      if constexpr (XKEY) {
+        if (wid < 2) rank1(part, t, bi1 % 5, 1);
+      }
       ((f32x4*)pq)[(t & 1) * 512 + (wid & 1) * 256 + (wid >> 1) * 64 + lane] = part;
     }
     BWT(5);
     // ---- row-wise work for later tiles: delta two tiles ahead; key 256: part A one tile ahead, part B for this tile
     if (t + 2 < nt) delta_of(t + 2);
-    {
+    if constexpr (XKEY) {
       const int role = (wid - 2 * t) & 7;            // rotates over the waves: 0, 1 = part A (query block), 2..6 = part B (d-block)
       if (role < 2) { if (t + 1 < nt) key256_a(t + 1, role); }
       else if (role < 7) key256_b(t, role - 2);
@@ -404,14 +430,18 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
   // ---------------------------------------------------------------------------------------------------- epilogue
   {
     const int ki = wid * 32 + r;
-    store_rows16(a.dk + g_off + (int64_t)ki * a.gT, dkt, a.scale, half, hm.k);
-    store_rows16(a.dv + g_off + (int64_t)ki * a.gT, dvt, 1.0f, half, hm.v);
+    if (owner && ki < T) {
+      store_rows16(a.dk + g_off + (int64_t)ki * a.gT, dkt, a.scale, half, hm.k);
+      store_rows16(a.dv + g_off + (int64_t)ki * a.gT, dvt, 1.0f, half, hm.v);
+    }
   }
-  if (tid < 160) {                                   // dK[256] | dV[256] (acc256: one wave per d-block and tile, in tile order)
-    const bool isv = tid >= 80;
-    const int e = isv ? tid - 80 : tid;
-    bf16* row = (isv ? a.dv : a.dk) + g_off + (int64_t)256 * a.gT;
-    row[hm_elem(e, isv ? hm.v : hm.k)] = (bf16)(isv ? acc256[tid] : acc256[tid] * a.scale);
+  if constexpr (XKEY) {
+    if (tid < 160) {                                 // dK[256] | dV[256] (acc256: one wave per d-block and tile, in tile order)
+      const bool isv = tid >= 80;
+      const int e = isv ? tid - 80 : tid;
+      bf16* row = (isv ? a.dv : a.dk) + g_off + (int64_t)(32 * NKT) * a.gT;
+      row[hm_elem(e, isv ? hm.v : hm.k)] = (bf16)(isv ? acc256[tid] : acc256[tid] * a.scale);
+    }
   }
 #ifdef A80_TRACE
   BWT(9);
@@ -427,10 +457,13 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
 
 // routing override OCTIC_ROUTE_ATTN_BWD_PAIR: 1 = the round-2 dq + dkv pair for every shape
 
-// shapes of the single-pass backward: head_dim 80, exactly 257 tokens (8 key tiles + one extra row), 32-bit offsets
+// shapes of the single-pass backward: head_dim 80; 257 tokens (8 key tiles + one extra row) or 193 .. 256 tokens (7 - 8 key
+// tiles, every token inside one: DINOv2 ViT-H/16's 197; shorter sequences leave more of the eight waves without a key tile -
+// and their instantiations spill - and stay on the dq + dkv pair); 32-bit offsets
 int attn80_bwd_ok(const AttnBwdArgs& a) {
   using namespace a80;
-  return (!route(OCTIC_ROUTE_ATTN_BWD_PAIR) && a.hd == HD && a.T == BW_T && (int64_t)a.T * a.sT * 2 < 0x7FFFFFF0ll && (int64_t)a.T * a.oT * 2 < 0x7FFFFFF0ll &&
+  return (!route(OCTIC_ROUTE_ATTN_BWD_PAIR) && a.hd == HD && (a.T == BW_T || (a.T > 192 && a.T <= 256)) &&
+          (int64_t)a.T * a.sT * 2 < 0x7FFFFFF0ll && (int64_t)a.T * a.oT * 2 < 0x7FFFFFF0ll &&
           (int64_t)a.T * a.gT * 2 < 0x7FFFFFF0ll) ? 1 : 0;
 }
 
@@ -438,10 +471,15 @@ int attn80_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s) {
   using namespace a80;
   static DeviceOnce once;
   if (once.first()) {
-    (void)hipFuncSetAttribute((const void*)bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)bwd_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)bwd_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)bwd_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
   }
-  bwd_kernel<<<(int)(B * a.H), 512, BW_LDS, s>>>(a);
+  const int grid = (int)(B * a.H);
+  if (a.T == BW_T) bwd_kernel<8, true><<<grid, 512, BW_LDS, s>>>(a);
+  else if (a.T > 224) bwd_kernel<8, false><<<grid, 512, BW_LDS, s>>>(a);
+  else bwd_kernel<7, false><<<grid, 512, BW_LDS, s>>>(a);
   return launch_status();
 }
 

@@ -169,6 +169,36 @@ def _bwd_raw(q, k, v, o, do, lse, scale, fused):
 
 # (17, 16) and (40, 16): more (batch, head) units than the chip has CUs - the round-5 kernel is persistent over heads: chunks of
 # 1-2 and 2-3 heads per workgroup (the next head's V behind the last tiles, its K image and first tile behind the row stores)
+@pytest.mark.parametrize("T", [197, 193, 224, 225, 256])
+def test_single_pass_backward_below_257_tokens_matches_fp64_and_the_pair(T):
+    """Round 5: the single-pass kernel for 193 .. 256 tokens (bwd_kernel<7 | 8, false>: every token inside a key tile, the
+    last tile partial - its keys masked out of P and dS -, no extra-row machinery): float64 reference, the dq + dkv pair's own
+    error as the yardstick, bitwise repeatable, and the rows of the partial tile checked on their own."""
+    from octic_vits_amd import ops
+    B, H, hd = 3, 16, 80
+    g = torch.Generator().manual_seed(T)
+    q, k, v = (torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    do = torch.randn(B, H, T, hd, generator=g).to(torch.bfloat16).cuda()
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, scale)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ro = torch.softmax((qd @ kd.transpose(-1, -2)) * scale, dim=-1) @ vd
+    ro.backward(do.double())
+    assert ops._attn_bwd_phases(T, hd)[0][0] == 3
+    fused = _bwd_raw(q, k, v, o, do, lse, scale, True)
+    pair = _bwd_raw(q, k, v, o, do, lse, scale, False)
+    again = _bwd_raw(q, k, v, o, do, lse, scale, True)
+    t0 = 32 * ((T - 1) // 32)                                  # first token of the last (partial) tile
+    for name, f, p, a, want in zip(("dq", "dk", "dv"), fused, pair, again, (qd.grad, kd.grad, vd.grad)):
+        assert torch.equal(f, a), f"{name}: two launches differ"
+        sc = max(1.0, float(want.abs().max()))
+        ef, ep = float((f.double() - want).abs().max()), float((p.double() - want).abs().max())
+        assert ef <= 3e-2 * sc, f"{name}: max err {ef:.3e} (scale {sc:.3g})"
+        assert ef <= 1.5 * ep + 1e-3 * sc, f"{name}: single-pass err {ef:.3e} vs two-kernel {ep:.3e}"
+        assert float((f.double()[:, :, t0:] - want[:, :, t0:]).abs().max()) <= 3e-2 * sc, f"{name}: last tile"
+        assert float((f.double() - want).norm() / want.norm()) < 1.2e-2, name
+
+
 @pytest.mark.parametrize("B,H", [(2, 3), (5, 16), (17, 16), (40, 16)])
 def test_single_pass_backward_matches_fp64_and_the_two_kernel_path(B, H):
     """csrc/attn80_bwd.hip (round 4: P and dS once per tile pair, dQ as a fixed-order sum of eight per-wave partials,
