@@ -1,16 +1,16 @@
 #!/bin/bash
-# Developer recipe: the measurements behind profiles/*_r4* (run on the GPU box from the repo root).
+# Developer recipe: the measurements behind profiles/*_r5* (run on the GPU box from the repo root).
 set -u
 export TMPDIR=/tmp
 O=gpurun_out
 B="python3 bench.py --no-cpu-baseline --no-forward-only --no-kernel-timing --no-graph"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_trace -- python3 bench.py --no-cpu-baseline --no-forward-only --no-step-variants --steps 10 --warmup 3 > $O/prof_trace.json 2> $O/prof_trace.log
-python3 tools/rocprof_summary.py $O/prof_trace $O/rocprof_r4_bench.txt
-python3 tools/step_gaps.py $O/prof_trace $O/step_gaps_r4.txt > /dev/null
+python3 tools/rocprof_summary.py $O/prof_trace $O/rocprof_r5_bench.txt
+python3 tools/step_gaps.py $O/prof_trace $O/step_gaps_r5.txt > /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --steps 3 --warmup 2 > /dev/null 2> $O/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B --steps 3 --warmup 2 > /dev/null 2> $O/pmc_write.log
-python3 tools/traffic_from_pmc.py $O/pmc_fetch $O/pmc_write $O/traffic_r4.json > $O/traffic_r4.txt
+python3 tools/traffic_from_pmc.py $O/pmc_fetch $O/pmc_write $O/traffic_r5.json > $O/traffic_r5.txt
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $B --steps 3 --warmup 2 > /dev/null 2> $O/pmc_sq.log
-python3 tools/pmc_sq_summary.py $O/pmc_sq $O/pmc_r4_sq.txt > /dev/null
+python3 tools/pmc_sq_summary.py $O/pmc_sq $O/pmc_r5_sq.txt > /dev/null
 rm -rf $O/prof_trace $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O | tail -15
