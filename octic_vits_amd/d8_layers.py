@@ -308,6 +308,8 @@ class LinearD8(nn.Module):
         cout = self.output_channels // 8
         dtype = compute_dtype(xp)
         rps = xp.shape[-2] if xp.dim() >= 2 else 1
+        if rs is not None and rs.numel() == xp.numel() // xp.shape[-1] and rs.numel() != xp.shape[0]:
+            rps = 1                                   # one factor per ROW (several crop sets in one row tensor: ragged.py)
         cs5 = (None,) * 5 if cs is None else tuple(cs)
         if torch.compiler.is_compiling():
             # being traced: the same kernels through the dispatcher (dispatch.py), no Python-side weight cache
@@ -693,7 +695,15 @@ class AttentionD8(nn.Module):
             raise ValueError("AttentionD8 expects [B, N, C] irreps")
         qkv = self.qkv(xs if isinstance(xs, Octic) else Octic(xp, c))
         drop = self.attn_drop.p if self.training else 0.
-        if (OF.ATTN_PACKED and drop == 0. and qkv.packed.is_cuda
+        rag = OF.RAGGED
+        if rag is not None and rag.matches(xp):
+            # several crop sets in one row tensor: the softmax core walks the sets, everything around it ran once on all rows
+            from . import ragged as _R
+            if not (OF.ATTN_PACKED and drop == 0. and qkv.packed.is_cuda
+                    and all(OF.ops.attn_packed_ok(T, c, self.num_heads, qkv.packed.dtype) for _, T, _ in rag.sets)):
+                raise RuntimeError("AttentionD8: a ragged row tensor needs the packed attention kernels (bf16, head_dim 80 / 64)")
+            on = Octic(_R.AttnPackedRaggedFn.apply(qkv.packed, rag, self.num_heads, c, (8 * c // self.num_heads) ** -0.5), c)
+        elif (OF.ATTN_PACKED and drop == 0. and qkv.packed.is_cuda
                 and OF.ops.attn_packed_ok(qkv.packed.shape[1], c, self.num_heads, qkv.packed.dtype)):
             # head split, softmax core and irrep re-assembly in the attention kernels themselves (head_dim 80)
             if torch.compiler.is_compiling():
@@ -834,10 +844,17 @@ class BlockD8(nn.Module):
         xp, c = as_packed(xs)
         dt = compute_dtype(xp)
         B, dev = xp.shape[0], xp.device
+        rag = OF.RAGGED if (OF.RAGGED is not None and OF.RAGGED.matches(xp)) else None
+        if rag is not None:                          # one mask per SAMPLE of every crop set, handed on as per-row factors
+            B = rag.samples
         m1 = self.drop_path1.mask(B, dev) if isinstance(self.drop_path1, DropPathD8) else None
+        if rag is not None and m1 is not None:
+            m1 = rag.row_scale(m1)
         cs1 = self.ls1.alphas() if isinstance(self.ls1, LayerScaleD8) else None
         x1 = _branch(self.norm1, self.attn, xp, c, m1, cs1, dt)
         m2 = self.drop_path2.mask(B, dev) if isinstance(self.drop_path2, DropPathD8) else None
+        if rag is not None and m2 is not None:
+            m2 = rag.row_scale(m2)
         cs2 = self.ls2.alphas() if isinstance(self.ls2, LayerScaleD8) else None
         return _branch(self.norm2, self.mlp, x1.packed, c, m2, cs2, dt)
 

@@ -26,6 +26,7 @@ def _pack8(ts):
     return torch.cat((ts[0], ts[1], ts[2], ts[3], ts[4], ts[6], ts[5], ts[7]), dim=-1)
 
 
+RAGGED_LISTS = True     # a list of crop sets runs as one token-row tensor where the engine's regime allows it (ragged.py)
 _RESIZE = {}
 
 
@@ -127,11 +128,53 @@ class OcticDinoVisionTransformer(OcticVisionTransformer):
     # ------------------------------------------------------------------------------------------ forward
     def forward_features_list(self, x_list, masks_list):
         xs = [self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)]
+        if RAGGED_LISTS and self._ragged_ok(xs):
+            return self._forward_features_ragged(xs, masks_list)
         for blk in self.blocks[:self.depth // 2]:
             xs = blk(xs)
         x = [self._hand_off(t) for t in xs]
         x = self._standard_half(x)
         return [self._out(t, m) for t, m in zip(x, masks_list)]
+
+    def _ragged_ok(self, xs):
+        """Can the crop sets run as ONE row tensor (ragged.py)?  The engine's bf16 training / inference regime on the GPU with
+        attention shapes the packed kernels take, the hybrid (non-invariant) hand-off, the stock block classes."""
+        from . import ops, vit
+        from .d8_layers import BlockD8
+        t = xs[0].packed
+        if not (len(xs) > 1 and t.is_cuda and t.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not torch.compiler.is_compiling()
+                and not self.invariant):
+            return False
+        c, brk = self.embed_dim // 8, self.depth // 2
+        H = getattr(getattr(self.blocks[0], "attn", None), "num_heads", 0)
+        if not (H and all(ops.attn_packed_ok(x.packed.shape[1], c, H, torch.bfloat16) for x in xs)):
+            return False
+        return (all(isinstance(b, BlockD8) and b.attn.attn_drop.p == 0. for b in self.blocks[:brk])
+                and all(isinstance(b, vit.NestedTensorBlock) for b in self.blocks[brk:]))
+
+    def _forward_features_ragged(self, xs, masks_list):
+        """Both halves on the token rows of all crop sets at once: every row-wise kernel of a block runs once, every parameter
+        enters the graph once, attention walks the sets (ragged.py)."""
+        from . import ragged as R
+        from . import vit
+        rows, rag = R.concat([x.packed for x in xs])
+        c = self.embed_dim // 8
+        prev_r, prev_o = OF.RAGGED, vit.STREAM_OWNED[0]
+        OF.RAGGED, vit.STREAM_OWNED[0] = rag, True
+        try:
+            t = Octic(rows, c)
+            for blk in self.blocks[:self.depth // 2]:
+                t = blk(t)
+            x = self._hand_off(t)
+            for blk in self.blocks[self.depth // 2:]:
+                x = blk(x)
+            xn = self.norm(x)
+        finally:
+            OF.RAGGED, vit.STREAM_OWNED[0] = prev_r, prev_o
+        r = self.num_register_tokens
+        return [{"x_norm_clstoken": n[:, 0], "x_norm_regtokens": n[:, 1:r + 1], "x_norm_patchtokens": n[:, r + 1:],
+                 "x_prenorm": p, "masks": m} for n, p, m in zip(rag.views(xn), rag.views(x), masks_list)]
 
     def forward_features(self, x, masks=None):
         if isinstance(x, list):

@@ -41,6 +41,8 @@ _FP16_NOTE = [False]
 
 
 ATTN_PACKED = True     # AttentionD8: attention kernels read / write the packed irrep rows (no pack / unpack passes)
+RAGGED = None          # ragged.Ragged of the [1, R, .] tensor the blocks are looking at (several crop sets as one row tensor:
+                       # set by dinov2_models' block loop, consulted by the attention modules), or None
 
 
 def compute_dtype(t: torch.Tensor):

@@ -223,9 +223,10 @@ def sample_blocks_ok(full, compact, idx):
             and (full[0].numel() * full.element_size()) % 16 == 0 and 0 < idx.numel() == compact.shape[0] <= 65535)
 
 
-def gather_samples(full, idx):
+def gather_samples(full, idx, out=None):
     """full[idx] for whole samples (leading dimension) on csrc/elementwise.hip sample_blocks_kernel."""
-    out = torch.empty((idx.numel(),) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    if out is None:
+        out = torch.empty((idx.numel(),) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
     check(lib().octic_sample_blocks(_p(full), _p(out), _p(idx), idx.numel(), full[0].numel() * full.element_size(), 0,
                                     _stream(full)))
     return out
@@ -513,10 +514,10 @@ def attn_packed_ok(T, c, H, dtype):
     return dtype == torch.bfloat16 and c in (10 * H, 8 * H) and 0 < T <= 320 and attn_supported(T, 8 * (c // H), dtype)
 
 
-def attn_fwd_packed(qkv, H, c, scale):
+def attn_fwd_packed(qkv, H, c, scale, out=None):
     """qkv packed [B,T,3*8c] bf16 -> (o packed [B,T,8c], lse [B,H,T]); no head pack / unpack copies."""
     B, T = qkv.shape[0], qkv.shape[1]
-    o = torch.empty((B, T, 8 * c), dtype=qkv.dtype, device=qkv.device)
+    o = out if out is not None else torch.empty((B, T, 8 * c), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
     t = KERNEL_TIMER.start()
     check(lib().octic_attn_fwd_packed(_p(qkv), _p(o), _p(lse), B, H, T, c, qkv.stride(1), o.stride(1), float(scale),
@@ -525,10 +526,10 @@ def attn_fwd_packed(qkv, H, c, scale):
     return o, lse
 
 
-def attn_bwd_packed(qkv, o, dout, lse, H, c, scale):
+def attn_bwd_packed(qkv, o, dout, lse, H, c, scale, out=None):
     """-> dqkv packed [B,T,3*8c] (dq | dk | dv in the layout of qkv)."""
     B, T = qkv.shape[0], qkv.shape[1]
-    dqkv = torch.empty_like(qkv)
+    dqkv = out if out is not None else torch.empty_like(qkv)
     delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
     for phase, name, nbytes, flops in _attn_bwd_phases(T, 8 * (c // H)):
         t = KERNEL_TIMER.start()

@@ -29,6 +29,14 @@ class DropPath(nn.Module):
         return x * mask
 
 
+def _rows_per_scale(y, rs):
+    """Rows that share one entry of the per-sample factor rs: the sequence length - or 1 when rs has one entry per ROW (several
+    crop sets of different lengths in one [1, R, .] row tensor: ragged.py)."""
+    if rs is not None and y.shape[0] == 1 and y.shape[1] > 1 and rs.numel() == y.shape[1]:
+        return 1
+    return y.shape[1]
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, norm_layer=None,
                  bias=True, drop=0.):
@@ -53,21 +61,22 @@ class Mlp(nn.Module):
     def forward_fused(self, y, xres, gamma, rs, dtype, next_norm=None):
         """xres + rs*gamma*fc2(gelu(fc1(y))) with y already normalised and in the compute dtype.  next_norm (an
         nn.LayerNorm): the hand-written path also returns next_norm(result) from the residual row pass -> (x, y_next)."""
+        rps = _rows_per_scale(y, rs)
         if (dtype == torch.bfloat16 and _OF.dense_hip_ok(y, self.fc1.weight) and _OF.dense_hip_ok(y, self.fc2.weight)
                 and ({"fc1", "fc2", "dfc1", "dfc2"} & _OF.DENSE_HIP)):
             if next_norm is not None:
                 return _OF.DenseMlpFn.apply(y, xres, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gamma,
-                                            rs, y.shape[1], self._c1, self._c2, next_norm.weight, next_norm.bias,
+                                            rs, rps, self._c1, self._c2, next_norm.weight, next_norm.bias,
                                             next_norm.eps)
             return _OF.DenseMlpFn.apply(y, xres, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gamma,
-                                        rs, y.shape[1], self._c1, self._c2)
+                                        rs, rps, self._c1, self._c2)
         if next_norm is not None:
             return self.forward_fused(y, xres, gamma, rs, dtype), None
         if dtype == torch.bfloat16 and self.fc1.out_features % 8 == 0:
             h = _OF.DenseLinearGeluFn.apply(y, self.fc1.weight, self.fc1.bias, self._c1)
         else:
             h = F.gelu(_OF.DenseLinearFn.apply(y, self.fc1.weight, self.fc1.bias, dtype, self._c1))
-        return _OF.LinearScaleResidualFn.apply(xres, h, self.fc2.weight, self.fc2.bias, gamma, rs, y.shape[1], dtype,
+        return _OF.LinearScaleResidualFn.apply(xres, h, self.fc2.weight, self.fc2.bias, gamma, rs, rps, dtype,
                                                self._c2)
 
 
@@ -101,14 +110,20 @@ class Attention(nn.Module):
             qkv = _OF.DenseLinearNTFn.apply(y, self.qkv.weight, self.qkv.bias, self._c1, "qkv", self._wgpair)
         else:
             qkv = _OF.DenseLinearFn.apply(y, self.qkv.weight, self.qkv.bias, dtype, self._c1)
-        a = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
+        rag = _OF.RAGGED
+        if rag is not None and rag.matches(y):       # several crop sets in one row tensor (ragged.py): attention per set
+            from . import ragged as _R
+            a = _R.AttnQKVRaggedFn.apply(qkv, rag, self.num_heads, hd ** -0.5)
+        else:
+            a = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
+        rps = _rows_per_scale(y, rs)
         if bf and _OF.dense_hip_ok(y, self.proj.weight, "proj"):
             if next_norm is not None:
-                return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2,
+                return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, rps, self._c2,
                                                   next_norm.weight, next_norm.bias, next_norm.eps, self._wgpair)
-            return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, self._c2,
+            return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, rps, self._c2,
                                               None, None, None, self._wgpair)
-        out = _OF.LinearScaleResidualFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, N, dtype, self._c2)
+        out = _OF.LinearScaleResidualFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, rps, dtype, self._c2)
         return out if next_norm is None else (out, None)
 
     def forward(self, x):
@@ -369,7 +384,78 @@ class NestedTensorBlock(Block):
             x = _L._ScatterRowsFn.apply(x, idx, out, link)
         return x
 
+    def _ragged(self, x, rag):
+        """One block on the rows of several crop sets at once (ragged.py).  Training with drop_path > 0.1: the batch-subset
+        stochastic depth per set (one randperm per set and branch), the kept samples of all sets gathered into one compact row
+        tensor, the branch once on all of them with the set's b / keep as per-row factor; otherwise the fused block with
+        per-row stochastic-depth masks.  None when the block cannot take the engine path (the caller splits the sets)."""
+        from . import d8_layers as _L
+        from . import ragged as _R
+        if not (x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not torch.compiler.is_compiling()):
+            return None
+        d = x.shape[-1]
+        for n in (self.norm1, self.norm2):
+            if type(n) is not nn.LayerNorm or tuple(n.normalized_shape) != (d,) or d % 4 or d > 2048:
+                return None
+        hd = d // self.attn.num_heads if isinstance(self.attn, Attention) else 0
+        if not (isinstance(self.attn, Attention) and isinstance(self.mlp, Mlp) and self.mlp.fusable()
+                and self.attn.fusable(rag.sets[0][1], torch.bfloat16) and _R.attn_sets_supported(rag, hd, torch.bfloat16)):
+            return None
+        gammas = []
+        for ls in (self.ls1, self.ls2):
+            if isinstance(ls, nn.Identity):
+                gammas.append(None)
+            elif isinstance(ls, LayerScale) and not ls.inplace:
+                gammas.append(ls.gamma)
+            else:
+                return None
+        bf = torch.bfloat16
+        if self.training and self.sample_drop_ratio > 0.1:
+            if not STREAM_OWNED[0]:
+                x = x.clone()
+            keeps = [max(int(B * (1 - self.sample_drop_ratio)), 1) for B, _, _ in rag.sets]
+            sub = _R.Ragged([(k, T) for k, (_, T, _) in zip(keeps, rag.sets)])
+            scale = sub.const_row_scale([B / k for k, (B, _, _) in zip(keeps, rag.sets)], x.device)
+            prev = _OF.RAGGED
+            try:
+                _OF.RAGGED = sub
+                for norm, branch, gamma in ((self.norm1, self.attn, gammas[0]), (self.norm2, self.mlp, gammas[1])):
+                    idxs = [torch.randperm(B, device=x.device)[:k] for k, (B, _, _) in zip(keeps, rag.sets)]
+                    link = _L._RowLink()
+                    xa = _R.GatherSetsFn.apply(x, idxs, rag, sub, link)
+                    y, xres = _OF.DenseLayerNormFn.apply(xa, norm.weight, norm.bias, norm.eps, bf)
+                    out = branch.forward_fused(y, xres, gamma, scale, bf)
+                    x = _R.ScatterSetsFn.apply(x, idxs, rag, sub, out, link)
+            finally:
+                _OF.RAGGED = prev
+            return x
+        scales = []
+        for dp in (self.drop_path1, self.drop_path1 if self.training and self.sample_drop_ratio > 0.0 else self.drop_path2):
+            if isinstance(dp, DropPath) and dp.drop_prob > 0. and dp.training:      # (block.py:104 reuses drop_path1 in training)
+                keep = 1 - dp.drop_prob
+                m = torch.empty(rag.samples, device=x.device, dtype=torch.float32).bernoulli_(keep)
+                scales.append(rag.row_scale(m / keep if (keep > 0.0 and dp.scale_by_keep) else m))
+            else:
+                scales.append(None)
+        y, xres = _OF.DenseLayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, bf)
+        x = self.attn.forward_fused(y, xres, gammas[0], scales[0], bf)
+        y, xres = _OF.DenseLayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, bf)
+        return self.mlp.forward_fused(y, xres, gammas[1], scales[1], bf)
+
     def _one(self, x):
+        rag = _OF.RAGGED
+        if rag is not None and rag.matches(x):
+            out = self._ragged(x, rag)
+            if out is not None:
+                return out
+            prev, _OF.RAGGED = _OF.RAGGED, None      # not in the engine's regime: set by set, as the reference loops
+            try:
+                parts = [self._one(v) for v in rag.views(x)]
+            finally:
+                _OF.RAGGED = prev
+            from . import ragged as _R
+            return _R.concat(parts)[0]
         if self.training and self.sample_drop_ratio > 0.1:
             out = self._subset_fused(x) if SUBSET_FUSED else None
             if out is not None:

@@ -147,6 +147,68 @@ def test_fused_adamw_and_teacher_ema_match_torch_adamw_and_the_foreach_ema():
     assert moved > 40                                            # the teacher trails the student, it is not a copy
 
 
+def _hd64_backbone(drop_path=0.0):
+    from octic_vits_amd import d8_layers, dinov2_models, vit
+    return dinov2_models.OcticDinoVisionTransformer(
+        img_size=32, patch_size=4, embed_dim=256, depth=4, num_heads=4, drop_path_rate=drop_path,
+        octic_block_layers=lambda **kw: d8_layers.NestedTensorBlockD8(init_values=0.3, **{k: v for k, v in kw.items() if k != "init_values"}),
+        standard_block_layers=lambda **kw: vit.NestedTensorBlock(attn_class=vit.MemEffAttention, init_values=0.3,
+                                                                 **{k: v for k, v in kw.items() if k != "init_values"}))
+
+
+def test_crop_sets_as_one_row_tensor_equal_the_set_by_set_loop():
+    """ragged.py (round 5): a list of crop sets (global 32 x 32 = 65 tokens, local 16 x 16 = 17 tokens, head_dim 64) through the
+    backbone as ONE token-row tensor - every row-wise kernel once on all rows, attention per set - against the reference's
+    set-by-set loop (dinov2_models.RAGGED_LISTS = False), bf16 autocast: tokens of both sets and every parameter gradient,
+    which each parameter now receives from ONE graph node instead of two.  Then training with drop_path 0.4: stochastic-depth
+    masks per sample of every set (octic half) and the batch-subset stochastic depth per set (standard half) run and train."""
+    from octic_vits_amd import dinov2_models as DM
+    torch.manual_seed(0)
+    net = _hd64_backbone().cuda().train()
+    net.patch_embed.strict_img_size = False
+    g = torch.Generator(device="cuda").manual_seed(1)
+    xg = torch.randn(4, 3, 32, 32, generator=g, device="cuda")
+    xl = torch.randn(8, 3, 16, 16, generator=g, device="cuda")
+    masks = torch.rand(4, 64, generator=g, device="cuda") < 0.3
+    cg = torch.randn(4, 65, 256, generator=g, device="cuda")
+    cl = torch.randn(8, 17, 256, generator=g, device="cuda")
+    params = [p for p in net.parameters() if p.requires_grad]
+
+    def run(ragged):
+        DM.RAGGED_LISTS = ragged
+        for p in params:
+            p.grad = None
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                og, ol = net([xg, xl], masks=[masks, None], is_training=True)
+        finally:
+            DM.RAGGED_LISTS = True
+        tg = torch.cat([og["x_norm_clstoken"].unsqueeze(1), og["x_norm_patchtokens"]], 1)
+        tl = torch.cat([ol["x_norm_clstoken"].unsqueeze(1), ol["x_norm_patchtokens"]], 1)
+        ((tg.float() * cg).sum() + (tl.float() * cl).sum()).backward()
+        return tg.detach().float(), tl.detach().float(), [p.grad.detach().float().clone() for p in params]
+
+    g0, l0, gr0 = run(False)
+    g1, l1, gr1 = run(True)
+    for a_, b_ in ((g0, g1), (l0, l1)):
+        assert float((a_ - b_).abs().max()) <= 3e-2 * float(a_.abs().max())
+    for a_, b_, p in zip(gr0, gr1, params):
+        assert float((a_ - b_).norm()) <= 4e-2 * float(a_.norm()) + 1e-6, tuple(p.shape)
+
+    torch.manual_seed(0)
+    net2 = _hd64_backbone(drop_path=0.4).cuda().train()
+    net2.patch_embed.strict_img_size = False
+    opt = torch.optim.SGD(net2.parameters(), lr=1e-3)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            og, ol = net2([xg, xl], masks=[masks, None], is_training=True)
+        loss = og["x_norm_patchtokens"].float().square().mean() + ol["x_norm_clstoken"].float().square().mean()
+        loss.backward()
+        assert torch.isfinite(loss) and all(p.grad is None or torch.isfinite(p.grad).all() for p in net2.parameters())
+        opt.step()
+
+
 def test_nested_block_subset_stochastic_depth_on_the_engine_equals_the_eager_composition():
     """vit.NestedTensorBlock in training with drop_path > 0.1 (dinov2/layers/block.py:113-140: the branch on a random batch
     subset, added back scaled by b / keep): the engine path (vit.SUBSET_FUSED: gathered rows through the fused LayerNorm /
