@@ -847,14 +847,21 @@ class BlockD8(nn.Module):
         rag = OF.RAGGED if (OF.RAGGED is not None and OF.RAGGED.matches(xp)) else None
         if rag is not None:                          # one mask per SAMPLE of every crop set, handed on as per-row factors
             B = rag.samples
-        m1 = self.drop_path1.mask(B, dev) if isinstance(self.drop_path1, DropPathD8) else None
-        if rag is not None and m1 is not None:
-            m1 = rag.row_scale(m1)
+        pool = rag.masks if rag is not None else None
+        if pool is not None:                         # drawn for the whole pass at once (ragged.Ragged.draw_masks)
+            m1 = pool.get(id(self.drop_path1))
+        else:
+            m1 = self.drop_path1.mask(B, dev) if isinstance(self.drop_path1, DropPathD8) else None
+            if rag is not None and m1 is not None:
+                m1 = rag.row_scale(m1)
         cs1 = self.ls1.alphas() if isinstance(self.ls1, LayerScaleD8) else None
         x1 = _branch(self.norm1, self.attn, xp, c, m1, cs1, dt)
-        m2 = self.drop_path2.mask(B, dev) if isinstance(self.drop_path2, DropPathD8) else None
-        if rag is not None and m2 is not None:
-            m2 = rag.row_scale(m2)
+        if pool is not None:
+            m2 = pool.get(id(self.drop_path2))
+        else:
+            m2 = self.drop_path2.mask(B, dev) if isinstance(self.drop_path2, DropPathD8) else None
+            if rag is not None and m2 is not None:
+                m2 = rag.row_scale(m2)
         cs2 = self.ls2.alphas() if isinstance(self.ls2, LayerScaleD8) else None
         return _branch(self.norm2, self.mlp, x1.packed, c, m2, cs2, dt)
 

@@ -163,6 +163,12 @@ class OcticDinoVisionTransformer(OcticVisionTransformer):
         prev_r, prev_o = OF.RAGGED, vit.STREAM_OWNED[0]
         OF.RAGGED, vit.STREAM_OWNED[0] = rag, True
         try:
+            if self.training:                        # every random draw of the pass up front: a handful of launches
+                brk, dev = self.depth // 2, rows.device
+                rag.draw_masks([d for b in self.blocks[:brk] for d in (b.drop_path1, b.drop_path2)], dev)
+                n = 2 * sum(1 for b in self.blocks[brk:] if b.sample_drop_ratio > 0.1)
+                if n:
+                    rag.draw_perms(n, dev)
             t = Octic(rows, c)
             for blk in self.blocks[:self.depth // 2]:
                 t = blk(t)

@@ -835,7 +835,7 @@ class DenseLinearNTFn(torch.autograd.Function):
     def forward(ctx, x, w, b, cache, tag, pair=None):
         ctx.pair = pair
         xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
-        wb, wt = cache.get_nt(w, b, ("d" + tag) in DENSE_HIP)
+        wb, wt = cache.get_nt(w, b, ("d" + tag) in DENSE_HIP and ctx.needs_input_grad[0])
         x2 = xb.reshape(-1, wb.shape[1])
         if tag in DENSE_HIP:
             y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b), name="dense_nt_kernel<plain>")
@@ -881,7 +881,7 @@ class DenseProjResidFn(torch.autograd.Function):
         ctx.pair = pair
         x = _c(x)
         ab = _c(a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16))
-        wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP)
+        wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP and ctx.needs_input_grad[1])
         a2 = ab.reshape(-1, wb.shape[1])
         g32, rs32 = _f32(gamma), _f32(rs)
         ctx.norm = neps is not None
@@ -955,8 +955,9 @@ class DenseMlpFn(torch.autograd.Function):
         that adds the residual."""
         x = _c(x)
         yb = _c(y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16))
-        w1b, w1t = c1.get_nt(w1, b1, "dfc1" in DENSE_HIP)
-        w2b, w2t = c2.get_nt(w2, b2, "dfc2" in DENSE_HIP)
+        need_t = any(ctx.needs_input_grad[:2])            # (an inference pass - the DINOv2 teacher - never transposes)
+        w1b, w1t = c1.get_nt(w1, b1, "dfc1" in DENSE_HIP and need_t)
+        w2b, w2t = c2.get_nt(w2, b2, "dfc2" in DENSE_HIP and need_t)
         y2 = yb.reshape(-1, w1b.shape[1])
         g32, rs32 = _f32(gamma), _f32(rs)
         # GELU_FACTOR: fc1's epilogue leaves gelu'(h) (bf16) instead of h; fc2's input gradient multiplies by it (modes 4 / 5 of

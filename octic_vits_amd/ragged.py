@@ -21,7 +21,7 @@ _CONST_SCALES = {}         # (sets, per-set constants, device) -> [R] f32 per-ro
 
 
 class Ragged:
-    __slots__ = ("sets", "rows", "samples")
+    __slots__ = ("sets", "rows", "samples", "masks", "perms", "perm_at")
 
     def __init__(self, shapes):
         """shapes: [(B_i, T_i)]"""
@@ -31,6 +31,7 @@ class Ragged:
             off += int(B) * int(T)
         self.rows = off
         self.samples = sum(b for b, _, _ in self.sets)
+        self.masks, self.perms, self.perm_at = None, None, 0      # draws of one forward pass, made at once (draw_*)
 
     def matches(self, t):
         return t.dim() == 3 and t.shape[0] == 1 and t.shape[1] == self.rows
@@ -50,6 +51,46 @@ class Ragged:
             out.append(per_sample[s0:s0 + B].repeat_interleave(T))
             s0 += B
         return torch.cat(out)
+
+    def row_to_sample(self, device):
+        """[R] int64: the (set-major) sample index of every row; cached."""
+        key = (tuple(self.sets), "r2s", str(device))
+        t = _CONST_SCALES.get(key)
+        if t is None:
+            t = _CONST_SCALES[key] = self.row_scale(torch.arange(self.samples, device=device))
+        return t
+
+    def draw_masks(self, drop_paths, device):
+        """Stochastic-depth factors of a whole forward pass in four launches: one Bernoulli(keep) / keep per sample for each
+        of the given DropPathD8-like modules (drop_prob, scale_by_keep), expanded to per-row factors.  `masks[id(module)]` is
+        what BlockD8 takes instead of drawing its own (timm's drop_path draws per call: the same distribution)."""
+        live = [d for d in drop_paths if getattr(d, "drop_prob", 0.) > 0. and d.training]
+        if not live:
+            return
+        keeps = tuple(1. - d.drop_prob for d in live)
+        divs = tuple((1. - d.drop_prob) if (d.scale_by_keep and d.drop_prob < 1.) else 1. for d in live)
+        key = (keeps, divs, "keep", str(device))
+        kd = _CONST_SCALES.get(key)
+        if kd is None:
+            kd = _CONST_SCALES[key] = (torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1),
+                                       torch.tensor(divs, dtype=torch.float32, device=device).unsqueeze(1))
+        keep, div = kd
+        m = (torch.rand(len(live), self.samples, device=device) < keep).float() / div
+        rows = m.index_select(1, self.row_to_sample(device))
+        self.masks = {id(d): rows[i] for i, d in enumerate(live)}
+
+    def draw_perms(self, n, device):
+        """n random permutations of every set's samples in two launches per set (argsort of uniforms) - what the batch-subset
+        stochastic depth of n branches would draw with n x sets torch.randperm calls."""
+        self.perms = [torch.rand(n, B, device=device).argsort(dim=1) for B, _, _ in self.sets]
+        self.perm_at = 0
+
+    def take_perms(self, keeps, device):
+        """The next branch's kept samples per set (idx_i = first keeps[i] entries of a random permutation)."""
+        if self.perms is not None and self.perm_at < self.perms[0].shape[0]:
+            i, self.perm_at = self.perm_at, self.perm_at + 1
+            return [p[i, :k] for p, k in zip(self.perms, keeps)]
+        return [torch.randperm(B, device=device)[:k] for k, (B, _, _) in zip(keeps, self.sets)]
 
     def const_row_scale(self, values, device):
         """Per-set constants -> cached [R] per-row factors."""

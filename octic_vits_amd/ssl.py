@@ -446,6 +446,61 @@ class SSLMetaArch(nn.Module):
         return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
+class _TeacherRefresh:
+    """The teacher's bf16 operand copies, remade in two launches right after the fused step rewrote its parameters (EMA): one
+    ``octic_dense_prep_batch`` for every projection of the standard half and one ``octic_linear_d8_prep_batch`` for the LinearD8
+    layers, adopted by the layers' caches - instead of ~145 per-layer casts at the teacher's next forward.  The values are the
+    round-to-nearest casts the caches would make themselves."""
+
+    def __init__(self, teacher):
+        import numpy as np
+        from . import _lib
+        from .functional import PrepBatch
+        from .train import library_gemm_layers, octic_weight_preps
+        self._lib = _lib
+        self.layers = [(lin, cache) for lin, cache, _ in library_gemm_layers(teacher)
+                       if lin.weight.is_cuda and lin.weight.dtype == torch.float32 and lin.weight.is_contiguous()]
+        self.items, self.bufs = None, []
+        if self.layers:
+            dev = self.layers[0][0].weight.device
+            dt = np.dtype([("src", "<u8"), ("wb", "<u8"), ("wt", "<u8"), ("N", "<i4"), ("K", "<i4"), ("block_begin", "<i4"),
+                           ("pad", "<i4")])
+            tab = np.zeros(len(self.layers), dtype=dt)
+            blocks = 0
+            for i, (lin, _) in enumerate(self.layers):
+                N, K = lin.weight.shape
+                wb = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+                bb = None if lin.bias is None else torch.empty_like(lin.bias, dtype=torch.bfloat16)
+                self.bufs.append((wb, bb))
+                tab[i]["src"], tab[i]["wb"], tab[i]["wt"] = lin.weight.data_ptr(), wb.data_ptr(), 0
+                tab[i]["N"], tab[i]["K"], tab[i]["block_begin"] = N, K, blocks
+                blocks += int(_lib.lib().octic_dense_prep_batch_blocks(N, K))
+            self.items = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+            self.blocks = blocks
+        self.prep = PrepBatch(octic_weight_preps(teacher))
+        self._ptrs = self._current()
+
+    def _current(self):
+        return tuple(t.data_ptr() for lin, _ in self.layers for t in (lin.weight, lin.bias) if t is not None)
+
+    def stale(self):
+        return self._current() != self._ptrs or self.prep.stale()
+
+    @torch.no_grad()
+    def run(self):
+        import ctypes
+        if self.items is not None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.items.device).cuda_stream)
+            self._lib.check(self._lib.lib().octic_dense_prep_batch(ctypes.c_void_p(self.items.data_ptr()), len(self.layers),
+                                                                   self.blocks, self._lib.F32, stream))
+            pairs = [(bb, lin.bias) for (lin, _), (_, bb) in zip(self.layers, self.bufs) if bb is not None]
+            if pairs:
+                torch._foreach_copy_([d for d, _ in pairs], [s.detach() for _, s in pairs])
+            for (lin, cache), (wb, bb) in zip(self.layers, self.bufs):
+                cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16)
+        self.prep.run()
+
+
 class SSLTrainer:
     """One iteration of dinov2/train/train.py:253-296: schedules' values are arguments; zero_grad -> forward_backward (bf16
     autocast student, ssl_default_config.yaml:25-31) -> clip_grad_norm_(3.0) per sub-model -> AdamW -> teacher EMA."""
@@ -461,6 +516,7 @@ class SSLTrainer:
         self.lr, self.weight_decay, self.betas = lr, weight_decay, betas
         self.fused = (self.device_type == "cuda") if fused_optimizer is None else bool(fused_optimizer)
         self._fused_opts = None                                   # built after the first backward (which tensors get gradients)
+        self._teacher_refresh = None
         self.optimizer = None
         if not self.fused:
             self.optimizer = torch.optim.AdamW(arch.get_params_groups(weight_decay), lr=lr, betas=betas)
@@ -539,3 +595,6 @@ class SSLTrainer:
             opt.step()
         from .functional import invalidate_weight_caches
         invalidate_weight_caches(arch.teacher)                    # the kernel rewrote the teacher's parameters
+        if self._teacher_refresh is None or self._teacher_refresh.stale():
+            self._teacher_refresh = _TeacherRefresh(arch.teacher)
+        self._teacher_refresh.run()

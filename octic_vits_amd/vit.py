@@ -421,7 +421,7 @@ class NestedTensorBlock(Block):
             try:
                 _OF.RAGGED = sub
                 for norm, branch, gamma in ((self.norm1, self.attn, gammas[0]), (self.norm2, self.mlp, gammas[1])):
-                    idxs = [torch.randperm(B, device=x.device)[:k] for k, (B, _, _) in zip(keeps, rag.sets)]
+                    idxs = rag.take_perms(keeps, x.device)
                     link = _L._RowLink()
                     xa = _R.GatherSetsFn.apply(x, idxs, rag, sub, link)
                     y, xres = _OF.DenseLayerNormFn.apply(xa, norm.weight, norm.bias, norm.eps, bf)
