@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 17
+#define OCTIC_ABI_VERSION 18
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -456,6 +456,21 @@ int64_t octic_dense_wgrad_pair_workspace_bytes(int M, int N0, int N1, int K);
 int octic_dense_wgrad_tn_pair(const void* dY0, const void* X0, int N0, int64_t ldy0, int64_t ldx0, float* dW0,
                               const void* dY1, const void* X1, int N1, int64_t ldy1, int64_t ldx1, float* dW1, int M, int K,
                               void* workspace, void* stream);
+
+/* ---- row kernels of the DINOv2 objective over the prototype axis (K % 8 == 0, row strides % 8 == 0) -----
+ * octic_softmax_center: out[r, :] = softmax((t[r, :] - center) * inv_temp) in f32 - the teacher's centred, sharpened
+ * probabilities (dinov2/loss/dino_clstoken_loss.py:43-51, ibot_patch_loss.py:63-77); center may be NULL; t f32 or bf16.
+ * octic_soft_ce_fwd: loss[r] = -sum_k t_k log_softmax(s[r, :] * inv_temp)_k with t = tprob[r % t_rows, :] (several student
+ * crops against the same teacher rows: dino_clstoken_loss.py:78-92; the masked patch tokens: ibot_patch_loss.py:26-34), plus
+ * the row statistics the gradient needs (lse[r], tsum[r] = sum_k t_k).  octic_soft_ce_bwd: ds[r, k] = g[r] inv_temp
+ * (softmax(s inv_temp)_k tsum[r] - t_k) in s's dtype.  s is read in its storage dtype (bf16 under autocast), arithmetic f32. */
+int octic_softmax_center(const void* t, int t_dtype, int64_t ldt, const float* center, float inv_temp, float* out,
+                         int64_t rows, int K, void* stream);
+int octic_soft_ce_fwd(const void* s, int s_dtype, int64_t lds, const float* tprob, int64_t t_rows, float inv_temp,
+                      float* loss, float* lse, float* tsum, int64_t rows, int K, void* stream);
+int octic_soft_ce_bwd(const void* s, int s_dtype, int64_t lds, const float* tprob, int64_t t_rows, float inv_temp,
+                      const float* g, const float* lse, const float* tsum, void* ds, int64_t ldd, int64_t rows, int K,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liboctic_hip.so")
-SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_wreg.hip", "wgrad.hip", "lamb.hip", "attention.hip", "attn80.hip", "attn80_bwd.hip", "dense.hip", "dense_gemm.hip", "dense_wgrad.hip"]
+SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_wreg.hip", "wgrad.hip", "lamb.hip", "attention.hip", "attn80.hip", "attn80_bwd.hip", "dense.hip", "dense_gemm.hip", "dense_wgrad.hip", "ssl_loss.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 

@@ -529,6 +529,30 @@ class DenseWeightCache:
         return wb, self.wt
 
 
+class SoftCrossEntropyFn(torch.autograd.Function):
+    """Per row of the student logits s [N, K]: -sum_k t_k log_softmax(s / temp)_k against the teacher probabilities
+    tprob [Nt, K] (f32, no gradient; row r uses tprob[r % Nt]) -> [N] f32.  One read of s and tprob forward, one read of each
+    and one write backward (csrc/ssl_loss.hip) - dinov2/loss/dino_clstoken_loss.py:78-92, ibot_patch_loss.py:26-34."""
+
+    @staticmethod
+    def forward(ctx, s, tprob, temp):
+        tprob = _c(tprob.detach().float())
+        loss, lse, tsum = ops.soft_ce_fwd(s, tprob, 1.0 / temp)
+        ctx.save_for_backward(s, tprob, lse, tsum)
+        ctx.temp = temp
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        s, tprob, lse, tsum = ctx.saved_tensors
+        return ops.soft_ce_bwd(s, tprob, 1.0 / ctx.temp, g, lse, tsum), None, None
+
+
+def loss_rows_ok(t):
+    """The prototype-axis row kernels take this tensor (GPU, f32 / bf16, rows of K % 8 == 0 elements)."""
+    return t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0 and not torch.compiler.is_compiling()
+
+
 class DenseLayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim of an f32 residual stream, result in the compute dtype.  Returns (y, x): the
     second output is the stream itself, to be used for the residual connection, so that the residual cotangent

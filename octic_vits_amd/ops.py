@@ -819,6 +819,56 @@ def dense_layernorm_bwd_tail(gy, x, w, stats, dres, yb, gamma, rs, rps, want_par
     return dx, dw, db, gyb, dgamma, colsum
 
 
+def _rows2d(t):
+    """[..., K] with contiguous rows -> (2-D view, rows, K, row stride)."""
+    K = t.shape[-1]
+    t2 = t.reshape(-1, K)
+    if t2.stride(1) != 1 or (t2.shape[0] > 1 and t2.stride(0) % 8):
+        t2 = t2.contiguous()
+    return t2, t2.shape[0], K, (t2.stride(0) if t2.shape[0] > 1 else K)
+
+
+def softmax_center(t, center, inv_temp):
+    """softmax((t - center) * inv_temp) over the last dim, f32 (t f32 / bf16 [..., K], center f32 [K] or None)."""
+    _require_cuda(t)
+    t2, rows, K, ld = _rows2d(t)
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    c = None if center is None else center.reshape(-1).float().contiguous()
+    tk = KERNEL_TIMER.start()
+    check(lib().octic_softmax_center(_p(t2), dt_code(t2.dtype), ld, _p(c), float(inv_temp), _p(out), rows, K, _stream(t)))
+    KERNEL_TIMER.stop(tk, f"softmax_center_kernel<{_DTN[t2.dtype]}>", rows * K * (2 * t2.element_size() + 4))
+    return out
+
+
+def soft_ce_fwd(s, tprob, inv_temp):
+    """Per row r of s [N, K]: -sum_k t_k log_softmax(s_r * inv_temp)_k with t = tprob[r % Nt] (tprob f32 [Nt, K] contiguous).
+    Returns (loss [N], lse [N], tsum [N]) f32."""
+    _require_cuda(s)
+    s2, rows, K, ld = _rows2d(s)
+    if tprob.dtype != torch.float32 or not tprob.is_contiguous() or tprob.shape[-1] != K:
+        raise ValueError("soft_ce_fwd: tprob must be a contiguous f32 [Nt, K] tensor")
+    nt = tprob.numel() // K
+    loss, lse, tsum = (torch.empty(rows, dtype=torch.float32, device=s.device) for _ in range(3))
+    tk = KERNEL_TIMER.start()
+    check(lib().octic_soft_ce_fwd(_p(s2), dt_code(s2.dtype), ld, _p(tprob), nt, float(inv_temp), _p(loss), _p(lse), _p(tsum),
+                                  rows, K, _stream(s)))
+    KERNEL_TIMER.stop(tk, f"soft_ce_fwd_kernel<{_DTN[s2.dtype]}>", rows * K * (s2.element_size() + 4))
+    return loss, lse, tsum
+
+
+def soft_ce_bwd(s, tprob, inv_temp, g, lse, tsum):
+    """d loss / d s for soft_ce_fwd, in s's dtype ([N, K] contiguous)."""
+    s2, rows, K, ld = _rows2d(s)
+    nt = tprob.numel() // K
+    ds = torch.empty((rows, K), dtype=s2.dtype, device=s.device)
+    g = g.reshape(-1).float().contiguous()
+    tk = KERNEL_TIMER.start()
+    check(lib().octic_soft_ce_bwd(_p(s2), dt_code(s2.dtype), ld, _p(tprob), nt, float(inv_temp), _p(g), _p(lse), _p(tsum),
+                                  _p(ds), K, rows, K, _stream(s)))
+    KERNEL_TIMER.stop(tk, f"soft_ce_bwd_kernel<{_DTN[s2.dtype]}>", rows * K * (2 * s2.element_size() + 4))
+    return ds.view(s.shape)
+
+
 def scale_residual_fwd(x, y, gamma, rs, rps):
     """out = x + rs[row // rps] * gamma * y   (x f32, y f32/bf16, same shape [..., d])."""
     _require_cuda(x)

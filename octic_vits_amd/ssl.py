@@ -21,6 +21,10 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as _OF
+
+FUSED_LOSS_ROWS = True      # GPU: the prototype-axis passes of the DINO / iBOT terms on csrc/ssl_loss.hip (False: the eager composition)
+
 
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -119,6 +123,8 @@ class DINOLoss(_Centered):
     @torch.no_grad()
     def softmax_center_teacher(self, teacher_output, teacher_temp):
         self.apply_center_update()
+        if FUSED_LOSS_ROWS and _OF.loss_rows_ok(teacher_output):
+            return _OF.ops.softmax_center(teacher_output, self.center, 1.0 / teacher_temp)
         return F.softmax((teacher_output - self.center) / teacher_temp, dim=-1)
 
     @torch.no_grad()
@@ -126,6 +132,15 @@ class DINOLoss(_Centered):
         return _sinkhorn(teacher_output, teacher_temp, teacher_output.shape[0] * _world(), n_iterations)
 
     def forward(self, student_output_list, teacher_out_softmaxed_centered_list):
+        sl, tl = list(student_output_list), list(teacher_out_softmaxed_centered_list)
+        if (FUSED_LOSS_ROWS and sl and tl and all(_OF.loss_rows_ok(s) and s.shape == sl[0].shape for s in sl)
+                and all(t.shape == sl[0].shape for t in tl)):
+            # sum_t sum_k t_k lsm_k is linear in t: every student crop meets the SUM of the teacher crops, all crops in one
+            # launch (row r of the stacked crops reads teacher row r % B)
+            tsum = tl[0] if len(tl) == 1 else torch.stack([t.float() for t in tl]).sum(0)
+            s = sl[0] if len(sl) == 1 else torch.cat(sl, dim=0)
+            rows = _OF.SoftCrossEntropyFn.apply(s, tsum, self.student_temp)
+            return rows.sum() / sl[0].shape[0]
         total_loss = 0
         for s in student_output_list:
             lsm = F.log_softmax(s / self.student_temp, dim=-1)
@@ -146,6 +161,8 @@ class iBOTPatchLoss(_Centered):
     @torch.no_grad()
     def softmax_center_teacher(self, teacher_patch_tokens, teacher_temp):
         self.apply_center_update()
+        if FUSED_LOSS_ROWS and _OF.loss_rows_ok(teacher_patch_tokens):
+            return _OF.ops.softmax_center(teacher_patch_tokens, self.center, 1.0 / teacher_temp)
         return F.softmax((teacher_patch_tokens - self.center) / teacher_temp, dim=-1)
 
     @torch.no_grad()
@@ -163,6 +180,15 @@ class iBOTPatchLoss(_Centered):
     def forward_masked(self, student_patch_tokens_masked, teacher_patch_tokens_masked, student_masks_flat,
                        n_masked_patches=None, masks_weight=None):
         # ibot_patch_loss.py:26-34: the pure-torch lossfunc (the xformers cross_entropy twin is CUDA-only)
+        if (FUSED_LOSS_ROWS and _OF.loss_rows_ok(student_patch_tokens_masked) and student_patch_tokens_masked.dim() == 2
+                and teacher_patch_tokens_masked.shape == student_patch_tokens_masked.shape):
+            loss = -_OF.SoftCrossEntropyFn.apply(student_patch_tokens_masked, teacher_patch_tokens_masked, self.student_temp)
+            if masks_weight is None:
+                masks_weight = ((1 / student_masks_flat.sum(-1).clamp(min=1.0)).unsqueeze(-1)
+                                .expand_as(student_masks_flat)[student_masks_flat])
+            if n_masked_patches is not None:
+                loss = loss[:n_masked_patches]
+            return -(loss * masks_weight).sum() / student_masks_flat.shape[0]
         loss = torch.sum(teacher_patch_tokens_masked.float()
                          * F.log_softmax(student_patch_tokens_masked.float() / self.student_temp, dim=-1), dim=-1)
         if masks_weight is None:
