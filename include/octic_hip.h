@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 18
+#define OCTIC_ABI_VERSION 19
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -390,6 +390,24 @@ int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const f
                              int64_t rows_per_scale, float* out, int64_t rows, int d, void* stream);
 int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, void* stream);
+
+/* The same four row kernels with a ROW MAP (int32 [rows]): the compact rows 0..rows-1 of a branch correspond to rows
+ * rowmap[r] of a larger f32 tensor - the residual stream (or its cotangent) of which the branch sees only the kept samples:
+ * DINOv2's batch-subset stochastic depth (dinov2/layers/block.py:113-140: x[brange] in, index_add back) without the gather
+ * and scatter passes.  _fwd_rows reads x[rowmap[r]] (and, xcopy != NULL, leaves the rows as read in a compact copy: what the
+ * backward needs once the stream has been edited in place); scale_residual_fwd_rows writes out[rowmap[r]] = x[r] + rs gamma
+ * y[r]; scale_residual_bwd_rows reads gout[rowmap[r]]; layernorm_bwd_rows reads dres[rowmap[r]] and writes dx[rowmap[r]]
+ * (dres == dx edits the stream's cotangent in place).  rowmap == NULL: the plain kernels.  Rows of a map must be distinct. */
+int octic_dense_layernorm_fwd_rows(const float* x, void* y, int y_dtype, const float* w, const float* b, float* stats,
+                                   int64_t rows, int d, float eps, const int* rowmap, float* xcopy, void* stream);
+int octic_dense_layernorm_bwd_rows(const void* gy, int g_dtype, const float* x, const float* w, const float* stats,
+                                   const float* dres, float* dx, float* partials, int64_t rows, int d, const int* rowmap,
+                                   void* stream);
+int octic_scale_residual_fwd_rows(const float* x, const void* y, int y_dtype, const float* gamma, const float* rs,
+                                  int64_t rows_per_scale, float* out, int64_t rows, int d, const int* rowmap, void* stream);
+int octic_scale_residual_bwd_rows(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
+                                  int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, const int* rowmap,
+                                  void* stream);
 
 /* bf16 operand copies of nn.Linear weights [N,K] for octic_dense_gemm_nt, all layers in one launch (what autocast's
  * per-use weight casts amount to, deit/engine.py:56): wb = bf16(src) [N,K] (may be NULL) and wt = bf16(src)^T [K,N]

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("OCTIC_LIB") or os.path.join(HERE, "liboctic_hip.so") 
 HEADER_PATH = os.path.join(HERE, "..", "include", "octic_hip.h")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 # knobs of octic_route_override (include/octic_hip.h)
 (ROUTE_DENSE_TILE, ROUTE_DENSE_SPLIT, ROUTE_WGRAD_SLABS, ROUTE_WGRAD_TILE, ROUTE_LINEAR_RING, ROUTE_RING_EVEN,
  ROUTE_ATTN_LEGACY, ROUTE_ATTN_ONLINE, ROUTE_ATTN_BWD_PAIR) = range(9)
@@ -71,6 +71,14 @@ _PROTOS = {
     "octic_dense_finish_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "octic_dense_gelu_blocks": (c_int, []),
     "octic_dense_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "octic_dense_layernorm_fwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float,
+                                               c_void_p, c_void_p, c_void_p]),
+    "octic_dense_layernorm_bwd_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                                               c_int, c_void_p, c_void_p]),
+    "octic_scale_residual_fwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int,
+                                              c_void_p, c_void_p]),
+    "octic_scale_residual_bwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64,
+                                              c_int, c_void_p, c_void_p]),
     "octic_softmax_center": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_float, c_void_p, c_i64, c_int, c_void_p]),
     "octic_soft_ce_fwd": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                                   c_void_p]),

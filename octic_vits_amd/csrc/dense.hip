@@ -39,7 +39,11 @@ __device__ inline float hsum(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 template <typename TOUT, int NV>
 __global__ __launch_bounds__(256) void dense_ln_fwd_kernel(const float* __restrict__ x, TOUT* __restrict__ y,
                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                           float* __restrict__ stats, long rows, int d, float eps) {
+                                                           float* __restrict__ stats, long rows, int d, float eps,
+                                                           const int* __restrict__ rowmap = nullptr,
+                                                           float* __restrict__ xcopy = nullptr) {
+  // rowmap: row r of y / stats / xcopy is row rowmap[r] of x (batch-subset stochastic depth: the kept samples of a stream);
+  // xcopy: the rows as read, compact (what the backward needs once the stream has been edited in place)
   const int lane = threadIdx.x & 63;
   const long nw = (long)gridDim.x * 4;
   f32x4 wv[NV], bv[NV];
@@ -53,13 +57,18 @@ __global__ __launch_bounds__(256) void dense_ln_fwd_kernel(const float* __restri
   }
   const float inv_d = 1.0f / (float)d;
   for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
-    const float* xr = x + r * d;
+    const float* xr = x + (rowmap ? (long)rowmap[r] : r) * d;
     f32x4 xv[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       xv[i] = ok[i] ? *(const f32x4*)(xr + (i * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       s += hsum(xv[i]);
+    }
+    if (xcopy) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (ok[i]) *(f32x4*)(xcopy + r * d + (i * 64 + lane) * 4) = xv[i];
     }
     const float mean = wave_total(s) * inv_d;
     float q = 0.f;
@@ -191,7 +200,8 @@ template <typename TG, int NV>
 __global__ __launch_bounds__(kDenseWaves * 64, 4) void dense_ln_bwd_kernel(
     const TG* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
-    float* __restrict__ partials, long rows, int d) {
+    float* __restrict__ partials, long rows, int d, const int* __restrict__ rowmap = nullptr) {
+  // rowmap: dres and dx are rows rowmap[r] of a larger tensor (the stream's cotangent, edited in place when dres == dx)
   extern __shared__ float lds[];             // [2][d] slab image | [d] weights (kept out of the register budget)
   const int lane = threadIdx.x & 63;
   const long nw = (long)gridDim.x * kDenseWaves;
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(kDenseWaves * 64, 4) void dense_ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       if (ok[i]) {
-        const long o = r * d + (i * 64 + lane) * 4;
+        const long o = (rowmap ? (long)rowmap[r] : r) * d + (i * 64 + lane) * 4;
         f32x4 v = (g[i] - m1 - xh[i] * m2) * rstd;
         if (dres) v += *(const f32x4*)(dres + o);
         *(f32x4*)(dx + o) = v;
@@ -249,7 +259,7 @@ template <typename TG, int NV>
 __global__ __launch_bounds__(OCTIC_DLNBWD_WAVES * 64, OCTIC_DLNBWD_WAVES / 4) void dense_ln_bwd_wide_kernel(
     const TG* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ stats, const float* __restrict__ dres, float* __restrict__ dx,
-    float* __restrict__ partials, long rows, int d) {
+    float* __restrict__ partials, long rows, int d, const int* __restrict__ rowmap = nullptr) {
   extern __shared__ float lds[];             // [2][d] slab image | [d] weights
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   const long nw = (long)gridDim.x * nwaves;
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(OCTIC_DLNBWD_WAVES * 64, OCTIC_DLNBWD_WAVES / 4) vo
   const float inv_d = 1.0f / (float)d;
   for (long r = (long)blockIdx.x * nwaves + (threadIdx.x >> 6); r < rows; r += nw) {
     const long o = r * d + lane * 4;
+    const long om = (rowmap ? (long)rowmap[r] : r) * d + lane * 4;      // row of dres / dx
     f32x4 xh[NV], g[NV], dr[NV];
     typename Row4<TG>::vec gr[NV];
 #pragma unroll
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(OCTIC_DLNBWD_WAVES * 64, OCTIC_DLNBWD_WAVES / 4) vo
 #pragma unroll
     for (int i = 0; i < NV; ++i) gr[i] = Row4<TG>::load_raw(gy + o + i * 256);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) dr[i] = dres ? *(const f32x4*)(dres + o + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NV; ++i) dr[i] = dres ? *(const f32x4*)(dres + om + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float mean = stats[2 * r], rstd = stats[2 * r + 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(OCTIC_DLNBWD_WAVES * 64, OCTIC_DLNBWD_WAVES / 4) vo
     for (int i = 0; i < NV; ++i) {
       f32x4 v = (g[i] - m1 - xh[i] * m2) * rstd;
       if (dres) v += dr[i];
-      *(f32x4*)(dx + o + i * 256) = v;
+      *(f32x4*)(dx + om + i * 256) = v;
     }
   }
   if (partials) slab_reduce<NV>(lds, partials + (long)blockIdx.x * 2 * d, pw, pb, ok, d);
@@ -375,7 +386,9 @@ template <typename TY>
 __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const float* __restrict__ x, const TY* __restrict__ y,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ rs, long rps,
-                                                                 float* __restrict__ out, long rows, int d) {
+                                                                 float* __restrict__ out, long rows, int d,
+                                                                 const int* __restrict__ rowmap = nullptr) {
+  // rowmap: row r of the result is row rowmap[r] of `out` (the kept samples written back into the stream)
   const int d4 = d >> 2;
   const long n4 = rows * d4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -383,7 +396,8 @@ __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const float* __
     const int col = (int)(i - r * d4) * 4;
     f32x4 s = gamma ? *(const f32x4*)(gamma + col) : f32x4{1.f, 1.f, 1.f, 1.f};
     if (rs) s *= rs[r / rps];
-    *(f32x4*)(out + i * 4) = *(const f32x4*)(x + i * 4) + s * Row4<TY>::load(y + i * 4);
+    const long io = rowmap ? (long)rowmap[r] * d + col : i * 4;
+    *(f32x4*)(out + io) = *(const f32x4*)(x + i * 4) + s * Row4<TY>::load(y + i * 4);
   }
 }
 
@@ -391,7 +405,9 @@ __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const float* __
 template <typename TY, int NV>
 __global__ __launch_bounds__(kDenseWaves * 64) void scale_residual_bwd_kernel(
     const float* __restrict__ gout, const TY* __restrict__ y, const float* __restrict__ gamma,
-    const float* __restrict__ rs, long rps, TY* __restrict__ gy, float* __restrict__ partials, long rows, int d) {
+    const float* __restrict__ rs, long rps, TY* __restrict__ gy, float* __restrict__ partials, long rows, int d,
+    const int* __restrict__ rowmap = nullptr) {
+  // rowmap: row r of the cotangent is row rowmap[r] of gout (the stream's cotangent; y, gy and rs stay compact)
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const long nw = (long)gridDim.x * kDenseWaves;
@@ -411,10 +427,11 @@ __global__ __launch_bounds__(kDenseWaves * 64) void scale_residual_bwd_kernel(
     for (long r = (long)blockIdx.x * kDenseWaves + (threadIdx.x >> 6); r < rows; r += nw) {
       const float s = rs ? rs[r / rps] : 1.f;
       const long o = r * d + lane * 4;
+      const long og = (rowmap ? (long)rowmap[r] : r) * d + lane * 4;
       f32x4 g[NV];
       typename Row4<TY>::vec yv[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) g[i] = *(const f32x4*)(gout + o + i * 256);
+      for (int i = 0; i < NV; ++i) g[i] = *(const f32x4*)(gout + og + i * 256);
 #pragma unroll
       for (int i = 0; i < NV; ++i) yv[i] = Row4<TY>::load_raw(y + o + i * 256);
 #pragma unroll
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(kDenseWaves * 64) void scale_residual_bwd_kernel(
       for (int i = 0; i < NV; ++i)
         if (ok[i]) {
           const long o = r * d + (i * 64 + lane) * 4;
-          f32x4 g = *(const f32x4*)(gout + o) * s;
+          f32x4 g = *(const f32x4*)(gout + (rowmap ? (long)rowmap[r] : r) * d + (i * 64 + lane) * 4) * s;
           p1[i] += g;
           if (partials) p0[i] += g * Row4<TY>::load(y + o);
           Row4<TY>::store(gy + o, g * gm[i]);
@@ -704,6 +721,11 @@ extern "C" {
 
 int octic_dense_layernorm_fwd(const float* x, void* y, int y_dtype, const float* w, const float* b, float* stats,
                               int64_t rows, int d, float eps, void* stream) {
+  return octic_dense_layernorm_fwd_rows(x, y, y_dtype, w, b, stats, rows, d, eps, nullptr, nullptr, stream);
+}
+
+int octic_dense_layernorm_fwd_rows(const float* x, void* y, int y_dtype, const float* w, const float* b, float* stats,
+                                   int64_t rows, int d, float eps, const int* rowmap, float* xcopy, void* stream) {
   if (rows == 0) return OCTIC_OK;
   if (!x || !y || !stats) return OCTIC_ENULL;
   if (int e = dense_check(rows, d)) return e;
@@ -712,9 +734,9 @@ int octic_dense_layernorm_fwd(const float* x, void* y, int y_dtype, const float*
   if (blocks > 4096) blocks = 4096;
   hipStream_t s = (hipStream_t)stream;
   if (y_dtype == OCTIC_BF16) {
-    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_fwd_kernel<bf16, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (bf16*)y, w, b, stats, rows, d, eps)));
+    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_fwd_kernel<bf16, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (bf16*)y, w, b, stats, rows, d, eps, rowmap, xcopy)));
   } else {
-    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_fwd_kernel<float, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (float*)y, w, b, stats, rows, d, eps)));
+    DENSE_NV_SWITCH(dense_nv(d), (dense_ln_fwd_kernel<float, NV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (float*)y, w, b, stats, rows, d, eps, rowmap, xcopy)));
   }
   return launch_status();
 }
@@ -746,6 +768,12 @@ int octic_dense_blocks(int64_t rows) { return dense_blocks(rows); }
 
 int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const float* w, const float* stats,
                               const float* dres, float* dx, float* partials, int64_t rows, int d, void* stream) {
+  return octic_dense_layernorm_bwd_rows(gy, g_dtype, x, w, stats, dres, dx, partials, rows, d, nullptr, stream);
+}
+
+int octic_dense_layernorm_bwd_rows(const void* gy, int g_dtype, const float* x, const float* w, const float* stats,
+                                   const float* dres, float* dx, float* partials, int64_t rows, int d, const int* rowmap,
+                                   void* stream) {
   if (rows == 0) return OCTIC_OK;
   if (!gy || !x || !stats || !dx) return OCTIC_ENULL;
   if (int e = dense_check(rows, d)) return e;
@@ -756,19 +784,19 @@ int octic_dense_layernorm_bwd(const void* gy, int g_dtype, const float* x, const
   if (d == dense_nv(d) * 256 && dense_nv(d) <= 6) {      // whole-chunk rows: the unpredicated eight-wave kernel
     if (g_dtype == OCTIC_BF16) {
       DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<bf16, NV><<<dim3(blocks), dim3(OCTIC_DLNBWD_WAVES * 64), lds, s>>>((const bf16*)gy, x, w, stats, dres, dx,
-                                                            partials, rows, d)));
+                                                            partials, rows, d, rowmap)));
     } else {
       DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_wide_kernel<float, NV><<<dim3(blocks), dim3(OCTIC_DLNBWD_WAVES * 64), lds, s>>>((const float*)gy, x, w, stats, dres, dx,
-                                                             partials, rows, d)));
+                                                             partials, rows, d, rowmap)));
     }
     return launch_status();
   }
   if (g_dtype == OCTIC_BF16) {
     DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_kernel<bf16, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>((const bf16*)gy, x, w, stats, dres,
-                                                     dx, partials, rows, d)));
+                                                     dx, partials, rows, d, rowmap)));
   } else {
     DENSE_NV_SWITCH(dense_nv(d), (dense_ln_bwd_kernel<float, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>((const float*)gy, x, w, stats,
-                                                     dres, dx, partials, rows, d)));
+                                                     dres, dx, partials, rows, d, rowmap)));
   }
   return launch_status();
 }
@@ -842,6 +870,11 @@ int octic_dense_gelu_bwd(const void* h, const void* g, void* dh, float* partials
 
 int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, float* out, int64_t rows, int d, void* stream) {
+  return octic_scale_residual_fwd_rows(x, y, y_dtype, gamma, rs, rows_per_scale, out, rows, d, nullptr, stream);
+}
+
+int octic_scale_residual_fwd_rows(const float* x, const void* y, int y_dtype, const float* gamma, const float* rs,
+                                  int64_t rows_per_scale, float* out, int64_t rows, int d, const int* rowmap, void* stream) {
   if (rows == 0) return OCTIC_OK;
   if (!x || !y || !out) return OCTIC_ENULL;
   if (int e = dense_check(rows, d)) return e;
@@ -853,15 +886,21 @@ int octic_scale_residual_fwd(const float* x, const void* y, int y_dtype, const f
   hipStream_t s = (hipStream_t)stream;
   if (y_dtype == OCTIC_BF16)
     scale_residual_fwd_kernel<bf16><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (const bf16*)y,
-                       gamma, rs, rows_per_scale, out, rows, d);
+                       gamma, rs, rows_per_scale, out, rows, d, rowmap);
   else
     scale_residual_fwd_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (const float*)y,
-                       gamma, rs, rows_per_scale, out, rows, d);
+                       gamma, rs, rows_per_scale, out, rows, d, rowmap);
   return launch_status();
 }
 
 int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
                              int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, void* stream) {
+  return octic_scale_residual_bwd_rows(gout, y, y_dtype, gamma, rs, rows_per_scale, gy, partials, rows, d, nullptr, stream);
+}
+
+int octic_scale_residual_bwd_rows(const float* gout, const void* y, int y_dtype, const float* gamma, const float* rs,
+                                  int64_t rows_per_scale, void* gy, float* partials, int64_t rows, int d, const int* rowmap,
+                                  void* stream) {
   if (rows == 0) return OCTIC_OK;
   if (!gout || !gy || (partials && !y)) return OCTIC_ENULL;
   if (int e = dense_check(rows, d)) return e;
@@ -872,10 +911,10 @@ int octic_scale_residual_bwd(const float* gout, const void* y, int y_dtype, cons
   hipStream_t s = (hipStream_t)stream;
   if (y_dtype == OCTIC_BF16) {
     DENSE_NV_SWITCH(dense_nv(d), (scale_residual_bwd_kernel<bf16, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>(gout, (const bf16*)y, gamma, rs,
-                                                     rows_per_scale, (bf16*)gy, partials, rows, d)));
+                                                     rows_per_scale, (bf16*)gy, partials, rows, d, rowmap)));
   } else {
     DENSE_NV_SWITCH(dense_nv(d), (scale_residual_bwd_kernel<float, NV><<<dim3(blocks), dim3(kDenseWaves * 64), lds, s>>>(gout, (const float*)y, gamma, rs,
-                                                     rows_per_scale, (float*)gy, partials, rows, d)));
+                                                     rows_per_scale, (float*)gy, partials, rows, d, rowmap)));
   }
   return launch_status();
 }

@@ -166,9 +166,12 @@ class OcticDinoVisionTransformer(OcticVisionTransformer):
             if self.training:                        # every random draw of the pass up front: a handful of launches
                 brk, dev = self.depth // 2, rows.device
                 rag.draw_masks([d for b in self.blocks[:brk] for d in (b.drop_path1, b.drop_path2)], dev)
-                n = 2 * sum(1 for b in self.blocks[brk:] if b.sample_drop_ratio > 0.1)
-                if n:
-                    rag.draw_perms(n, dev)
+                sub = [b for b in self.blocks[brk:] if b.sample_drop_ratio > 0.1]
+                if sub:
+                    ratios = {b.sample_drop_ratio for b in sub}
+                    keeps = ([max(int(B * (1 - sub[0].sample_drop_ratio)), 1) for B, _, _ in rag.sets]
+                             if len(ratios) == 1 else None)        # one ratio for all blocks (the reference's uniform dpr)
+                    rag.draw_perms(2 * len(sub), dev, keeps)
             t = Octic(rows, c)
             for blk in self.blocks[:self.depth // 2]:
                 t = blk(t)

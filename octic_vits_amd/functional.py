@@ -580,6 +580,54 @@ class DenseLayerNormFn(torch.autograd.Function):
         return dx, (dw if ctx.has_w else None), (db if ctx.has_b else None), None, None
 
 
+class RowsTo:
+    """Where the tail of a branch that saw only some rows of the residual stream puts its result: rows `rowmap[r]` of
+    `stream` (int32 map, one entry per compact row), in place.  `link` carries the stream's cotangent from the tail's backward
+    to the LayerNorm's (DenseLayerNormRowsFn), which edits it in place - DINOv2's batch-subset stochastic depth
+    (dinov2/layers/block.py:113-140) without gather / scatter passes."""
+    __slots__ = ("stream", "rowmap", "link")
+
+    def __init__(self, stream, rowmap, link):
+        self.stream, self.rowmap, self.link = stream, rowmap, link
+
+
+class _Link:
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
+class DenseLayerNormRowsFn(torch.autograd.Function):
+    """LayerNorm of rows rowmap[r] of the f32 stream -> (y compute dtype, xa f32): both compact [1, rows, d]; xa = the rows as
+    read (the residual input of the branch's tail, and what the backward needs after the stream was edited in place).
+    Backward: the stream's cotangent g arrives through `link` (set by the tail's backward, which returns no gradient for xa);
+    g[rowmap[r]] = LN'(gy[r]) + g[rowmap[r]] in place, and g is returned as the gradient of the stream."""
+
+    @staticmethod
+    def forward(ctx, stream, rowmap, w, b, eps, out_dtype, link):
+        if stream.dtype != torch.float32 or not stream.is_contiguous():
+            raise ValueError("DenseLayerNormRowsFn: the stream must be a contiguous f32 tensor (it is edited in place)")
+        w32 = None if w is None else _c(w.detach().float())
+        b32 = None if b is None else _c(b.detach().float())
+        y, stats, xa = ops.dense_layernorm_fwd_rows(stream, rowmap, w32, b32, eps, out_dtype)
+        ctx.save_for_backward(xa, stats, w32, rowmap)
+        ctx.has_w, ctx.has_b, ctx.link = w is not None, b is not None, link
+        ctx.set_materialize_grads(False)
+        return y, xa
+
+    @staticmethod
+    def backward(ctx, gy, gxa):
+        xa, stats, w32, rowmap = ctx.saved_tensors
+        g, ctx.link.g = ctx.link.g, None
+        if g is None or gxa is not None or gy is None:
+            raise RuntimeError("DenseLayerNormRowsFn: expects the stream cotangent through its link (RowsTo tail) and no direct "
+                               "gradient for the compact rows")
+        want = ctx.has_w and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        dw, db = ops.dense_layernorm_bwd_rows_(_c(gy), xa, w32, stats, g, rowmap, want_param_grads=want)
+        return g, None, (dw if ctx.has_w else None), (db if ctx.has_b else None), None, None, None
+
+
 class DenseLinearFn(torch.autograd.Function):
     """nn.Linear on the BLAS library with cached compute-dtype weights (no per-step cast kernels in the graph)."""
 
@@ -899,10 +947,12 @@ class DenseProjResidFn(torch.autograd.Function):
     fused epilogue; backward = one HIP row pass (gy, d gamma, bias gradient) + the input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, a, w, b, gamma, rs, rps, cache, nw=None, nb=None, neps=None, pair=None):
+    def forward(ctx, x, a, w, b, gamma, rs, rps, cache, nw=None, nb=None, neps=None, pair=None, rows_to=None, stream=None):
         """neps is not None: also return LayerNorm(out; nw, nb, neps) in bf16 - the norm that opens the next branch - from
-        the same row pass that adds the residual (NEXT_NORM_FUSED)."""
+        the same row pass that adds the residual (NEXT_NORM_FUSED).  rows_to (RowsTo; stream = rows_to.stream, passed as a
+        tensor so that autograd sees the in-place edit): x are compact rows of the stream, the result goes back into it."""
         ctx.pair = pair
+        ctx.rows_to = rows_to
         x = _c(x)
         ab = _c(a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16))
         wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP and ctx.needs_input_grad[1])
@@ -919,6 +969,13 @@ class DenseProjResidFn(torch.autograd.Function):
             ctx.meta = (rps, b is not None, gamma is not None, a.dtype, a.shape, nw is not None, nb is not None)
             ctx.set_materialize_grads(False)
             return out.view(x.shape), yn.view(x.shape)
+        if rows_to is not None:
+            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>")
+            ops.scale_residual_fwd_rows_(stream, rows_to.rowmap, x.view(-1, wb.shape[0]), y, g32, rs32, rps)
+            ctx.save_for_backward(a2, wb, wt, y, g32, rs32, rows_to.rowmap)
+            ctx.meta = (rps, b is not None, gamma is not None, a.dtype, a.shape)
+            ctx.mark_dirty(stream)
+            return stream
         if DENSE_RESID_FUSED:
             y, out = ops.dense_gemm_nt(a2, wb, 2, bias=_f32(b), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, wb.shape[0]),
                                        name="dense_nt_kernel<resid>")
@@ -948,6 +1005,14 @@ class DenseProjResidFn(torch.autograd.Function):
                 else:
                     gout, dnw, dnb = ops.dense_layernorm_bwd(g2, out, nw32, stats, dres, want_param_grads=want)
                 dnw, dnb = (dnw if has_nw else None), (dnb if has_nb else None)
+        elif ctx.rows_to is not None:
+            a2, wb, wt, y, g32, rs32, rowmap = ctx.saved_tensors
+            rps, has_b, has_gamma, a_dtype, a_shape = ctx.meta
+            gout = _c(gout.float())
+            ctx.rows_to.link.g = gout             # the LayerNorm of this branch edits it in place and hands it on
+            gy, dgamma, colsum = ops.scale_residual_bwd(gout, y, g32, rs32, rps, want_gamma=has_gamma, want_colsum=has_b,
+                                                        rowmap=rowmap)
+            tail_done = True
         else:
             a2, wb, wt, y, g32, rs32 = ctx.saved_tensors
             rps, has_b, has_gamma, a_dtype, a_shape = ctx.meta
@@ -963,7 +1028,8 @@ class DenseProjResidFn(torch.autograd.Function):
             dw = ctx.pair.park(gy, a2)           # written by the qkv weight gradient's launch (or at the end of the pass)
         else:
             dw = _wgrad_lib(gy, a2)
-        return gout.view(ctx.x_shape), ga, dw, colsum, dgamma, None, None, None, dnw, dnb, None, None
+        gx = None if ctx.rows_to is not None else gout.view(ctx.x_shape)
+        return gx, ga, dw, colsum, dgamma, None, None, None, dnw, dnb, None, None, None, None
 
 
 class DenseMlpFn(torch.autograd.Function):
@@ -974,9 +1040,10 @@ class DenseMlpFn(torch.autograd.Function):
     csrc/dense_wgrad.hip (WGRAD_HIP)."""
 
     @staticmethod
-    def forward(ctx, y, x, w1, b1, w2, b2, gamma, rs, rps, c1, c2, nw=None, nb=None, neps=None):
+    def forward(ctx, y, x, w1, b1, w2, b2, gamma, rs, rps, c1, c2, nw=None, nb=None, neps=None, rows_to=None, stream=None):
         """neps is not None: also return LayerNorm(out; nw, nb, neps) in bf16 (the NEXT block's norm1) from the row pass
-        that adds the residual."""
+        that adds the residual.  rows_to / stream: as in DenseProjResidFn."""
+        ctx.rows_to = rows_to
         x = _c(x)
         yb = _c(y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16))
         need_t = any(ctx.needs_input_grad[:2])            # (an inference pass - the DINOv2 teacher - never transposes)
@@ -1005,6 +1072,14 @@ class DenseMlpFn(torch.autograd.Function):
             ctx.meta = (rps, b1 is not None, b2 is not None, gamma is not None, y.dtype, y.shape, nw is not None, nb is not None)
             ctx.set_materialize_grads(False)
             return out.view(x.shape), yn.view(x.shape)
+        if rows_to is not None:
+            br = (ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>") if "fc2" in DENSE_HIP
+                  else _linear_lib(a, w2b, None if b2 is None else c2.b))
+            ops.scale_residual_fwd_rows_(stream, rows_to.rowmap, x.view(-1, w2b.shape[0]), br, g32, rs32, rps)
+            ctx.save_for_backward(y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32, rows_to.rowmap)
+            ctx.meta = (rps, b1 is not None, b2 is not None, gamma is not None, y.dtype, y.shape)
+            ctx.mark_dirty(stream)
+            return stream
         if "fc2" in DENSE_HIP and DENSE_RESID_FUSED:
             br, out = ops.dense_gemm_nt(a, w2b, 2, bias=_f32(b2), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, w2b.shape[0]),
                                         name="dense_nt_kernel<resid>")
@@ -1037,6 +1112,14 @@ class DenseMlpFn(torch.autograd.Function):
                 else:
                     gout, dnw, dnb = ops.dense_layernorm_bwd(g2, out, nw32, stats, dres, want_param_grads=want)
                 dnw, dnb = (dnw if has_nw else None), (dnb if has_nb else None)
+        elif ctx.rows_to is not None:
+            y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32, rowmap = ctx.saved_tensors
+            rps, has_b1, has_b2, has_gamma, y_dtype, y_shape = ctx.meta
+            gout = _c(gout.float())
+            ctx.rows_to.link.g = gout
+            gbr, dgamma, db2 = ops.scale_residual_bwd(gout, br, g32, rs32, rps, want_gamma=has_gamma, want_colsum=has_b2,
+                                                      rowmap=rowmap)
+            tail_done = True
         else:
             y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32 = ctx.saved_tensors
             rps, has_b1, has_b2, has_gamma, y_dtype, y_shape = ctx.meta
@@ -1058,7 +1141,8 @@ class DenseMlpFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>") if w1t is not None
                   else _mm_lib(dh, w1b)).view(y_shape).to(y_dtype)
-        return gy, gout.view(ctx.x_shape), gw1, db1, gw2, db2, dgamma, None, None, None, None, dnw, dnb, None
+        gx = None if ctx.rows_to is not None else gout.view(ctx.x_shape)
+        return gy, gx, gw1, db1, gw2, db2, dgamma, None, None, None, None, dnw, dnb, None, None, None
 
 
 # -------------------------------------------------------------------------------------- hand-off

@@ -751,6 +751,46 @@ def dense_layernorm_fwd(x, w, b, eps, out_dtype):
     return y, stats
 
 
+def _check_rowmap(rowmap, rows):
+    if rowmap.dtype != torch.int32 or not rowmap.is_contiguous() or rowmap.numel() != rows:
+        raise ValueError("row map: a contiguous int32 tensor with one entry per compact row")
+
+
+def dense_layernorm_fwd_rows(x, rowmap, w, b, eps, out_dtype):
+    """LayerNorm of rows rowmap[r] of the f32 stream x [..., d] -> (y [1, rows, d] out_dtype, stats, xa = those rows, compact)."""
+    _require_cuda(x)
+    d = x.shape[-1]
+    rows = rowmap.numel()
+    _check_rowmap(rowmap, rows)
+    y = torch.empty((1, rows, d), dtype=out_dtype, device=x.device)
+    xa = torch.empty((1, rows, d), dtype=torch.float32, device=x.device)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_layernorm_fwd_rows(_p(x), _p(y), dt_code(out_dtype), _p(w), _p(b), _p(stats), rows, d, float(eps),
+                                               _p(rowmap), _p(xa), _stream(x)))
+    KERNEL_TIMER.stop(t, f"dense_ln_fwd_kernel<{_DTN[out_dtype]},rows>", rows * d * (8 + y.element_size()))
+    return y, stats, xa
+
+
+def dense_layernorm_bwd_rows_(gy, xa, w, stats, g, rowmap, want_param_grads=True):
+    """In place on the stream's cotangent g: g[rowmap[r]] = LN'(gy[r]; xa[r]) + g[rowmap[r]].  Returns (dw, db)."""
+    d = xa.shape[-1]
+    rows = rowmap.numel()
+    _check_rowmap(rowmap, rows)
+    nblk = lib().octic_dense_blocks(rows)
+    partials = torch.empty((nblk, 2, d), dtype=torch.float32, device=xa.device) if want_param_grads else None
+    t = KERNEL_TIMER.start()
+    check(lib().octic_dense_layernorm_bwd_rows(_p(gy), dt_code(gy.dtype), _p(xa), _p(w), _p(stats), _p(g), _p(g), _p(partials),
+                                               rows, d, _p(rowmap), _stream(xa)))
+    KERNEL_TIMER.stop(t, f"dense_ln_bwd_kernel<{_DTN[gy.dtype]},rows>", rows * d * (gy.element_size() + 12))
+    if not want_param_grads:
+        return None, None
+    dw = torch.empty(d, dtype=torch.float32, device=xa.device)
+    db = torch.empty(d, dtype=torch.float32, device=xa.device)
+    _finish(partials, nblk, d, dw, db, None, _stream(xa))
+    return dw, db
+
+
 def dense_resid_layernorm_fwd(x, yb, gamma, rs, rps, w, b, eps, out_dtype):
     """xout = x + rs[row // rps] * gamma * yb ; y = LayerNorm(xout) in one row pass -> (xout f32, y out_dtype, stats)."""
     _require_cuda(x)
@@ -882,17 +922,33 @@ def scale_residual_fwd(x, y, gamma, rs, rps):
     return out
 
 
-def scale_residual_bwd(gout, y, gamma, rs, rps, want_gamma=True, want_colsum=True):
-    """Returns (gy in y's dtype, dgamma, gamma * colsum(rs*gout) = bias gradient of the producer of y)."""
+def scale_residual_fwd_rows_(stream, rowmap, x, y, gamma, rs, rps):
+    """In place on the f32 stream: stream[rowmap[r]] = x[r] + rs[r // rps] * gamma * y[r]  (x, y compact)."""
+    _require_cuda(x)
+    d = x.shape[-1]
+    rows = rowmap.numel()
+    _check_rowmap(rowmap, rows)
+    t = KERNEL_TIMER.start()
+    check(lib().octic_scale_residual_fwd_rows(_p(x), _p(y), dt_code(y.dtype), _p(gamma), _p(rs), int(rps), _p(stream), rows, d,
+                                              _p(rowmap), _stream(x)))
+    KERNEL_TIMER.stop(t, f"scale_residual_fwd_kernel<{_DTN[y.dtype]},rows>", rows * d * (8 + y.element_size()))
+    return stream
+
+
+def scale_residual_bwd(gout, y, gamma, rs, rps, want_gamma=True, want_colsum=True, rowmap=None):
+    """Returns (gy in y's dtype, dgamma, gamma * colsum(rs*gout) = bias gradient of the producer of y).  rowmap: the compact
+    rows of y are rows rowmap[r] of gout (the cotangent of a stream of which the branch saw a subset)."""
     d = gout.shape[-1]
-    rows = gout.numel() // d
-    gy = torch.empty(gout.shape, dtype=y.dtype, device=gout.device)
+    rows = gout.numel() // d if rowmap is None else rowmap.numel()
+    if rowmap is not None:
+        _check_rowmap(rowmap, rows)
+    gy = torch.empty(gout.shape if rowmap is None else y.shape, dtype=y.dtype, device=gout.device)
     nblk = lib().octic_dense_blocks(rows)
     want = want_gamma or want_colsum
     partials = torch.empty((nblk, 2, d), dtype=torch.float32, device=gout.device) if want else None
     t = KERNEL_TIMER.start()
-    check(lib().octic_scale_residual_bwd(_p(gout), _p(y), dt_code(y.dtype), _p(gamma), _p(rs), int(rps), _p(gy),
-                                         _p(partials), rows, d, _stream(gout)))
+    check(lib().octic_scale_residual_bwd_rows(_p(gout), _p(y), dt_code(y.dtype), _p(gamma), _p(rs), int(rps), _p(gy),
+                                              _p(partials), rows, d, _p(rowmap), _stream(gout)))
     KERNEL_TIMER.stop(t, f"scale_residual_bwd_kernel<{_DTN[y.dtype]}>", rows * d * (4 + 2 * y.element_size()))
     if not want:
         return gy, None, None

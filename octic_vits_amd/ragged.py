@@ -21,7 +21,7 @@ _CONST_SCALES = {}         # (sets, per-set constants, device) -> [R] f32 per-ro
 
 
 class Ragged:
-    __slots__ = ("sets", "rows", "samples", "masks", "perms", "perm_at")
+    __slots__ = ("sets", "rows", "samples", "masks", "perms", "perm_at", "rowmaps", "map_keeps")
 
     def __init__(self, shapes):
         """shapes: [(B_i, T_i)]"""
@@ -32,6 +32,7 @@ class Ragged:
         self.rows = off
         self.samples = sum(b for b, _, _ in self.sets)
         self.masks, self.perms, self.perm_at = None, None, 0      # draws of one forward pass, made at once (draw_*)
+        self.rowmaps, self.map_keeps = None, None
 
     def matches(self, t):
         return t.dim() == 3 and t.shape[0] == 1 and t.shape[1] == self.rows
@@ -79,11 +80,28 @@ class Ragged:
         rows = m.index_select(1, self.row_to_sample(device))
         self.masks = {id(d): rows[i] for i, d in enumerate(live)}
 
-    def draw_perms(self, n, device):
+    def draw_perms(self, n, device, keeps=None):
         """n random permutations of every set's samples in two launches per set (argsort of uniforms) - what the batch-subset
-        stochastic depth of n branches would draw with n x sets torch.randperm calls."""
+        stochastic depth of n branches would draw with n x sets torch.randperm calls.  keeps (kept samples per set, the same
+        for all n branches): also the n ROW MAPS [n, sum_i keeps_i T_i] int32 - compact row (set-major, kept sample, token) ->
+        row of the full tensor - that let the LayerNorm / tail kernels read and write the kept rows in place."""
         self.perms = [torch.rand(n, B, device=device).argsort(dim=1) for B, _, _ in self.sets]
         self.perm_at = 0
+        self.rowmaps, self.map_keeps = None, None
+        if keeps is not None:
+            parts = []
+            for p, k, (B, T, off) in zip(self.perms, keeps, self.sets):
+                parts.append(((p[:, :k] * T).unsqueeze(2) + torch.arange(T, device=device)).reshape(n, k * T) + off)
+            self.rowmaps = torch.cat(parts, dim=1).to(torch.int32).contiguous()
+            self.map_keeps = tuple(int(k) for k in keeps)
+
+    def take_subset(self, keeps, device):
+        """The next branch's kept samples per set and, when the maps were drawn for these keeps, its row map."""
+        i = self.perm_at
+        idxs = self.take_perms(keeps, device)
+        if self.rowmaps is not None and i < self.rowmaps.shape[0] and tuple(int(k) for k in keeps) == self.map_keeps:
+            return idxs, self.rowmaps[i]
+        return idxs, None
 
     def take_perms(self, keeps, device):
         """The next branch's kept samples per set (idx_i = first keeps[i] entries of a random permutation)."""

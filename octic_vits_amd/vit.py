@@ -58,10 +58,21 @@ class Mlp(nn.Module):
         return (not drop and isinstance(self.norm, nn.Identity) and type(self.act) is nn.GELU
                 and self.act.approximate == "none" and type(self.fc1) is nn.Linear and type(self.fc2) is nn.Linear)
 
-    def forward_fused(self, y, xres, gamma, rs, dtype, next_norm=None):
+    def rows_ok(self, y):
+        """forward_fused takes `rows_to` for this input (the hand-written path runs)."""
+        return (_OF.dense_hip_ok(y, self.fc1.weight) and _OF.dense_hip_ok(y, self.fc2.weight)
+                and bool({"fc1", "fc2", "dfc1", "dfc2"} & _OF.DENSE_HIP))
+
+    def forward_fused(self, y, xres, gamma, rs, dtype, next_norm=None, rows_to=None):
         """xres + rs*gamma*fc2(gelu(fc1(y))) with y already normalised and in the compute dtype.  next_norm (an
-        nn.LayerNorm): the hand-written path also returns next_norm(result) from the residual row pass -> (x, y_next)."""
+        nn.LayerNorm): the hand-written path also returns next_norm(result) from the residual row pass -> (x, y_next).
+        rows_to (functional.RowsTo): y / xres are compact rows of a stream; the result is written back into it."""
         rps = _rows_per_scale(y, rs)
+        if rows_to is not None:
+            if not (dtype == torch.bfloat16 and self.rows_ok(y)) or next_norm is not None:
+                raise RuntimeError("Mlp.forward_fused: rows_to needs the hand-written bf16 path (check rows_ok first)")
+            return _OF.DenseMlpFn.apply(y, xres, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gamma,
+                                        rs, rps, self._c1, self._c2, None, None, None, rows_to, rows_to.stream)
         if (dtype == torch.bfloat16 and _OF.dense_hip_ok(y, self.fc1.weight) and _OF.dense_hip_ok(y, self.fc2.weight)
                 and ({"fc1", "fc2", "dfc1", "dfc2"} & _OF.DENSE_HIP)):
             if next_norm is not None:
@@ -100,9 +111,13 @@ class Attention(nn.Module):
         return (not drop and self.fused_attn and type(self.qkv) is nn.Linear and type(self.proj) is nn.Linear
                 and _ops.attn_supported(N, self.qkv.in_features // self.num_heads, dtype))
 
-    def forward_fused(self, y, xres, gamma, rs, dtype, next_norm=None):
+    def rows_ok(self, y):
+        return _OF.dense_hip_ok(y, self.proj.weight, "proj")
+
+    def forward_fused(self, y, xres, gamma, rs, dtype, next_norm=None, rows_to=None):
         """xres + rs*gamma*proj(attention(qkv(y))) with y already normalised and in the compute dtype.  next_norm (an
-        nn.LayerNorm): the hand-written path also returns next_norm(result) from the residual row pass -> (x, y_next)."""
+        nn.LayerNorm): the hand-written path also returns next_norm(result) from the residual row pass -> (x, y_next).
+        rows_to (functional.RowsTo): y / xres are compact rows of a stream; the result is written back into it."""
         B, N, C = y.shape
         hd = C // self.num_heads
         bf = dtype == torch.bfloat16
@@ -117,6 +132,11 @@ class Attention(nn.Module):
         else:
             a = _OF.AttnFusedQKVFn.apply(qkv.view(B, N, 3, self.num_heads, hd), hd ** -0.5)
         rps = _rows_per_scale(y, rs)
+        if rows_to is not None:
+            if not (bf and self.rows_ok(y)) or next_norm is not None:
+                raise RuntimeError("Attention.forward_fused: rows_to needs the hand-written bf16 path (check rows_ok first)")
+            return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, rps, self._c2,
+                                              None, None, None, self._wgpair, rows_to, rows_to.stream)
         if bf and _OF.dense_hip_ok(y, self.proj.weight, "proj"):
             if next_norm is not None:
                 return _OF.DenseProjResidFn.apply(xres, a, self.proj.weight, self.proj.bias, gamma, rs, rps, self._c2,
@@ -312,6 +332,7 @@ class Block(nn.Module):
 
 
 SUBSET_FUSED = True             # developer A/B: False = the eager composition of drop_add_residual_stochastic_depth
+ROW_MAPS = True                 # ragged pass: the subset's rows through row maps in the LayerNorm / tail kernels (False: gather + scatter)
 STREAM_OWNED = [False]          # set by a model's block loop: the tensors handed from block to block belong to the loop
 MemEffAttention = Attention     # dinov2.layers.MemEffAttention: same parameters; the HIP core replaces xformers
 
@@ -421,7 +442,15 @@ class NestedTensorBlock(Block):
             try:
                 _OF.RAGGED = sub
                 for norm, branch, gamma in ((self.norm1, self.attn, gammas[0]), (self.norm2, self.mlp, gammas[1])):
-                    idxs = rag.take_perms(keeps, x.device)
+                    idxs, rowmap = rag.take_subset(keeps, x.device)
+                    if rowmap is not None and ROW_MAPS and d % 4 == 0:
+                        # the kept rows read / written THROUGH a row map by the LayerNorm and the residual tail themselves
+                        link = _OF._Link()
+                        y, xa = _OF.DenseLayerNormRowsFn.apply(x, rowmap, norm.weight, norm.bias, norm.eps, bf, link)
+                        if branch.rows_ok(y):
+                            x = branch.forward_fused(y, xa, gamma, scale, bf, rows_to=_OF.RowsTo(x, rowmap, link))
+                            continue
+                        raise RuntimeError("NestedTensorBlock: the row-map path met a shape the dense kernels refuse")
                     link = _L._RowLink()
                     xa = _R.GatherSetsFn.apply(x, idxs, rag, sub, link)
                     y, xres = _OF.DenseLayerNormFn.apply(xa, norm.weight, norm.bias, norm.eps, bf)

@@ -209,6 +209,75 @@ def test_crop_sets_as_one_row_tensor_equal_the_set_by_set_loop():
         opt.step()
 
 
+def test_row_maps_equal_gather_and_scatter_bitwise():
+    """The batch-subset stochastic depth of the ragged pass with the kept rows read / written through row maps inside the
+    LayerNorm and residual-tail kernels (vit.ROW_MAPS) against explicit gather / scatter passes: same draws (same seed), same
+    arithmetic per element -> outputs and every gradient bit for bit."""
+    from octic_vits_amd import vit
+    torch.manual_seed(0)
+    net = _hd64_backbone(drop_path=0.4).cuda().train()
+    net.patch_embed.strict_img_size = False
+    g = torch.Generator(device="cuda").manual_seed(1)
+    xg = torch.randn(4, 3, 32, 32, generator=g, device="cuda")
+    xl = torch.randn(8, 3, 16, 16, generator=g, device="cuda")
+    params = [p for p in net.parameters() if p.requires_grad]
+
+    def run(maps):
+        vit.ROW_MAPS = maps
+        for p in params:
+            p.grad = None
+        torch.manual_seed(7)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                og, ol = net([xg, xl], masks=[None, None], is_training=True)
+        finally:
+            vit.ROW_MAPS = True
+        (og["x_norm_patchtokens"].float().square().mean() + ol["x_norm_clstoken"].float().square().mean()).backward()
+        return (og["x_prenorm"].detach().clone(), ol["x_prenorm"].detach().clone(),
+                [None if p.grad is None else p.grad.detach().clone() for p in params])
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert sum(g is not None for g in a[2]) > 100
+    for ga, gb, p in zip(a[2], b[2], params):
+        assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb)), tuple(p.shape)
+
+
+def test_row_map_kernels_against_index_arithmetic():
+    """octic_*_rows through the C ABI: LayerNorm of mapped rows (+ compact copy), tail written to mapped rows, tail backward
+    reading mapped rows, LayerNorm backward editing mapped rows in place - against the plain kernels on gathered rows."""
+    from octic_vits_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    R, d, k = 300, 1280, 117
+    x = torch.randn(1, R, d, generator=g, device="cuda")
+    w, b = torch.randn(d, generator=g, device="cuda"), torch.randn(d, generator=g, device="cuda")
+    rowmap = torch.randperm(R, generator=g, device="cuda")[:k].to(torch.int32)
+    idx = rowmap.long()
+    y, stats, xa = ops.dense_layernorm_fwd_rows(x, rowmap, w, b, 1e-6, torch.bfloat16)
+    y0, stats0 = ops.dense_layernorm_fwd(x[0, idx].contiguous(), w, b, 1e-6, torch.bfloat16)
+    assert torch.equal(y[0], y0) and torch.equal(stats, stats0) and torch.equal(xa[0], x[0, idx])
+    f = torch.randn(k, d, generator=g, device="cuda").to(torch.bfloat16)
+    gamma, rs = torch.randn(d, generator=g, device="cuda"), torch.rand(k, generator=g, device="cuda")
+    stream = x.clone()
+    ops.scale_residual_fwd_rows_(stream, rowmap, xa.view(k, d), f, gamma, rs, 1)
+    ref = x.clone()
+    ref[0, idx] = ops.scale_residual_fwd(xa.view(k, d), f, gamma, rs, 1)
+    assert torch.equal(stream, ref)
+    gs = torch.randn(1, R, d, generator=g, device="cuda")
+    gy, dgamma, colsum = ops.scale_residual_bwd(gs, f, gamma, rs, 1, rowmap=rowmap)
+    gy0, dgamma0, colsum0 = ops.scale_residual_bwd(gs[0, idx].contiguous(), f, gamma, rs, 1)
+    assert torch.equal(gy, gy0) and torch.equal(dgamma, dgamma0) and torch.equal(colsum, colsum0)
+    gln = torch.randn(k, d, generator=g, device="cuda").to(torch.bfloat16)
+    g_edit = gs.clone()
+    dw, db = ops.dense_layernorm_bwd_rows_(gln, xa, w, stats, g_edit, rowmap)
+    dx0, dw0, db0 = ops.dense_layernorm_bwd(gln, xa.view(k, d), w, stats, gs[0, idx].contiguous())
+    ref = gs.clone()
+    ref[0, idx] = dx0
+    assert torch.equal(g_edit, ref) and torch.equal(dw, dw0) and torch.equal(db, db0)
+    with pytest.raises(ValueError):
+        ops.dense_layernorm_fwd_rows(x, rowmap.long(), w, b, 1e-6, torch.bfloat16)
+
+
 def test_nested_block_subset_stochastic_depth_on_the_engine_equals_the_eager_composition():
     """vit.NestedTensorBlock in training with drop_path > 0.1 (dinov2/layers/block.py:113-140: the branch on a random batch
     subset, added back scaled by b / keep): the engine path (vit.SUBSET_FUSED: gathered rows through the fused LayerNorm /

@@ -1,6 +1,6 @@
 """Developer probe: which ATen operators of one DINOv2 student/teacher step (tools/bench_ssl.py's workload) still cost GPU time,
 by operator + input shapes + the innermost octic_vits_amd frame that issued them (torch.profiler, one step).
-usage: ssl_aten_ops.py [images_per_gpu=32] [rows=40]"""
+usage: ssl_aten_ops.py [images_per_gpu=32] [rows=40] [--by-count]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,5 +32,6 @@ for ev in prof.events():
     a[1] += ev.self_device_time_total
 tot = sum(a[1] for a in agg.values())
 print(f"ATen self device time of one step: {tot / 1e3:.2f} ms")
-for (name, shapes, frame), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:rows]:
+by_count = "--by-count" in sys.argv
+for (name, shapes, frame), (n, us) in sorted(agg.items(), key=lambda kv: -(kv[1][0] if by_count else kv[1][1]))[:rows]:
     print(f"{us / 1e3:7.3f} ms {n:5d}  {name:28s} {shapes:70s} {frame}")
