@@ -453,16 +453,175 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Short sequences (T <= 32 NKT <= 64 tokens: the 96 x 96 local crops of DINOv2's multi-crop recipe, 37 tokens at patch 16).
+// The same single pass with a workgroup of NKT waves (wave w owns key tile w), EVERYTHING resident: the Q, dO and K images of
+// the head land once by LDS-DMA (no ring), the V rows of the own key tile and the dO / O chunks of delta come straight from
+// global memory into registers while the DMA flies, dQ^T's ten 16 x 16 blocks per query tile are dealt round-robin to the waves
+// over the whole key range (no quarters, no extra-row machinery).  38.5 KiB of LDS at NKT = 2: four workgroups per CU - the
+// dq + dkv pair ran this shape with one 128-thread workgroup per CU and staged every operand twice (4096 heads at B = 256:
+// 96 us for a 40 us HBM floor).
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT) void bwd_small_kernel(AttnBwdArgs a) {
+  constexpr int nt = NKT, W = NKT;
+  constexpr int IMG = NKT * TILE_B;
+  const int T = a.T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const qimg = smem;
+  char* const doimg = qimg + IMG;
+  char* const kimg = doimg + IMG;
+  char* const dsb = kimg + IMG;                      // dS tiles [2][W][2 KiB]
+  float* const lse_s = (float*)(dsb + 2 * NKT * BW_DST);
+  float* const del_s = lse_s + 32 * NKT;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned ldsQ = lds0, ldsDO = lds0 + IMG, ldsK = lds0 + 2 * IMG;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = wid_of();
+  const int r = lane & 31, half = lane >> 5;
+  const int bh = unit_of(blockIdx.x, gridDim.x, a.sH < a.sT), b = bh / a.H, h = bh - b * a.H;
+  const int64_t in_off = b * a.sB + h * a.sH, o_off = b * a.oB + h * a.oH, g_off = b * a.gB + h * a.gH;
+  const int64_t stat_off = ((int64_t)b * a.H + h) * T;
+  const HeadMaps hm = head_maps(a, h);
+  FragAddr fa;
+  fa.setup(lane);
+
+  // ---- prologue: the Q, dO, K images by LDS-DMA; meanwhile V rows, delta and the row statistics from global memory
+  {
+    const i32x4 rq = make_rs(a.q, in_off, a.sT, T, a.cv_in), rk = make_rs(a.k, in_off, a.sT, T, a.cv_in);
+    const i32x4 rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt) {
+      Stager::issue(wid, W, lane, jt, nt, T, ldsK, ldsQ, rk, rq, hm.k.bs, hm.q.bs, a.sT, a.sT, a.cv_in, a.cv_in);
+      Stager::issue(wid, W, lane, jt, nt, T, ldsDO, ldsDO, rdo, rdo, hm.o.bs, hm.o.bs, a.oT, a.oT, a.cv_out, a.cv_out, -1, 1);
+    }
+  }
+  bf16x8 vf[KS];                                     // V rows of the own key tile: B operand of dP (rows past T: the last row -
+  load_rows(vf, a.v + in_off, a.sT, wid, T, lane, hm.v);   // their keys are masked out of P)
+  for (int t = tid; t < 32 * NKT; t += 64 * NKT) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
+  {
+    // delta = <dO, O> per query: 16 lanes per query (lane j < 10 owns 16-byte chunk j), four queries per wave and pass
+    const int j16 = lane & 15;
+    const bool jon = j16 < 10;
+    const int jc = jon ? j16 : 9;
+    float* const dl = a.delta + stat_off;
+    for (int q = 4 * wid + (lane >> 4); q < 32 * NKT; q += 4 * W) {
+      const int qc = q < T ? q : T - 1;
+      const u32x4 dc = hm_load16(a.dout + o_off + (int64_t)qc * a.oT, jc, hm.o), oc = hm_load16(a.o + o_off + (int64_t)qc * a.oT, jc, hm.o);
+      const float d = sum16_from8(sum8(jon ? dot8_bf16(dc, oc, 0.f) : 0.f));
+      if (j16 == 0) {
+        del_s[q] = q < T ? d : 0.f;
+        if (q < T) dl[q] = d;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // images, statistics and delta are visible
+
+  const char* const kt_ = kimg + wid * TILE_B;
+  const float kmask = (wid * 32 + r < T) ? 1.0f : 0.0f;      // keys of the partial last tile past T: out of P and dS
+  f32x16 dkt[DT], dvt[DT];
+  zero_acc<DT>(dkt);
+  zero_acc<DT>(dvt);
+  bf16* const dqb = a.dq + g_off;
+  const int gT = (int)a.gT;
+  // transposing-read geometry of the 16 x 16 x 32 products (as in bwd_kernel)
+  const int kq = lane >> 4, ti = lane & 15, q4 = ti >> 2, pp = ti & 3;
+  const int trow = 8 * kq + q4;
+  auto blk_lo = [&](int db) { return db < 4 ? trow * 128 + (((2 * db + (pp >> 1)) ^ swz(trow)) << 4) + (pp & 1) * 8 : TAIL_OFF + trow * 32 + pp * 8; };
+  auto blk_hi = [&](int db) { return db < 4 ? (trow + 4) * 128 + (((2 * db + (pp >> 1)) ^ swz(trow + 4)) << 4) + (pp & 1) * 8 : TAIL_OFF + (trow + 4) * 32 + pp * 8; };
+  auto tr8 = [&](const char* lo, const char* hi) {
+    const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lo);
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)hi);
+    const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+    return __builtin_bit_cast(bf16x8, w);
+  };
+  const int qpos16 = 4 * (ti >> 3) + (ti & 3) + 8 * ((ti & 7) >> 2);
+
+  for (int t = 0; t < nt; ++t) {
+    const char* qt_ = qimg + t * TILE_B;
+    const char* dt_ = doimg + t * TILE_B;
+    char* const mydst = dsb + (t & 1) * (W * BW_DST) + wid * BW_DST;
+    // ---- S' and dP (query on the accumulator row, key on the lane), P and dS in registers, the dS tile to LDS
+    bf16x8 p0, p1, s0, s1;
+    {
+      f32x16 x, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { x[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_, fa, ks), rowfrag(kt_, fa, ks), x, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(dt_, fa, ks), vf[ks], dp, 0, 0, 0);
+      }
+      float ps[16], ds[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int q0 = t * 32 + 8 * g4 + 4 * half;
+        const f32x4 l4 = *(const f32x4*)(lse_s + q0), d4 = *(const f32x4*)(del_s + q0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g4 + e;
+          const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], a.scale_log2, -l4[e])) * kmask;
+          ps[i] = pe;
+          ds[i] = pe * (dp[i] - d4[e]);
+        }
+      }
+      p0 = pack8(ps); p1 = pack8(ps + 8); s0 = pack8(ds); s1 = pack8(ds + 8);
+      const int sw = (r >> 3) & 1;
+      *(bf16x8*)(mydst + r * 64 + (sw * 32) + half * 16) = s0;
+      *(bf16x8*)(mydst + r * 64 + ((sw ^ 1) * 32) + half * 16) = s1;
+    }
+    // ---- the one barrier of a tile: every wave's dS tile is visible; everyone is done with tile t - 1 (its dS buffer).
+    // (No vmcnt: nothing is loaded inside the loop, and the dq stores of the previous tile may stay in flight.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dt_, fa, d, 0), p0, dvt[d], 0, 0, 0);
+      dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dt_, fa, d, 1), p1, dvt[d], 0, 0, 0);
+      dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_, fa, d, 0), s0, dkt[d], 0, 0, 0);
+      dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_, fa, d, 1), s1, dkt[d], 0, 0, 0);
+    }
+    // ---- dQ^T = K^T dS^T: blocks wid, wid + W, ... of the ten (d-block bi % 5, query block bi / 5), whole key range each
+    const char* dsr = dsb + (t & 1) * (W * BW_DST);
+    for (int bi = wid; bi < 10; bi += W) {
+      const int db = bi % 5, qb = bi / 5;
+      const int lo = blk_lo(db), hi = blk_hi(db), kb = trow * 64 + ((qb ^ (kq & 1)) * 32) + pp * 8;
+      f32x4 e = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NKT; ++k) {
+        const char* kp = kimg + k * TILE_B;
+        const char* sp = dsr + k * BW_DST + kb;
+        e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(kp + lo, kp + hi), tr8(sp, sp + 256), e, 0, 0, 0);
+      }
+      const int q = 32 * t + 16 * qb + qpos16;
+      if (q < T) {
+        const int d0 = 16 * db + 4 * kq;
+        const bf16x4 o4 = {(bf16)(e[0] * a.scale), (bf16)(e[1] * a.scale), (bf16)(e[2] * a.scale), (bf16)(e[3] * a.scale)};
+        hm_store8_at(dqb, q * gT, d0 >> 3, (d0 >> 2) & 1, __builtin_bit_cast(u32x2, o4), hm.q);
+      }
+    }
+  }
+  // ---- epilogue: dK, dV rows of the own key tile
+  {
+    const int ki = wid * 32 + r;
+    if (ki < T) {
+      store_rows16(a.dk + g_off + (int64_t)ki * a.gT, dkt, a.scale, half, hm.k);
+      store_rows16(a.dv + g_off + (int64_t)ki * a.gT, dvt, 1.0f, half, hm.v);
+    }
+  }
+}
+
 }  // namespace a80
 
 // routing override OCTIC_ROUTE_ATTN_BWD_PAIR: 1 = the round-2 dq + dkv pair for every shape
 
-// shapes of the single-pass backward: head_dim 80; 257 tokens (8 key tiles + one extra row) or 193 .. 256 tokens (7 - 8 key
-// tiles, every token inside one: DINOv2 ViT-H/16's 197; shorter sequences leave more of the eight waves without a key tile -
-// and their instantiations spill - and stay on the dq + dkv pair); 32-bit offsets
+// shapes of the single-pass backward: head_dim 80; 257 tokens (8 key tiles + one extra row), 193 .. 256 tokens (7 - 8 key
+// tiles, every token inside one: DINOv2 ViT-H/16's 197) or <= 64 tokens (bwd_small_kernel: the 37-token local crops); 65 .. 192
+// tokens would leave most of the eight waves without a key tile (and those instantiations spill) and stay on the dq + dkv
+// pair; 32-bit offsets
 int attn80_bwd_ok(const AttnBwdArgs& a) {
   using namespace a80;
-  return (!route(OCTIC_ROUTE_ATTN_BWD_PAIR) && a.hd == HD && (a.T == BW_T || (a.T > 192 && a.T <= 256)) &&
+  return (!route(OCTIC_ROUTE_ATTN_BWD_PAIR) && a.hd == HD && (a.T == BW_T || (a.T > 192 && a.T <= 256) || a.T <= 64) &&
           (int64_t)a.T * a.sT * 2 < 0x7FFFFFF0ll && (int64_t)a.T * a.oT * 2 < 0x7FFFFFF0ll &&
           (int64_t)a.T * a.gT * 2 < 0x7FFFFFF0ll) ? 1 : 0;
 }
@@ -477,6 +636,8 @@ int attn80_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s) {
     (void)hipGetLastError();
   }
   const int grid = (int)(B * a.H);
+  if (a.T <= 32) { bwd_small_kernel<1><<<grid, 64, 3 * TILE_B + 2 * BW_DST + 2 * 32 * 4, s>>>(a); return launch_status(); }
+  if (a.T <= 64) { bwd_small_kernel<2><<<grid, 128, 6 * TILE_B + 4 * BW_DST + 2 * 64 * 4, s>>>(a); return launch_status(); }
   if (a.T == BW_T) bwd_kernel<8, true><<<grid, 512, BW_LDS, s>>>(a);
   else if (a.T > 224) bwd_kernel<8, false><<<grid, 512, BW_LDS, s>>>(a);
   else bwd_kernel<7, false><<<grid, 512, BW_LDS, s>>>(a);

@@ -489,7 +489,7 @@ ATTN_BWD_FUSED = True
 
 def _attn_bwd_phases(T, hd):
     """(phase, timer name, algorithmic bytes per element of q, flops per B H T^2 hd) of the backward launches."""
-    if ATTN_BWD_FUSED and hd == 80 and (T == 257 or 192 < T <= 256):    # csrc/attn80_bwd.hip: attn80_bwd_ok
+    if ATTN_BWD_FUSED and hd == 80 and (T == 257 or 192 < T <= 256 or T <= 64):    # csrc/attn80_bwd.hip: attn80_bwd_ok
         return ((3, "attn_bwd_kernel", 8, 10.0),)         # reads q k v o dO, writes dq dk dv
     return ((1, "attn_bwd_dq_kernel", 6, 6.0), (2, "attn_bwd_dkv_kernel", 6, 8.0))
 

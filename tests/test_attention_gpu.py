@@ -95,7 +95,7 @@ def test_attn_fused_qkv_function_matches_reference():
     assert float((qkv.grad.float() - ref.grad).abs().max()) <= 3e-2 * scale
 
 
-@pytest.mark.parametrize("B,T,H,w", [(2, 257, 16, 10), (3, 197, 16, 10), (1, 64, 4, 10), (2, 33, 8, 10),
+@pytest.mark.parametrize("B,T,H,w", [(2, 257, 16, 10), (3, 197, 16, 10), (1, 64, 4, 10), (2, 33, 8, 10), (20, 37, 16, 10),
                                      (3, 197, 16, 8), (2, 257, 16, 8), (1, 64, 4, 8)])
 def test_packed_attention_matches_pack_attention_unpack(B, T, H, w):
     """octic_attn_{fwd,bwd}_packed (AttentionD8 between its two linears, reference d8_layers.py:631-656, on the packed rows)
@@ -169,11 +169,12 @@ def _bwd_raw(q, k, v, o, do, lse, scale, fused):
 
 # (17, 16) and (40, 16): more (batch, head) units than the chip has CUs - the round-5 kernel is persistent over heads: chunks of
 # 1-2 and 2-3 heads per workgroup (the next head's V behind the last tiles, its K image and first tile behind the row stores)
-@pytest.mark.parametrize("T", [197, 193, 224, 225, 256])
+@pytest.mark.parametrize("T", [197, 193, 224, 225, 256, 37, 50, 64, 33, 32, 17, 1])
 def test_single_pass_backward_below_257_tokens_matches_fp64_and_the_pair(T):
     """Round 5: the single-pass kernel for 193 .. 256 tokens (bwd_kernel<7 | 8, false>: every token inside a key tile, the
-    last tile partial - its keys masked out of P and dS -, no extra-row machinery): float64 reference, the dq + dkv pair's own
-    error as the yardstick, bitwise repeatable, and the rows of the partial tile checked on their own."""
+    last tile partial - its keys masked out of P and dS -, no extra-row machinery) and the resident-image kernel for <= 64
+    tokens (bwd_small_kernel<1 | 2>: DINOv2's 37-token local crops): float64 reference, the dq + dkv pair's own error as the
+    yardstick, bitwise repeatable, and the rows of the partial tile checked on their own."""
     from octic_vits_amd import ops
     B, H, hd = 3, 16, 80
     g = torch.Generator().manual_seed(T)
@@ -196,7 +197,8 @@ def test_single_pass_backward_below_257_tokens_matches_fp64_and_the_pair(T):
         assert ef <= 3e-2 * sc, f"{name}: max err {ef:.3e} (scale {sc:.3g})"
         assert ef <= 1.5 * ep + 1e-3 * sc, f"{name}: single-pass err {ef:.3e} vs two-kernel {ep:.3e}"
         assert float((f.double()[:, :, t0:] - want[:, :, t0:]).abs().max()) <= 3e-2 * sc, f"{name}: last tile"
-        assert float((f.double() - want).norm() / want.norm()) < 1.2e-2, name
+        # (one token: dS = 0, so dq and dk are exactly zero in exact arithmetic - absolute bound there)
+        assert float((f.double() - want).norm()) < 1.2e-2 * max(float(want.norm()), 1e-3), name
 
 
 @pytest.mark.parametrize("B,H", [(2, 3), (5, 16), (17, 16), (40, 16)])
