@@ -38,32 +38,14 @@
 // every landed-wait are always one of each kind: vmcnt(9)), two K-tiles of 72 KiB fill the ring, and the epilogue stages
 // the tile in two 64-row passes.
 #include <type_traits>
-#ifndef DG_DMA_IN_MMA
-#define DG_DMA_IN_MMA 0      // 0: DMA issued in the R interval (beside the partner's MFMAs); 1: mid-MFMA; 2: M start
-#endif
 #include "octic_common.hpp"
 
 namespace octic {
 
 constexpr int DG_BM = 256, DG_BK = 64;
 constexpr int DG_UNIT = 128 * 128;            // bytes per 128-row unit
-#ifndef DG_DIST
-#define DG_DIST 6
-#endif
-#ifndef DG_PRIO
-#define DG_PRIO 2       // measured on MI355X (A/B in one process): 2 > 0 > 1 by ~5 %
-#endif
-#ifndef DG_ABL
-#define DG_ABL 0
-#endif
-#ifndef DG_READS_FIRST
-#define DG_READS_FIRST 0
-#endif
-#ifndef DG_BALANCED
-#define DG_BALANCED 0    // 1: first row half of the next K-tile is read in phase 3 (reads 4/4/8/8 instead of 12/4/8/0)
-#endif
 constexpr int DG_SLOTS = 8;                   // ring = two K-tiles of four units
-constexpr int DG_D = DG_DIST;                 // prefetch distance in units: unit g+D is issued in R_g (D <= slots - 2)
+constexpr int DG_D = 6;                 // prefetch distance in units: unit g+D is issued in R_g (D <= slots - 2)
 static_assert(DG_D >= 4 && DG_D <= DG_SLOTS - 2, "prefetch distance");
 // Per tile width (NT = n-tiles of 16 columns per wave; 4 waves along N):
 //   column sets of a wave: NA = NT - 2 tiles first, 2 tiles second; unit kinds 0 / 3 = A row halves (16 KiB),
@@ -170,7 +152,7 @@ extern "C" void* octic_dbg_dense_trace2(void) {
 // GELU for the fused epilogues.  The epilogue runs after the main loop with nothing to hide its VALU work behind (one
 // workgroup per CU), and libm's erff costs ~40 instructions per element (~100 us for the 84 M elements of fc1).  erf by
 // Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, one v_exp + one v_rcp + 6 fma) is far inside the bf16 output's 2^-9.
-// (Round 4: the math of the GELU tail is 3.8 us of a tile's 8.3 us epilogue - tools/dense_phases.py with FLAGS=-DDG_ABL=32 - and
+// (Round 4: the math of the GELU tail is 3.8 us of a tile's 8.3 us epilogue - round-4 ablation build - and
 // VALU-throughput bound: a transcendental-free form, Phi(x) = 1/2 + x P12(0.08 x^2 - 1) on |x| <= 5, thirteen packed fmas and
 // 3.9e-7 of error, was built and timed EQUAL (245 vs 246 us per launch): the quarter-rate v_exp / v_rcp overlap the packed
 // fmas of the other wave, so the form with fewer full-rate instructions stays.)
@@ -183,15 +165,10 @@ __device__ inline float dg_erf(float x) {
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
-#if DG_ABL & 32   // timing-only ablation: the fused tails without their transcendental math (what the VALU part of the epilogue costs)
-__device__ inline float dg_gelu(float x) { return 0.5f * x; }
-__device__ inline float dg_gelu_grad(float x) { return 0.5f + 0.25f * x; }
-#else
 __device__ inline float dg_gelu(float x) { return 0.5f * x * (1.0f + dg_erf(x * kSqrt1Over2)); }
 __device__ inline float dg_gelu_grad(float x) {
   return 0.5f * (1.0f + dg_erf(x * kSqrt1Over2)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
 }
-#endif
 // gelu(x) and gelu'(x) from ONE erf evaluation: Phi(x) = (1 + erf(x / sqrt 2)) / 2, and the exp(-x^2 / 2) inside the erf
 // approximation is the density term of the derivative (DG_GELUF: the fc1 epilogue that also leaves the backward's factor)
 __device__ inline void dg_gelu_both(float x, float& g, float& d) {
@@ -293,13 +270,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)((int64_t)a.M * a.lda * 2), 0x27000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)((int64_t)a.N * a.ldb * 2), 0x27000);
   const int r0 = 16 * wid + drow;                                   // unit row of instruction 0
-#if DG_ABL & 8    // timing-only ablation: every tile reads the operand panels of tile (0, 0) (all-L2-hit operand stream)
-  const int am0 = 0, an0 = 0;
-#elif DG_ABL & 16  // timing-only ablation: A panels as they are, every tile reads B panel 0
-  const int am0 = m0, an0 = 0;
-#else
   const int am0 = m0, an0 = n0;
-#endif
   const unsigned voA = (unsigned)(((int64_t)(am0 + (r0 >> 6) * 128 + (r0 & 63)) * a.lda + dch * 8) * 2);
   // B: a wave's DMA rows of the first column sets are unit rows 8 NA wid + 8 j + drow (j < NA), of the second sets
   // 16 wid + 8 j + drow; unit row blocks of 16 NA (32) rows belong to column wave wc = block index
@@ -344,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const int rdo1 = fr * 128 + (((4 + kg) ^ sw) << 4);
   const int a_row0 = wr * 64;          // unit rows of this wave inside units 0 / 3
 
-  bf16x8 Af[1 + DG_BALANCED][2][4];    // [row half (one set unless DG_BALANCED)][kstep][m-tile]
+  bf16x8 Af[1][2][4];    // [one row half at a time][kstep][m-tile]
   bf16x8 Bf0[2][NA], Bf1[2][2];        // first / second column set: [kstep][n-tile]
   f32x4 acc0[2][4][NA], acc1[2][4][2]; // first / second column set: [m-half][m-tile][n-tile]
 #pragma unroll
@@ -363,20 +334,14 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   const int live_mask = __builtin_amdgcn_readfirstlane((rt_hi > 0 ? 1 : 0) | (rt_hi > 4 ? 2 : 0));   // scalar: s_bitcmp + s_cbranch
 
   auto readA = [&](int mh, int unit) {
-#if DG_ABL & 2
-    if (unit > 3) return;
-#endif
     const char* base = lds + ((unit >> 2) & 1) * GE::KT + GE::unit_off(mh ? 3 : 0) + a_row0 * 128;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      Af[mh * DG_BALANCED][0][mi] = *(const bf16x8*)(base + mi * 2048 + rdo0);
-      Af[mh * DG_BALANCED][1][mi] = *(const bf16x8*)(base + mi * 2048 + rdo1);
+      Af[0][0][mi] = *(const bf16x8*)(base + mi * 2048 + rdo0);
+      Af[0][1][mi] = *(const bf16x8*)(base + mi * 2048 + rdo1);
     }
   };
   auto readB = [&](int nh, int unit) {
-#if DG_ABL & 2
-    if (unit > 3) return;
-#endif
     if (nh == 0) {
       const char* base = lds + ((unit >> 2) & 1) * GE::KT + GE::unit_off(1) + wc * (16 * NA) * 128;
 #pragma unroll
@@ -396,14 +361,8 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
   // 16 MFMAs of one quadrant; the DMA of the next unit is issued from inside the block (the matrix pipe is busy for 16
   // cycles per MFMA, the issue slots in between are free), which keeps the R intervals short
   auto mma = [&](int mh, int nh, auto kind_c) {
-#if DG_DMA_IN_MMA == 2
-    if (u_issue < nunits) issue_unit(kind_c);     // right after the barrier, ahead of the MFMAs
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-#if DG_PRIO == 1
-    __builtin_amdgcn_s_setprio(1);
-#endif
     if (live_mask & (mh ? 2 : 1)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -412,25 +371,15 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
         if (nh == 0) {
 #pragma unroll
           for (int ni = 0; ni < NA; ++ni)
-            acc0[mh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf0[ks][ni], Af[mh * DG_BALANCED][ks][mi], acc0[mh][mi][ni], 0, 0, 0);
+            acc0[mh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf0[ks][ni], Af[0][ks][mi], acc0[mh][mi][ni], 0, 0, 0);
         } else {
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc1[mh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf1[ks][ni], Af[mh * DG_BALANCED][ks][mi], acc1[mh][mi][ni], 0, 0, 0);
+            acc1[mh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf1[ks][ni], Af[0][ks][mi], acc1[mh][mi][ni], 0, 0, 0);
         }
       }
-#if DG_DMA_IN_MMA
-      if (ks == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (u_issue < nunits) issue_unit(kind_c);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
     }
     }
-#if DG_PRIO == 1
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -464,11 +413,6 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     // slot of unit v is refilled in M_v, which is only safe because every unit is read in a phase < v.
     const int ok = (u_issue - 1) - 1;
     dg_wait_vmcnt(ok > 0 ? young_instr(ok) : 0);
-#if DG_BALANCED
-    __builtin_amdgcn_s_barrier();
-    readA(0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
   }
   if (hi) __builtin_amdgcn_s_barrier();
   DGT2(1);
@@ -479,37 +423,18 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     constexpr bool STEADY = decltype(steady_c)::value != 0;
     const int u0 = 4 * t;
     auto dma = [&](auto kind_c) {
-#if DG_ABL & 1   // timing-only ablation: no DMA in the loop (results are garbage)
-      ++u_issue;
-#else
       if (STEADY || u_issue < nunits) issue_unit(kind_c);
-#endif
     };
     auto landed = [&]() {
-#if DG_ABL & 5   // bit 2: DMA is issued but never waited for (timing-only: separates issue cost from memory waits)
-      return;
-#endif
       if constexpr (STEADY) dg_wait_imm<GE::INFLIGHT>();
       else wait_landed();
     };
-#if DG_PRIO == 2    // the R interval (DMA issue + LDS reads) is the long one: give IT the issue priority
 #define DG_RP(x) do { __builtin_amdgcn_s_setprio(x); } while (0)
-#else
-#define DG_RP(x) do {} while (0)
-#endif
-#if DG_READS_FIRST
-#define DG_R(q, reads) do { DG_RP(2); reads; dma(DG_IC(((q) + DG_D) & 3)); DG_RP(0); } while (0)
-#else
 #define DG_R(q, reads) do { DG_RP(2); dma(DG_IC(((q) + DG_D) & 3)); reads; DG_RP(0); } while (0)
-#endif
     // phase 0: first row half x first column half
     __builtin_amdgcn_s_barrier();
     DGT();
-#if DG_BALANCED
-    DG_R(0, readB(0, u0 + 1));
-#else
     DG_R(0, readA(0, u0); readB(0, u0 + 1));
-#endif
     if (hi) landed();
     DGT();
     __builtin_amdgcn_s_barrier();
@@ -545,11 +470,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     // phase 3: second row half x first column half (fragments already in registers)
     __builtin_amdgcn_s_barrier();
     DGT();
-#if DG_BALANCED
-    DG_R(3, if (t + 1 < nkt) readA(0, u0 + 4));
-#else
     DG_R(3, (void)0);
-#endif
     if (hi) landed();
     DGT();
     __builtin_amdgcn_s_barrier();
