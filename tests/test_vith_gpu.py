@@ -1,6 +1,7 @@
 """The headline model itself: `hybrid_deit_huge_patch14` (BASELINE configs[1], 16 octic + 16 standard blocks, D = 1280,
 patch 14, 224x224) on the GPU against the CPU oracle (oracle/octic_ref.py, pinned to the reference by tests/golden) -
-and, since round 4, the same recipe for `hybrid_deit_large_patch16` (reference octic_vits/deit_models.py:11-25: D = 1024,
+and, since round 5, for BASELINE configs[3] `d8_inv_early_deit_huge_patch14` (power-spectrum hand-off + invariant projection,
+octic_vits/deit_models.py:42-56) and, since round 4, the same recipe for `hybrid_deit_large_patch16` (reference octic_vits/deit_models.py:11-25: D = 1024,
 head_dim 64, T = 197: the packed attention at c = 8 H, the dense kernels at M = 394 rows) and for the ViT-H with the
 bench's drop_path_rate = 0.5, the masks drawn from the reference's CPU stream (new_empty(B,1,1).bernoulli_, same seed,
 same order: octic_vits/d8_layers.py:140-152, deit/vit.py:14-27) so the fused residual / next-norm / LayerNorm-tail kernels
@@ -42,7 +43,7 @@ def reference_drop_path_stream():
 
 @pytest.mark.timeout(1800)
 @pytest.mark.parametrize("name,drop_path", [("hybrid_deit_huge_patch14", 0.0), ("hybrid_deit_huge_patch14", 0.5),
-                                            ("hybrid_deit_large_patch16", 0.0)])
+                                            ("hybrid_deit_large_patch16", 0.0), ("d8_inv_early_deit_huge_patch14", 0.0)])
 def test_hybrid_vit_forward_f32_and_bf16_gradients_match_the_oracle(name, drop_path, reference_drop_path_stream):
     ref, net = _models(name, drop_path)
     nimg = 4 if drop_path > 0 else 2                 # (with two images half of the drop-path draws would be all-or-nothing)
@@ -91,11 +92,13 @@ def test_hybrid_vit_forward_f32_and_bf16_gradients_match_the_oracle(name, drop_p
         den = max(float(np.linalg.norm(w)), 1e-6)
         rel = float(np.linalg.norm(g_got[n] - w)) / den
         rel_oracle = float(np.linalg.norm(g_yard[n] - w)) / den
-        lim = max(3e-2, 2.0 * rel_oracle)
+        # (invariant model: gradients upstream of PowerSpectrum's |x| / norms flip sign with the bf16 rounding of small x - the
+        # oracle's own CPU-bf16 run is 7-10 % away from f32 on those tensors; two independent bf16 evaluations: 2.5 x)
+        lim = max(3e-2, (2.5 if "inv" in name else 2.0) * rel_oracle)
         worst.append((rel / lim, n, rel, rel_oracle))
     worst.sort(reverse=True)
     bad = [w for w in worst if w[0] > 1.0]
-    assert not bad, f"{name} (drop_path {drop_path}) bf16 gradients beyond max(3e-2, 2 x oracle-under-bf16): " + \
+    assert not bad, f"{name} (drop_path {drop_path}) bf16 gradients beyond max(3e-2, 2 (2.5) x oracle-under-bf16): " + \
         "; ".join(f"{n}: {r:.4f} (oracle {ro:.4f})" for _, n, r, ro in bad[:8])
 
 
