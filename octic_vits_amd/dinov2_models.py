@@ -128,7 +128,11 @@ class OcticDinoVisionTransformer(OcticVisionTransformer):
     # ------------------------------------------------------------------------------------------ forward
     def forward_features_list(self, x_list, masks_list):
         xs = [self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)]
+        # (ssl.SSLTrainer: gradients of block parameters may be written at the END of backward only if every block module
+        # contributed one gradient - true for the one-row-tensor pass, false for the set-by-set loop)
+        self._single_use_pass = False
         if RAGGED_LISTS and self._ragged_ok(xs):
+            self._single_use_pass = True
             return self._forward_features_ragged(xs, masks_list)
         for blk in self.blocks[:self.depth // 2]:
             xs = blk(xs)

@@ -354,7 +354,9 @@ class SSLMetaArch(nn.Module):
         sg, sl = self.student.backbone([global_crops, local_crops], masks=[masks, None], is_training=True)
         return sg, sl
 
-    def forward_backward(self, images, teacher_temp, backward=True):
+    def forward_backward(self, images, teacher_temp, backward=True, backward_scope=None):
+        """backward_scope: a context-manager factory entered around total.backward() (SSLTrainer: batched parameter-gradient
+        finishes where every block module was used once in the pass)."""
         n_global_crops, n_local_crops = 2, self.n_local_crops
         global_crops, local_crops = images["collated_global_crops"], images["collated_local_crops"]
         masks, mask_indices_list = images["collated_masks"], images["mask_indices_list"]
@@ -443,7 +445,11 @@ class SSLMetaArch(nn.Module):
             loss_dict["ibot_loss"] = l / 2
             total = total + self.ibot_loss_weight * l
         if backward:
-            total.backward()
+            if backward_scope is None:
+                total.backward()
+            else:
+                with backward_scope():
+                    total.backward()
         loss_dict["total"] = total.detach()
         return loss_dict
 
@@ -573,9 +579,9 @@ class SSLTrainer:
                 p.grad = None
         if self.autocast:
             with torch.autocast(self.device_type, dtype=torch.bfloat16):
-                loss_dict = self.arch.forward_backward(images, teacher_temp)
+                loss_dict = self.arch.forward_backward(images, teacher_temp, backward_scope=self._finish_scope)
         else:
-            loss_dict = self.arch.forward_backward(images, teacher_temp)
+            loss_dict = self.arch.forward_backward(images, teacher_temp, backward_scope=self._finish_scope)
         if self._ddp is not None and _world() > 1:                # the heads are outside the DDP wrapper
             for p in self._head_params:
                 if p.grad is not None:
@@ -590,6 +596,18 @@ class SSLTrainer:
         self.optimizer.step()
         self.arch.update_teacher(momentum)
         return loss_dict
+
+    def _finish_scope(self):
+        """The parameter-gradient slab reductions of the pass as batched launches at its end, and the qkv + proj weight gradients
+        of a standard block as one launch (ops.DEFERRED_FINISHES, functional.WGRAD_PAIRED) - only where nothing reads a
+        parameter gradient before the end of backward: no DDP hooks, and every block module used ONCE in the pass (the crop
+        sets as one row tensor: a module used twice would have autograd add two gradient buffers before they are written)."""
+        from . import ops
+        from .train import BATCHED_FINISHES, _FinishScope
+        bb = self.arch.student["backbone"] if "backbone" in self.arch.student else None
+        safe = (BATCHED_FINISHES and self.device_type == "cuda" and self._ddp is None
+                and getattr(bb, "_single_use_pass", False))
+        return _FinishScope(ops.DEFERRED_FINISHES, safe)
 
     def _fused_step(self, momentum):
         """One octic_adamw_step per sub-model (dinov2/train/train.py:274-296: clip per sub-model, optimizer step, teacher EMA).

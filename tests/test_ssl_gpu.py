@@ -209,6 +209,38 @@ def test_crop_sets_as_one_row_tensor_equal_the_set_by_set_loop():
         opt.step()
 
 
+def test_ssl_trainer_batched_finishes_equal_immediate_ones():
+    """SSLTrainer on a backbone whose crop sets run as one row tensor (every block module used once per pass): the
+    parameter-gradient reductions batched at the end of backward + the paired qkv / proj weight gradients (train.BATCHED_FINISHES)
+    against immediate finishes - same seeds, two steps: losses equal, student parameters equal to f32 summation-order noise."""
+    from octic_vits_amd import ssl as S, train as TR
+
+    def run(batched):
+        TR.BATCHED_FINISHES = batched
+        try:
+            torch.manual_seed(0)
+            arch = S.SSLMetaArch(lambda: _hd64_backbone(drop_path=0.4), 256, head_n_prototypes=512, head_hidden_dim=128,
+                                 head_bottleneck_dim=64, local_crops_number=4).cuda()
+            for m in (arch.student["backbone"], arch.teacher["backbone"]):
+                m.patch_embed.strict_img_size = False
+            tr = S.SSLTrainer(arch, lr=1e-3)
+            images = S.synthetic_multicrop_batch(4, "cuda", seed=3, global_size=32, local_size=16, n_local=4, patch_size=4)
+            losses = []
+            for i in range(2):
+                torch.manual_seed(10 + i)
+                out = tr.step(images, teacher_temp=0.05, momentum=0.99)
+                losses.append(float(out["total"]))
+            assert arch.student["backbone"]._single_use_pass
+            return losses, [p.detach().clone() for p in arch.student.parameters()]
+        finally:
+            TR.BATCHED_FINISHES = True
+
+    (la, pa), (lb, pb) = run(True), run(False)
+    assert la[0] == lb[0] and abs(la[1] - lb[1]) <= 1e-4 * abs(lb[1])
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())) + 2e-6
+
+
 def test_row_maps_equal_gather_and_scatter_bitwise():
     """The batch-subset stochastic depth of the ragged pass with the kept rows read / written through row maps inside the
     LayerNorm and residual-tail kernels (vit.ROW_MAPS) against explicit gather / scatter passes: same draws (same seed), same
