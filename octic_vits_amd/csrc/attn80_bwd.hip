@@ -455,12 +455,12 @@ __global__ __launch_bounds__(512) void bwd_kernel(AttnBwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Short sequences (T <= 32 NKT <= 64 tokens: the 96 x 96 local crops of DINOv2's multi-crop recipe, 37 tokens at patch 16).
-// The same single pass with a workgroup of NKT waves (wave w owns key tile w), EVERYTHING resident: the Q, dO and K images of
-// the head land once by LDS-DMA (no ring), the V rows of the own key tile and the dO / O chunks of delta come straight from
-// global memory into registers while the DMA flies, dQ^T's ten 16 x 16 blocks per query tile are dealt round-robin to the waves
-// over the whole key range (no quarters, no extra-row machinery).  38.5 KiB of LDS at NKT = 2: four workgroups per CU - the
-// dq + dkv pair ran this shape with one 128-thread workgroup per CU and staged every operand twice (4096 heads at B = 256:
-// 96 us for a 40 us HBM floor).
+// The same single pass with a workgroup of NKT waves (wave w owns key tile w), EVERYTHING resident: the Q, dO, O, K and V
+// images of the head land once by LDS-DMA (no ring), delta of all query tiles is formed in the prologue, the dS tiles take over
+// the O image, dQ^T's ten 16 x 16 blocks per query tile are dealt round-robin to the waves over the whole key range (no
+// quarters, no extra-row machinery).  50.5 KiB of LDS at NKT = 2: three workgroups per CU.  (V rows and the delta chunks
+// straight from global memory - 38.5 KiB, four workgroups per CU - timed the same on strided rows, 77 against 76 us, and lost on
+// packed rows, whose 16-byte chunks straddle irrep pieces: the DMA stager's piece addressing is the cheaper path there.)
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void bwd_small_kernel(AttnBwdArgs a) {
   constexpr int nt = NKT, W = NKT;
@@ -470,11 +470,14 @@ __global__ __launch_bounds__(64 * NKT) void bwd_small_kernel(AttnBwdArgs a) {
   char* const qimg = smem;
   char* const doimg = qimg + IMG;
   char* const kimg = doimg + IMG;
-  char* const dsb = kimg + IMG;                      // dS tiles [2][W][2 KiB]
-  float* const lse_s = (float*)(dsb + 2 * NKT * BW_DST);
+  char* const vimg = kimg + IMG;
+  char* const oimg = vimg + IMG;                     // prologue: the O image (delta); afterwards the dS tiles [2][W][2 KiB]
+  char* const dsb = oimg;
+  float* const lse_s = (float*)(oimg + IMG);
   float* const del_s = lse_s + 32 * NKT;
+  static_assert(2 * NKT * BW_DST <= IMG, "the dS tiles fit into the O image");
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned ldsQ = lds0, ldsDO = lds0 + IMG, ldsK = lds0 + 2 * IMG;
+  const unsigned ldsQ = lds0, ldsDO = lds0 + IMG, ldsK = lds0 + 2 * IMG, ldsV = lds0 + 3 * IMG, ldsO = lds0 + 4 * IMG;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = wid_of();
   const int r = lane & 31, half = lane >> 5;
@@ -485,19 +488,24 @@ __global__ __launch_bounds__(64 * NKT) void bwd_small_kernel(AttnBwdArgs a) {
   FragAddr fa;
   fa.setup(lane);
 
-  // ---- prologue: the Q, dO, K images by LDS-DMA; meanwhile V rows, delta and the row statistics from global memory
+  // ---- prologue: every image of the head by LDS-DMA, the row statistics
   {
     const i32x4 rq = make_rs(a.q, in_off, a.sT, T, a.cv_in), rk = make_rs(a.k, in_off, a.sT, T, a.cv_in);
-    const i32x4 rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
+    const i32x4 rv = make_rs(a.v, in_off, a.sT, T, a.cv_in), rdo = make_rs(a.dout, o_off, a.oT, T, a.cv_out);
+    const i32x4 ro = make_rs(a.o, o_off, a.oT, T, a.cv_out);
 #pragma unroll
     for (int jt = 0; jt < NKT; ++jt) {
-      Stager::issue(wid, W, lane, jt, nt, T, ldsK, ldsQ, rk, rq, hm.k.bs, hm.q.bs, a.sT, a.sT, a.cv_in, a.cv_in);
-      Stager::issue(wid, W, lane, jt, nt, T, ldsDO, ldsDO, rdo, rdo, hm.o.bs, hm.o.bs, a.oT, a.oT, a.cv_out, a.cv_out, -1, 1);
+      Stager::issue(wid, W, lane, jt, nt, T, ldsK, ldsV, rk, rv, hm.k.bs, hm.v.bs, a.sT, a.sT, a.cv_in, a.cv_in);
+      Stager::issue(wid, W, lane, jt, nt, T, ldsDO, ldsO, rdo, ro, hm.o.bs, hm.o.bs, a.oT, a.oT, a.cv_out, a.cv_out);
+      Stager::issue(wid, W, lane, jt, nt, T, ldsQ, ldsQ, rq, rq, hm.q.bs, hm.q.bs, a.sT, a.sT, a.cv_in, a.cv_in, -1, 1);
     }
+    for (int t = tid; t < 32 * NKT; t += 64 * NKT) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
   }
-  bf16x8 vf[KS];                                     // V rows of the own key tile: B operand of dP (rows past T: the last row -
-  load_rows(vf, a.v + in_off, a.sT, wid, T, lane, hm.v);   // their keys are masked out of P)
-  for (int t = tid; t < 32 * NKT; t += 64 * NKT) lse_s[t] = t < T ? a.lse[stat_off + t] : INFINITY;   // padded queries: P = 0
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 vf[KS];                                     // V rows of the own key tile: B operand of dP
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) vf[ks] = rowfrag(vimg + wid * TILE_B, fa, ks);
   {
     // delta = <dO, O> per query: 16 lanes per query (lane j < 10 owns 16-byte chunk j), four queries per wave and pass
     const int j16 = lane & 15;
@@ -505,17 +513,17 @@ __global__ __launch_bounds__(64 * NKT) void bwd_small_kernel(AttnBwdArgs a) {
     const int jc = jon ? j16 : 9;
     float* const dl = a.delta + stat_off;
     for (int q = 4 * wid + (lane >> 4); q < 32 * NKT; q += 4 * W) {
-      const int qc = q < T ? q : T - 1;
-      const u32x4 dc = hm_load16(a.dout + o_off + (int64_t)qc * a.oT, jc, hm.o), oc = hm_load16(a.o + o_off + (int64_t)qc * a.oT, jc, hm.o);
+      const int t = q >> 5, qq = q & 31;
+      const u32x4 dc = *(const u32x4*)tile_chunk(doimg + t * TILE_B, qq, jc), oc = *(const u32x4*)tile_chunk(oimg + t * TILE_B, qq, jc);
       const float d = sum16_from8(sum8(jon ? dot8_bf16(dc, oc, 0.f) : 0.f));
       if (j16 == 0) {
-        del_s[q] = q < T ? d : 0.f;
+        del_s[q] = d;                                // rows past T are zero rows: d = 0
         if (q < T) dl[q] = d;
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                      // images, statistics and delta are visible
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // the O image is dead (dS tiles from here on); delta is visible
 
   const char* const kt_ = kimg + wid * TILE_B;
   const float kmask = (wid * 32 + r < T) ? 1.0f : 0.0f;      // keys of the partial last tile past T: out of P and dS
@@ -636,8 +644,8 @@ int attn80_bwd_launch(const AttnBwdArgs& a, int64_t B, hipStream_t s) {
     (void)hipGetLastError();
   }
   const int grid = (int)(B * a.H);
-  if (a.T <= 32) { bwd_small_kernel<1><<<grid, 64, 3 * TILE_B + 2 * BW_DST + 2 * 32 * 4, s>>>(a); return launch_status(); }
-  if (a.T <= 64) { bwd_small_kernel<2><<<grid, 128, 6 * TILE_B + 4 * BW_DST + 2 * 64 * 4, s>>>(a); return launch_status(); }
+  if (a.T <= 32) { bwd_small_kernel<1><<<grid, 64, 5 * TILE_B + 2 * 32 * 4, s>>>(a); return launch_status(); }
+  if (a.T <= 64) { bwd_small_kernel<2><<<grid, 128, 10 * TILE_B + 2 * 64 * 4, s>>>(a); return launch_status(); }
   if (a.T == BW_T) bwd_kernel<8, true><<<grid, 512, BW_LDS, s>>>(a);
   else if (a.T > 224) bwd_kernel<8, false><<<grid, 512, BW_LDS, s>>>(a);
   else bwd_kernel<7, false><<<grid, 512, BW_LDS, s>>>(a);
