@@ -812,9 +812,9 @@ class Layer_scale_init_BlockD8(nn.Module):
 
 
 def link_octic_blocks(blocks):
-    """Tell every Layer_scale_init_BlockD8 which LayerNormD8 follows it (norm1 of the next one in `blocks`); held in a
-    tuple: not a sub-module, state_dict keys do not change."""
-    seq = [b for b in blocks if isinstance(b, Layer_scale_init_BlockD8)]
+    """Tell every Layer_scale_init_BlockD8 / BlockD8 which LayerNormD8 follows it (norm1 of the next one in `blocks`); held
+    in a tuple: not a sub-module, state_dict keys do not change."""
+    seq = [b for b in blocks if isinstance(b, (Layer_scale_init_BlockD8, BlockD8))]
     for cur, nxt in zip(seq[:-1], seq[1:]):
         if type(nxt.norm1) is LayerNormD8:
             cur._next_norm = (nxt.norm1,)
@@ -855,7 +855,18 @@ class BlockD8(nn.Module):
             if rag is not None and m1 is not None:
                 m1 = rag.row_scale(m1)
         cs1 = self.ls1.alphas() if isinstance(self.ls1, LayerScaleD8) else None
-        x1 = _branch(self.norm1, self.attn, xp, c, m1, cs1, dt)
+        # norm2 out of the attention branch's last layer, norm1 of the NEXT block out of the MLP's (link_octic_blocks), as in
+        # Layer_scale_init_BlockD8: each pair is one autograd node whose backward needs no cast pass (OF.LinearD8NormFn)
+        chain = (not torch.compiler.is_compiling() and OF.OCTIC_NEXT_NORM and xp.is_cuda and dt == torch.bfloat16
+                 and type(self.norm2) is LayerNormD8)
+        y2 = None
+        if chain:
+            pre = getattr(xs, "_prenorm", None)
+            pre1 = pre[1] if (pre is not None and pre[0] is self.norm1 and pre[1] is not None
+                              and pre[2] == xp._version and pre[3] == xp.data_ptr()) else None
+            x1, y2 = _branch(self.norm1, self.attn, xp, c, m1, cs1, dt, pre=pre1, next_norm=self.norm2)
+        else:
+            x1 = _branch(self.norm1, self.attn, xp, c, m1, cs1, dt)
         if pool is not None:
             m2 = pool.get(id(self.drop_path2))
         else:
@@ -863,7 +874,14 @@ class BlockD8(nn.Module):
             if rag is not None and m2 is not None:
                 m2 = rag.row_scale(m2)
         cs2 = self.ls2.alphas() if isinstance(self.ls2, LayerScaleD8) else None
-        return _branch(self.norm2, self.mlp, x1.packed, c, m2, cs2, dt)
+        nn_ = getattr(self, "_next_norm", None) if chain else None
+        nxt = nn_[0] if nn_ else None
+        if nxt is None:
+            return _branch(self.norm2, self.mlp, x1.packed, c, m2, cs2, dt, pre=y2)
+        x2, yn = _branch(self.norm2, self.mlp, x1.packed, c, m2, cs2, dt, pre=y2, next_norm=nxt)
+        if yn is not None:
+            x2._prenorm = (nxt, yn, x2.packed._version, x2.packed.data_ptr())
+        return x2
 
 
 class NestedTensorBlockD8(BlockD8):
