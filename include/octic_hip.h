@@ -439,6 +439,8 @@ int octic_dense_prep_batch(const octic_dense_prep_item* items_dev, int n_items, 
  *             pre-activation itself (gelu and gelu' share one erf evaluation in the epilogue);  C2 = gelu(acc + bias)
  *   5 DFACT : like 3 with H = the factor stored by mode 4: C = H * acc, no transcendental in the epilogue (one more bf16
  *             rounding of the factor than mode 1 + 3; same column sums)
+ *   6 GELUO : C = gelu(acc + bias) only (the value mode 1 leaves in C2): passes that never run a backward - inference, the
+ *             DINOv2 teacher - write half the bytes
  * C / C2 / H are bf16 [M,N] with row stride ldc.  bias, gamma [N] f32 and rs f32 may be NULL.  workspace:
  * octic_dense_gemm_workspace_bytes(M,N,K) bytes (split-K slabs of the last partial round of tiles + counters), ZEROED once
  * by the caller when it is allocated (the kernels re-arm their counters; calls sharing a workspace must be stream-ordered). */

@@ -96,7 +96,8 @@ struct DgArgs {
 
 enum DgMode { DG_PLAIN = 0, DG_GELU = 1, DG_RESID = 2, DG_DGELU = 3,
               DG_GELUF = 4,    // like GELU, but C = gelu'(pre-activation) in bf16 (the factor the backward multiplies by) instead of it
-              DG_DFACT = 5 };  // like DGELU with H = that stored factor: C = H * acc, no transcendental in the epilogue
+              DG_DFACT = 5,    // like DGELU with H = that stored factor: C = H * acc, no transcendental in the epilogue
+              DG_GELUO = 6 };  // GELU only: C = gelu(pre-activation), nothing kept for a backward (inference passes)
 
 __device__ inline void dg_wait_vmcnt(int n) {      // n even, wave-uniform; anything unexpected drains (always safe)
   switch (n) {
@@ -660,6 +661,11 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) y[e] = (bf16)dg_gelu((float)cb[e]);           // F.gelu of the bf16-rounded h
       *(bf16x8*)(a.C2 + (int64_t)m * a.ldc + n) = y;
+    } else if (MODE == DG_GELUO) {
+      bf16x8 y;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (bf16)dg_gelu((float)cb[e]);           // F.gelu of the bf16-rounded h, as mode 1
+      *(bf16x8*)cp = y;
     } else if (MODE == DG_GELUF) {
       bf16x8 y, f;
 #pragma unroll
@@ -840,7 +846,8 @@ int octic_dense_gemm_colsum_rows(int M, int N, int K) {
 
 // mode: 0 plain (C = A B^T + bias), 1 GELU (C = pre-activation, C2 = gelu(C)), 2 RESID (C = branch, OUT = X + rs*gamma*C),
 // 3 DGELU (C = gelu'(H) * (A B^T); colsum != NULL: octic_dense_gemm_colsum_rows() slabs [N] of column sums of C),
-// 4 GELUF (C = gelu'(pre-activation), C2 = gelu(pre-activation)), 5 DFACT (C = H * (A B^T), H = the factor of mode 4).
+// 4 GELUF (C = gelu'(pre-activation), C2 = gelu(pre-activation)), 5 DFACT (C = H * (A B^T), H = the factor of mode 4),
+// 6 GELUO (C = gelu(pre-activation) only: passes without a backward).
 int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs, int64_t rps,
                         const float* X, float* OUT, const void* H, float* colsum, void* workspace, void* stream) {
@@ -876,6 +883,7 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_DGELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_GELUF, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_DFACT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)dense_nt_kernel<DG_GELUO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipGetLastError();
   }
   switch (mode) {
@@ -888,6 +896,7 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
     case DG_DGELU: dense_nt_kernel<DG_DGELU, 4><<<p.grid, 512, smem, s>>>(a); break;
     case DG_GELUF: dense_nt_kernel<DG_GELUF, 4><<<p.grid, 512, smem, s>>>(a); break;
     case DG_DFACT: dense_nt_kernel<DG_DFACT, 4><<<p.grid, 512, smem, s>>>(a); break;
+    case DG_GELUO: dense_nt_kernel<DG_GELUO, 4><<<p.grid, 512, smem, s>>>(a); break;
     default: return OCTIC_ESHAPE;
   }
   return launch_status();

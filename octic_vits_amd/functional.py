@@ -1055,7 +1055,11 @@ class DenseMlpFn(torch.autograd.Function):
         # octic_dense_gemm_nt) - the erf of the backward epilogue is computed once, in the forward, beside gelu's
         factor = GELU_FACTOR and "fc1" in DENSE_HIP and w2t is not None
         ctx.factor = factor
-        if "fc1" in DENSE_HIP:
+        if "fc1" in DENSE_HIP and not any(ctx.needs_input_grad):
+            # no backward will come (inference, the DINOv2 teacher): gelu(h) only, nothing kept (mode 6)
+            a = ops.dense_gemm_nt(y2, w1b, 6, bias=_f32(b1), name="dense_nt_kernel<gelu-only>")
+            h = a
+        elif "fc1" in DENSE_HIP:
             h, a = ops.dense_gemm_nt(y2, w1b, 4 if factor else 1, bias=_f32(b1), name="dense_nt_kernel<gelu>")
         else:
             h = _linear_lib(y2, w1b, None if b1 is None else c1.b)

@@ -1010,7 +1010,8 @@ def dense_colsum(g):
 def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None, want_colsum=False):
     """C[M,N] = a[M,K] @ b[N,K]^T on the hand-written MFMA kernel (csrc/dense_gemm.hip) with a fused tail:
     mode 0 -> c ; 1 -> (c, gelu(c)) ; 2 -> (c, x + rs*gamma*c) ; 3 -> gelu'(h) * c (want_colsum: also the f32 column
-    sums of that result) ; 4 -> (gelu'(c), gelu(c)) ; 5 -> h * c with h = the factor of mode 4 (want_colsum as 3).
+    sums of that result) ; 4 -> (gelu'(c), gelu(c)) ; 5 -> h * c with h = the factor of mode 4 (want_colsum as 3) ;
+    6 -> gelu(c) only.
     a, b bf16 2-D, K contiguous."""
     _require_cuda(a)
     M, K = a.shape

@@ -165,6 +165,44 @@ def test_dense_nt_dgelu(M, N, K):
     assert torch.equal(o.dense_gemm_nt(a, b, 3, h=h, want_colsum=True)[1], cs)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 264, 256), (12608, 5120, 1280), (16448, 5120, 1280)])
+def test_dense_nt_gelu_only_equals_the_gelu_output_of_mode_1(M, N, K):
+    """Mode 6 (round 5): gelu(acc + bias) alone for passes that never run a backward (inference, the DINOv2 teacher) -
+    the tensor mode 1 returns beside its pre-activation, bit for bit (same epilogue arithmetic), split-K tail tiles included."""
+    o = ops()
+    a, b = rnd((M, K), 21), rnd((N, K), 22, K ** -0.5)
+    bias = rnd((N,), 23, dtype=torch.float32)
+    _, y1 = o.dense_gemm_nt(a, b, 1, bias=bias)
+    y6 = o.dense_gemm_nt(a, b, 6, bias=bias)
+    assert y6.dtype == torch.bfloat16 and torch.equal(y6, y1)
+    assert torch.equal(o.dense_gemm_nt(a, b, 6), o.dense_gemm_nt(a, b, 1)[1])        # no bias
+
+
+def test_standard_mlp_without_grad_takes_the_gelu_only_epilogue():
+    """vit.Mlp.forward_fused under torch.no_grad (DenseMlpFn: no input needs a gradient -> mode 6) equals the training-mode
+    forward of the same inputs bit for bit when the training pass keeps h (GELU_FACTOR off: mode 1), and to one bf16 ulp of the
+    activation against the stored-factor form (mode 4)."""
+    from octic_vits_amd import functional as OF, vit
+    torch.manual_seed(0)
+    mlp = vit.Mlp(1280, 5120).cuda()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    y = torch.randn(2, 197, 1280, generator=g, device=DEV).to(torch.bfloat16)
+    x = torch.randn(2, 197, 1280, generator=g, device=DEV)
+    gamma = torch.rand(1280, generator=g, device=DEV)
+    with torch.no_grad():
+        out0 = mlp.forward_fused(y, x, gamma, None, torch.bfloat16)
+    old = OF.GELU_FACTOR
+    try:
+        OF.GELU_FACTOR = False
+        out1 = mlp.forward_fused(y.clone().requires_grad_(True), x.clone().requires_grad_(True), gamma, None, torch.bfloat16)
+        OF.GELU_FACTOR = True
+        out4 = mlp.forward_fused(y.clone().requires_grad_(True), x.clone().requires_grad_(True), gamma, None, torch.bfloat16)
+    finally:
+        OF.GELU_FACTOR = old
+    assert torch.equal(out0, out1.detach())
+    assert float((out0 - out4.detach()).abs().max()) <= 1e-2 * float(out0.abs().max())
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 264, 256), (16448, 5120, 1280)])
 def test_dense_nt_gelu_factor_pair(M, N, K):
     """Modes 4 / 5 (round 5): fc1's epilogue leaves gelu'(h) in bf16 beside gelu(h), fc2's input gradient multiplies by the
