@@ -169,6 +169,27 @@ def _baseline_metric():
 METRIC = _baseline_metric()
 
 
+def ssl_side_figure():
+    """BASELINE configs[4] on one GPU as a side figure (never `value`): tools/bench_ssl.py - the DINOv2 student / teacher step of
+    the hybrid ViT-H/16 (the largest DINOv2 factory the reference has; there is no ViT-g/14 one), 32 images per GPU = 64 global
+    224^2 + 256 local 96^2 crops, bf16, 65 536 prototypes - in a CHILD process started after the headline measurement: its
+    failure or timeout costs the line nothing."""
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        r = subprocess.run([sys.executable, os.path.join(here, "tools", "bench_ssl.py"), "32", "6"], capture_output=True,
+                           text=True, timeout=420, cwd=here)
+        m = re.search(r"([0-9.]+) ms/step, ([0-9.]+) images/s, peak memory ([0-9.]+) GiB", r.stdout or "")
+        if r.returncode != 0 or not m:
+            return {"ssl_side_error": ((r.stderr or r.stdout or "no output").strip().splitlines() or ["?"])[-1][:300]}
+        return {"ssl_step_ms": float(m.group(1)), "ssl_images_per_s": float(m.group(2)), "ssl_peak_gib": float(m.group(3)),
+                "ssl_note": "side figure, never `value`: DINOv2 student/teacher step (tools/bench_ssl.py: hybrid ViT-H/16, 32 "
+                            "images/GPU = 64 global + 256 local crops, bf16, eager, fused AdamW + EMA), child process"}
+    except Exception as e:
+        return {"ssl_side_error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +246,8 @@ def main():
     ap.add_argument("--force-ddp", action="store_true",
                     help="developer: wrap the model in DistributedDataParallel at world size 1 (one-rank RCCL group): the N > 1 "
                          "code path on one GPU")
+    ap.add_argument("--no-ssl-side", action="store_true",
+                    help="skip the DINOv2 student / teacher step side figure (BASELINE configs[4] on one GPU, a child process)")
     ap.add_argument("--no-step-variants", action="store_true",
                     help="skip the extra figures of the 1-GPU line (eager_ms_per_step, segment_graph_ms_per_step)")
     ap.add_argument("--bucket-mb", type=int, default=None, help="DDP gradient bucket size (default: train.DDP_BUCKET_MB)")
@@ -559,6 +582,8 @@ def main():
                 line.update(step_variants(trainer, model, samples, targets, args))
             except Exception as e:                    # side figures only: the line and its `value` are complete without them
                 line["step_variants_error"] = f"{type(e).__name__}: {e}"[:300]
+        if world == 1 and not args.no_ssl_side and not args.no_step_variants:
+            line.update(ssl_side_figure())
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=real_stdout, flush=True)
