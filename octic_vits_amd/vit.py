@@ -441,16 +441,16 @@ class NestedTensorBlock(Block):
             prev = _OF.RAGGED
             try:
                 _OF.RAGGED = sub
+                # (rows_ok looks at the weights and an upper bound of the row count: decided once, before anything runs)
+                maps_ok = ROW_MAPS and d % 4 == 0 and x.is_contiguous() and self.attn.rows_ok(x) and self.mlp.rows_ok(x)
                 for norm, branch, gamma in ((self.norm1, self.attn, gammas[0]), (self.norm2, self.mlp, gammas[1])):
                     idxs, rowmap = rag.take_subset(keeps, x.device)
-                    if rowmap is not None and ROW_MAPS and d % 4 == 0:
+                    if rowmap is not None and maps_ok:
                         # the kept rows read / written THROUGH a row map by the LayerNorm and the residual tail themselves
                         link = _OF._Link()
                         y, xa = _OF.DenseLayerNormRowsFn.apply(x, rowmap, norm.weight, norm.bias, norm.eps, bf, link)
-                        if branch.rows_ok(y):
-                            x = branch.forward_fused(y, xa, gamma, scale, bf, rows_to=_OF.RowsTo(x, rowmap, link))
-                            continue
-                        raise RuntimeError("NestedTensorBlock: the row-map path met a shape the dense kernels refuse")
+                        x = branch.forward_fused(y, xa, gamma, scale, bf, rows_to=_OF.RowsTo(x, rowmap, link))
+                        continue
                     link = _L._RowLink()
                     xa = _R.GatherSetsFn.apply(x, idxs, rag, sub, link)
                     y, xres = _OF.DenseLayerNormFn.apply(xa, norm.weight, norm.bias, norm.eps, bf)

@@ -394,3 +394,57 @@ def test_trainer_finish_checks_the_losses_the_late_watch_has_not_seen():
     t._watch.push(torch.tensor(float("inf")))    # the last step of a run: never reached by check()
     with pytest.raises(FloatingPointError):
         t.finish()
+
+
+def test_ragged_row_bookkeeping():
+    """ragged.Ragged (several crop sets in one row tensor): offsets, per-set views, per-sample -> per-row factors, the one-shot
+    draws of a pass - every row map is a set of DISTINCT rows made of whole kept samples, set-major, in the order the compact
+    tensor of the subset branch uses."""
+    import torch
+    from octic_vits_amd import ragged as R
+    a, b = torch.arange(2 * 5 * 4.0).view(2, 5, 4), 100 + torch.arange(3 * 2 * 4.0).view(3, 2, 4)
+    rows, rag = R.concat([a, b])
+    assert rag.sets == [(2, 5, 0), (3, 2, 10)] and rag.rows == 16 and rag.samples == 5 and rows.shape == (1, 16, 4)
+    assert rag.matches(rows) and not rag.matches(rows[:, :15])
+    va, vb = rag.views(rows)
+    assert torch.equal(va, a) and torch.equal(vb, b)
+    per_sample = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0])
+    assert rag.row_scale(per_sample).tolist() == [1.0] * 5 + [2.0] * 5 + [3.0] * 2 + [4.0] * 2 + [5.0] * 2
+    assert rag.row_to_sample("cpu").tolist() == [0] * 5 + [1] * 5 + [2] * 2 + [3] * 2 + [4] * 2
+    assert rag.const_row_scale([2.0, 1.5], "cpu").tolist() == [2.0] * 10 + [1.5] * 6
+    torch.manual_seed(0)
+    keeps = [1, 2]
+    rag.draw_perms(4, "cpu", keeps)
+    assert rag.rowmaps.shape == (4, 1 * 5 + 2 * 2) and rag.rowmaps.dtype == torch.int32
+    for i in range(4):
+        idxs, rowmap = rag.take_subset(keeps, "cpu")
+        assert [len(ix) for ix in idxs] == keeps
+        m = rowmap.tolist()
+        assert len(set(m)) == len(m)
+        want = [int(idxs[0][0]) * 5 + t for t in range(5)] + [10 + int(j) * 2 + t for j in idxs[1] for t in range(2)]
+        assert m == want
+    idxs, rowmap = rag.take_subset(keeps, "cpu")          # the pool is used up: fresh permutations, no map
+    assert rowmap is None and [len(ix) for ix in idxs] == keeps
+    rag.draw_perms(2, "cpu", keeps)
+    assert rag.take_subset([2, 2], "cpu")[1] is None      # other keep counts than the maps were drawn for
+
+
+def test_ragged_mask_pool_statistics():
+    import torch
+    from octic_vits_amd import ragged as R
+    from octic_vits_amd.d8_layers import DropPathD8
+
+    rag = R.Ragged([(400, 3), (600, 2)])
+    dps = [DropPathD8(0.25), DropPathD8(0.0), DropPathD8(0.5)]
+    for d in dps:
+        d.train()
+    torch.manual_seed(1)
+    rag.draw_masks(dps, "cpu")
+    assert set(rag.masks) == {id(dps[0]), id(dps[2])}       # inactive modules draw nothing
+    for d in (dps[0], dps[2]):
+        m = rag.masks[id(d)]
+        keep = 1 - d.drop_prob
+        assert m.shape == (rag.rows,) and all(v == 0.0 or abs(v - 1 / keep) < 1e-6 for v in m.unique().tolist())
+        per_sample = torch.cat([m[:1200].view(400, 3)[:, 0], m[1200:].view(600, 2)[:, 0]])
+        assert torch.equal(rag.row_scale(per_sample), m)     # one value per sample, repeated over its rows
+        assert abs(float((per_sample > 0).float().mean()) - keep) < 0.06
