@@ -429,11 +429,27 @@ def main():
                     torch.cuda.synchronize()
                     if i >= 10:
                         times.append(time.time() - t1)
-        model.train()
         mean = sum(times) / len(times)
         fwd_only = {"images_per_s": round(64 / mean, 1), "ms_per_forward": round(mean * 1e3, 3),
                     "protocol": "experiments/complexity.py: eval, no_grad, batch 64, 224x224, 10 warm-up + 100 forwards, "
                                 "synchronize after each, mean; bf16 autocast (reference: fp16 autocast + torch.compile)"}
+        try:                                          # the same protocol with the forward as one hipGraph replay (serve.py)
+            from octic_vits_amd.serve import GraphedForward
+            gf = GraphedForward(model, img)
+            gt = []
+            for i in range(10 + 100):
+                t1 = time.time()
+                gf(img, copy_out=False)
+                torch.cuda.synchronize()
+                if i >= 10:
+                    gt.append(time.time() - t1)
+            gm = sum(gt) / len(gt)
+            fwd_only["graph_images_per_s"] = round(64 / gm, 1)
+            fwd_only["graph_ms_per_forward"] = round(gm * 1e3, 3)
+            del gf
+        except Exception as e:
+            fwd_only["graph_error"] = f"{type(e).__name__}: {e}"[:200]
+        model.train()
         log(f"forward-only (reference protocol): {fwd_only['images_per_s']} img/s")
     if world > 1:
         dist.barrier()

@@ -579,3 +579,27 @@ def test_compacted_stochastic_depth_equals_the_masked_full_batch():
     assert g_f.keys() == g_c.keys()
     worst = max((float((g_c[n] - g_f[n]).norm() / g_f[n].norm().clamp_min(1e-6)), n) for n in g_f)
     assert worst[0] <= 3e-2, worst
+
+
+def test_graphed_inference_forward_equals_eager_and_refuses_stale_weights():
+    """serve.GraphedForward: the eval forward of a hybrid model as one hipGraph replay - bitwise equal to the eager forward on
+    fresh inputs, shape changes and parameter updates behind the graph are refused."""
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.serve import GraphedForward
+    torch.manual_seed(0)
+    net = OcticVisionTransformer(img_size=32, patch_size=4, embed_dim=256, depth=4, num_heads=4, num_classes=10).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x0 = torch.randn(8, 3, 32, 32, generator=g, device="cuda")
+    gf = GraphedForward(net, x0)
+    for seed in (2, 3):
+        x = torch.randn(8, 3, 32, 32, generator=torch.Generator(device="cuda").manual_seed(seed), device="cuda")
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            want = net(x)
+        got = gf(x)
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        gf(x[:4])
+    with torch.no_grad():
+        net.head.weight.add_(1.0)
+    with pytest.raises(RuntimeError):
+        gf(x)
