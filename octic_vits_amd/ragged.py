@@ -18,6 +18,11 @@ from . import ops
 
 
 _CONST_SCALES = {}         # (sets, per-set constants, device) -> [R] f32 per-row factors
+# Test hooks (None = draw): MASK_SOURCE(live drop-path modules, ragged) -> [len(live), samples] 0/1 keep masks;
+# PERM_SOURCE(n, ragged) -> per set an [n, B] integer tensor of permutations.  They let a test replay the draws of a
+# reference run (tests/test_ssl_gpu.py: the oracle's masks and batch subsets) through the one-shot draws of a pass.
+MASK_SOURCE = None
+PERM_SOURCE = None
 
 
 class Ragged:
@@ -76,7 +81,10 @@ class Ragged:
             kd = _CONST_SCALES[key] = (torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1),
                                        torch.tensor(divs, dtype=torch.float32, device=device).unsqueeze(1))
         keep, div = kd
-        m = (torch.rand(len(live), self.samples, device=device) < keep).float() / div
+        if MASK_SOURCE is not None:
+            m = MASK_SOURCE(live, self).to(device=device, dtype=torch.float32) / div
+        else:
+            m = (torch.rand(len(live), self.samples, device=device) < keep).float() / div
         rows = m.index_select(1, self.row_to_sample(device))
         self.masks = {id(d): rows[i] for i, d in enumerate(live)}
 
@@ -85,7 +93,10 @@ class Ragged:
         stochastic depth of n branches would draw with n x sets torch.randperm calls.  keeps (kept samples per set, the same
         for all n branches): also the n ROW MAPS [n, sum_i keeps_i T_i] int32 - compact row (set-major, kept sample, token) ->
         row of the full tensor - that let the LayerNorm / tail kernels read and write the kept rows in place."""
-        self.perms = [torch.rand(n, B, device=device).argsort(dim=1) for B, _, _ in self.sets]
+        if PERM_SOURCE is not None:
+            self.perms = [p.to(device=device, dtype=torch.int64) for p in PERM_SOURCE(n, self)]
+        else:
+            self.perms = [torch.rand(n, B, device=device).argsort(dim=1) for B, _, _ in self.sets]
         self.perm_at = 0
         self.rowmaps, self.map_keeps = None, None
         if keeps is not None:

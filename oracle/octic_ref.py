@@ -926,12 +926,17 @@ class OcticVisionTransformer(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # DINOv2 entry points (octic_vits/dinov2_models.py) with the standard blocks of dinov2/layers/block.py
 # ----------------------------------------------------------------------------------------------
+subset_observer = None      # test hook: callable (batch, kept indices) called for every batch-subset draw, in draw order
+
+
 def drop_add_residual_stochastic_depth(x, residual_func, sample_drop_ratio=0.0):
     """dinov2/layers/block.py:113-140: the residual branch runs on a random subset of the batch and is added back
     scaled by batch / subset (training with drop_path > 0.1)."""
     b = x.shape[0]
     keep = max(int(b * (1 - sample_drop_ratio)), 1)
     brange = torch.randperm(b, device=x.device)[:keep]
+    if subset_observer is not None:                  # test hook: sees every subset in the order the reference draws them
+        subset_observer(b, brange)
     residual = residual_func(x[brange]).flatten(1)
     out = torch.index_add(x.flatten(1), 0, brange, residual.to(x.dtype), alpha=b / keep)
     return out.view_as(x)

@@ -209,6 +209,106 @@ def test_crop_sets_as_one_row_tensor_equal_the_set_by_set_loop():
         opt.step()
 
 
+def test_stochastic_depth_of_the_one_row_tensor_pass_matches_the_oracle_draw_for_draw():
+    """The student pass with drop_path 0.4 against the CPU oracle WITH THE SAME RANDOM DRAWS: the oracle (set-by-set loop,
+    dinov2_models.py:139-160; per-sample masks of the octic blocks, d8_layers.py:249-271; batch subsets of the standard
+    blocks, dinov2/layers/block.py:113-140) runs first and its draws are recorded in draw order (block -> crop set -> branch);
+    the engine's pass - both crop sets as one row tensor, masks and subsets drawn once per pass, the subset's rows through row
+    maps - replays them through ragged.MASK_SOURCE / PERM_SOURCE.  Outputs within 3e-2 of scale, every parameter gradient
+    within max(5e-2, 2.5 x the oracle's own distance under CPU bf16 autocast with the same draws)."""
+    import numpy as np
+    from octic_vits_amd import ragged as RG
+    kw_strip = lambda kw: {k: v for k, v in kw.items() if k != "init_values"}
+    ref = R.OcticDinoVisionTransformer(
+        img_size=32, patch_size=4, embed_dim=256, depth=4, num_heads=4, drop_path_rate=0.4,
+        octic_block_layers=lambda **kw: R.NestedTensorBlockD8(init_values=0.3, **kw_strip(kw)),
+        standard_block_layers=lambda **kw: R.NestedTensorBlock(init_values=0.3, **kw_strip(kw)))
+    ref.patch_embed.strict_img_size = False
+    cases.fill_parameters(ref, salt="ragdp.")
+    net = _hd64_backbone(drop_path=0.4)
+    net.patch_embed.strict_img_size = False
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.cuda().train()
+    ref.train()
+    xg, xl = cases.randn("ragdp.g", 4, 3, 32, 32), cases.randn("ragdp.l", 8, 3, 16, 16)
+    cg, cl = cases.randn("ragdp.cg", 4, 65, 256), cases.randn("ragdp.cl", 8, 17, 256)
+    names = [n for n, p in ref.named_parameters() if p.requires_grad]
+
+    def tokens(o):
+        return torch.cat([o["x_norm_clstoken"].unsqueeze(1), o["x_norm_patchtokens"]], 1)
+
+    rec_masks, rec_subsets = [], []
+
+    def mask_rec(B, keep):
+        m = torch.empty((B, 1, 1)).bernoulli_(keep).flatten()       # the reference's own call (d8_layers.py:256-262)
+        rec_masks.append(m.clone())
+        return m
+
+    def oracle(autocast):
+        rec_masks.clear()
+        rec_subsets.clear()
+        for p in ref.parameters():
+            p.grad = None
+        torch.manual_seed(77)
+        R.drop_path_mask_source, R.subset_observer = mask_rec, lambda b, br: rec_subsets.append((b, br.clone()))
+        try:
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    og, ol = ref([xg, xl], masks=[None, None], is_training=True)
+            else:
+                og, ol = ref([xg, xl], masks=[None, None], is_training=True)
+        finally:
+            R.drop_path_mask_source, R.subset_observer = None, None
+        tg, tl = tokens(og).float(), tokens(ol).float()
+        ((tg * cg).sum() + (tl * cl).sum()).backward()
+        rp = dict(ref.named_parameters())
+        return tg.detach(), tl.detach(), {n: rp[n].grad.detach().double().numpy().copy() for n in names if rp[n].grad is not None}
+
+    tg0, tl0, g_ref = oracle(False)
+    masks0, subsets0 = [m.clone() for m in rec_masks], [(b, s.clone()) for b, s in rec_subsets]
+    _, _, g_yard = oracle(True)
+    assert all(torch.equal(a, b) for a, b in zip(masks0, rec_masks)) and all(torch.equal(a[1], b[1]) for a, b in zip(subsets0, rec_subsets))
+    assert len(masks0) == 2 * 2 * 2 and len(subsets0) == 2 * 2 * 2        # 2 blocks x 2 crop sets x 2 branches, each half
+
+    def mask_source(live, rag):          # live = [blk0.dp1, blk0.dp2, blk1.dp1, blk1.dp2]; oracle order: block, set, branch
+        assert len(live) == 4 and rag.samples == 12
+        return torch.stack([torch.cat([masks0[(i // 2) * 4 + s * 2 + (i % 2)] for s in range(2)]) for i in range(4)])
+
+    def perm_source(n, rag):             # branch i = 2 * block + branch of the standard half; per set an [n, B] permutation
+        assert n == 4
+        out = []
+        for s, (B, _, _) in enumerate(rag.sets):
+            rows = []
+            for i in range(n):
+                b, br = subsets0[(i // 2) * 4 + s * 2 + (i % 2)]
+                assert b == B
+                rest = torch.tensor([j for j in range(B) if j not in set(br.tolist())], dtype=torch.int64)
+                rows.append(torch.cat([br.to(torch.int64), rest]))
+            out.append(torch.stack(rows))
+        return out
+
+    RG.MASK_SOURCE, RG.PERM_SOURCE = mask_source, perm_source
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            og, ol = net([xg.cuda(), xl.cuda()], masks=[None, None], is_training=True)
+        tg, tl = tokens(og).float(), tokens(ol).float()
+        ((tg * cg.cuda()).sum() + (tl * cl.cuda()).sum()).backward()
+    finally:
+        RG.MASK_SOURCE, RG.PERM_SOURCE = None, None
+    assert net._single_use_pass
+    for got, want in ((tg, tg0), (tl, tl0)):
+        assert float((got.detach().cpu() - want).abs().max()) <= 3e-2 * float(want.abs().max())
+    mp = dict(net.named_parameters())
+    bad = []
+    for n, w in g_ref.items():
+        den = max(float(np.linalg.norm(w)), 1e-6)
+        rel = float(np.linalg.norm(mp[n].grad.detach().double().cpu().numpy() - w)) / den
+        rel_oracle = float(np.linalg.norm(g_yard[n] - w)) / den
+        if rel > max(5e-2, 2.5 * rel_oracle):
+            bad.append((n, round(rel, 4), round(rel_oracle, 4)))
+    assert not bad, bad[:8]
+
+
 def test_ssl_trainer_batched_finishes_equal_immediate_ones():
     """SSLTrainer on a backbone whose crop sets run as one row tensor (every block module used once per pass): the
     parameter-gradient reductions batched at the end of backward + the paired qkv / proj weight gradients (train.BATCHED_FINISHES)
