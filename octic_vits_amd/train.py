@@ -25,6 +25,12 @@ import torch.nn as nn
 # first iteration), so the exposed tail is one 48 MB all-reduce (~0.6 ms at ring speed) instead of a 128 MB one, while
 # each collective is still large enough (>> 1 MB) to run at link bandwidth rather than latency.
 DDP_BUCKET_MB = 48
+# DistributedDataParallel copies EVERY parameter gradient into its bucket with one launch per tensor when autograd accumulates it
+# (reducer.cpp mark_variable_ready_dense; 978 launches = 4.5 ms per ViT-H step, profiles NOTES section 9) - for the hundreds of
+# small tensors (biases, norm / layer-scale vectors, the 160 x 160 irrep blocks: 721 of the 978, 29 MB of the 1.42 GB) that is
+# all launch cost.  Tensors of at most this many elements are kept OUT of DDP and all-reduced as ONE flat buffer after the
+# backward pass (a handful of launches: concatenate, one collective, copy back); 0 = everything through DDP's buckets.
+DDP_FLAT_SMALL_NUMEL = 100_000
 
 
 class Lamb(torch.optim.Optimizer):
@@ -572,9 +578,9 @@ class DdpTrafficProxy:
         self.scratch = None
         self.bytes = 0                                  # bytes read (= bytes written) by the side stream so far
 
-    def hook(self, state, bucket):
-        buf = bucket.buffer()
-        n = buf.numel() // 2 if self.halve else buf.numel()     # bf16 buckets: half the payload
+    def traffic(self, buf, halve=False):
+        """Move `buf`'s bytes `copies` times on the side stream (what a collective over it would read and write)."""
+        n = buf.numel() // 2 if halve else buf.numel()
         if self.copies > 0 and n > 0:
             if self.scratch is None or self.scratch.numel() < n:
                 self.scratch = torch.empty(n, dtype=buf.dtype, device=buf.device)
@@ -583,6 +589,10 @@ class DdpTrafficProxy:
                 for _ in range(self.copies):
                     self.scratch[:n].copy_(buf[:n], non_blocking=True)
             self.bytes += n * buf.element_size() * self.copies
+
+    def hook(self, state, bucket):
+        buf = bucket.buffer()
+        self.traffic(buf, self.halve)                   # bf16 buckets: half the payload
         fut = torch.futures.Future()
         fut.set_result(buf)
         return fut
@@ -700,6 +710,23 @@ class Trainer:
     def _wrap_ddp(self):
         local_rank, bucket_cap_mb, bf16_buckets = self._ddp_args
         # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)
+        self._small = []
+        if DDP_FLAT_SMALL_NUMEL > 0:
+            small = [p for p in self.model.parameters() if p.requires_grad and p.numel() <= DDP_FLAT_SMALL_NUMEL]
+            big = sum(1 for p in self.model.parameters() if p.requires_grad) - len(small)
+            if small and big > 0:
+                ids = {id(p) for p in small}
+                # every name a small parameter can be reached by (a module registered twice - train._Segment - has two)
+                names = [f"{mn}.{pn}" if mn else pn for mn, mod in self.model.named_modules(remove_duplicate=False)
+                         for pn, p in mod.named_parameters(recurse=False) if id(p) in ids]
+                nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(self.model, names)
+                self._small = small
+                if dist.get_world_size() > 1:          # DDP broadcasts rank 0's values of the parameters IT manages only
+                    with torch.no_grad():
+                        flat = torch.cat([p.detach().reshape(-1) for p in self._small])
+                        dist.broadcast(flat, 0)
+                        torch._foreach_copy_([p.data for p in self._small],
+                                             [t.view_as(p) for t, p in zip(flat.split([p.numel() for p in self._small]), self._small)])
         self.model = nn.parallel.DistributedDataParallel(
             self.model, device_ids=[local_rank] if self.device_type == "cuda" else None,
             bucket_cap_mb=bucket_cap_mb or DDP_BUCKET_MB,
@@ -709,6 +736,34 @@ class Trainer:
         elif bf16_buckets:
             from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
             self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
+
+    @torch.no_grad()
+    def _reduce_small_grads(self):
+        """The gradients DDP does not manage (DDP_FLAT_SMALL_NUMEL): mean over the ranks through ONE flat buffer."""
+        small = getattr(self, "_small", None)
+        if not small:
+            return
+        world = dist.get_world_size()
+        if world == 1 and self._proxy is None:
+            return                                      # one rank: the gradients are final as they are
+        live = [p for p in small if p.grad is not None]
+        if not live:
+            return
+        key = tuple(id(p) for p in live)
+        if getattr(self, "_small_key", None) != key:    # (built once: the set of tensors with gradients does not change)
+            n = sum(p.numel() for p in live)
+            self._small_flat = torch.empty(n, dtype=live[0].grad.dtype, device=live[0].grad.device)
+            self._small_views = [t.view_as(p) for t, p in zip(self._small_flat.split([p.numel() for p in live]), live)]
+            self._small_key = key
+        grads = [p.grad for p in live]
+        torch._foreach_copy_(self._small_views, grads)
+        flat = self._small_flat
+        if world > 1:
+            flat.div_(world)
+            dist.all_reduce(flat)
+        else:
+            self._proxy.traffic(flat)                   # the 1-GPU stand-in for the collective (DdpTrafficProxy)
+        torch._foreach_copy_(grads, self._small_views)
 
     def capture_segments(self, samples, warmup=3):
         """hipGraphs for the slices of a ``segment_graphs`` trainer (call once, with ONE micro-batch of the training
@@ -795,6 +850,7 @@ class Trainer:
                     li = self._forward_loss(x, y) / len(xs)
                     li.backward()
                 loss = li.detach() if loss is None else loss + li.detach()
+        self._reduce_small_grads()
         if self._proxy is not None:
             self._proxy.join()                          # the optimizer reads the "reduced" buckets
         self.optimizer.step()

@@ -108,15 +108,27 @@ def _accum_batch():
     return x, y
 
 
-def _accum_worker(rank, world, port, out):
+def _accum_worker(rank, world, port, out, flat_numel=None):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
+    from octic_vits_amd import train as TR
     from octic_vits_amd.train import Trainer, init_distributed
     init_distributed()
     x, y = _accum_batch()
     per = 8 // world
-    tr = Trainer(_Net(), distributed=True, fused_optimizer=False, tuned_gemms=False, autocast=False, accum_steps=2,
+    net = _Net()
+    if flat_numel is not None:
+        # small tensors (biases, norm / layer-scale vectors) outside DDP, reduced as one flat buffer (train.DDP_FLAT_SMALL_NUMEL);
+        # rank 1 starts from other values: the wrapper must bring rank 0's over for the tensors DDP does not manage too
+        TR.DDP_FLAT_SMALL_NUMEL = flat_numel
+        if rank == 1:
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(0.37)
+    tr = Trainer(net, distributed=True, fused_optimizer=False, tuned_gemms=False, autocast=False, accum_steps=2,
                  ema_decay=None, device_type="cpu", bucket_cap_mb=1)
+    if flat_numel is not None:
+        assert 0 < len(tr._small) < sum(1 for p in net.parameters() if p.requires_grad)
     for _ in range(3):
         tr.step(x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per])
     flat = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
@@ -127,6 +139,25 @@ def _accum_worker(rank, world, port, out):
         torch.save(flat, out)
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_small_gradients_outside_ddp_as_one_flat_all_reduce(tmp_path):
+    """train.DDP_FLAT_SMALL_NUMEL: tensors of at most that many elements are not handed to DistributedDataParallel (which
+    copies every gradient into its bucket with one launch per tensor) but averaged over the ranks as ONE flat buffer after the
+    backward pass - 2 ranks x 2 accumulated micro-batches with a threshold that splits this model's tensors, rank 1 starting
+    from different values: equal to one process on all 8 samples."""
+    out = str(tmp_path / "flat.pt")
+    mp.spawn(_accum_worker, args=(2, _free_port(), out, 64), nprocs=2, join=True)
+    ddp = torch.load(out)
+    from octic_vits_amd.train import Trainer
+    x, y = _accum_batch()
+    tr = Trainer(_Net(), distributed=False, fused_optimizer=False, tuned_gemms=False, autocast=False, accum_steps=1,
+                 ema_decay=None, device_type="cpu")
+    for _ in range(3):
+        tr.step(x, y)
+    single = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
+    assert torch.allclose(ddp, single, rtol=1e-4, atol=1e-5), float((ddp - single).abs().max())
 
 
 @pytest.mark.timeout(300)
