@@ -290,7 +290,7 @@ class LinearD8Fn(torch.autograd.Function):
         w32 = [_c(w.detach().float()) for w in w5] if has_cs else None
         f32_masters = all(w.dtype == torch.float32 for w in w5)      # else the casts below read dw at once: no deferral
         dw, dcs, dbias = ops.linear_wgrad(xv, gv, M, cin, cout, dtype, x, w32=w32, cs5=cs32, bias=b32, dysum=dysum,
-                                          want_bias=has_bias, may_defer=f32_masters)
+                                          want_bias=has_bias, may_defer=f32_masters, wparams=w5 if f32_masters else None)
         if not f32_masters:
             dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
         dcs = dcs if has_cs else [None] * 5
@@ -362,7 +362,7 @@ class LinearD8NormFn(torch.autograd.Function):
         w32 = [_c(w.detach().float()) for w in w5] if has_cs else None
         f32_masters = all(w.dtype == torch.float32 for w in w5)      # else the casts below read dw at once: no deferral
         dw, dcs, dbias = ops.linear_wgrad(xv, gv, M, cin, cout, dtype, x, w32=w32, cs5=cs32, bias=b32, dysum=dysum,
-                                          want_bias=has_bias, may_defer=f32_masters)
+                                          want_bias=has_bias, may_defer=f32_masters, wparams=w5 if f32_masters else None)
         if not f32_masters:
             dw = [d.to(w.dtype) for d, w in zip(dw, w5)]
         dcs = dcs if has_cs else [None] * 5
@@ -699,6 +699,7 @@ class LinearScaleResidualFn(torch.autograd.Function):
         out = ops.scale_residual_fwd(x, y, g32, rs32, rps)
         ctx.save_for_backward(ab, wb, y, g32, rs32)
         ctx.meta = (rps, b is not None, gamma is not None, a.dtype)
+        ctx.wparam = w
         return out
 
     @staticmethod
@@ -709,7 +710,7 @@ class LinearScaleResidualFn(torch.autograd.Function):
         gy, dgamma, colsum = ops.scale_residual_bwd(gout, y, g32, rs32, rps, want_gamma=has_gamma, want_colsum=has_b)
         g2, a2 = gy.reshape(-1, wb.shape[0]), ab.reshape(-1, wb.shape[1])
         ga = _mm_lib(g2, wb).view(ab.shape).to(a_dtype) if ctx.needs_input_grad[1] else None
-        gw = _wgrad_lib(g2, a2)
+        gw = _wgrad_lib(g2, a2, ctx.wparam)
         return gout, ga, gw, colsum, dgamma, None, None, None, None
 
 
@@ -821,13 +822,14 @@ def wgrad_slabs(M, N, K):
 WGRAD_HIP = True
 
 
-def _wgrad_lib(g2, x2):
-    """dW = g^T x (f32 result): the hand-written TN kernel wherever it takes the shape, else the BLAS library."""
+def _wgrad_lib(g2, x2, wparam=None):
+    """dW = g^T x (f32 result): the hand-written TN kernel wherever it takes the shape, else the BLAS library.  wparam: the
+    parameter this is the gradient of - under DDP the result is written into its bucket view (ops.GRAD_DEST)."""
     M, N, K = g2.shape[0], g2.shape[1], x2.shape[1]
     if (WGRAD_HIP and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
             and g2.stride(1) == 1 and x2.stride(1) == 1 and ops.dense_wgrad_ok(M, N, K)
             and M * max(g2.stride(0), x2.stride(0)) * 2 < 2 ** 31):
-        return ops.dense_wgrad_tn(g2, x2)
+        return ops.dense_wgrad_tn(g2, x2, out=ops.grad_dest(wparam, (N, K)))
     S = wgrad_slabs(M, N, K)
     if S > 1 and g2.is_contiguous() and x2.is_contiguous():
         with torch.autocast("cuda", enabled=False):
@@ -906,6 +908,7 @@ class DenseLinearNTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, cache, tag, pair=None):
         ctx.pair = pair
+        ctx.wparam = w
         xb = _c(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
         wb, wt = cache.get_nt(w, b, ("d" + tag) in DENSE_HIP and ctx.needs_input_grad[0])
         x2 = xb.reshape(-1, wb.shape[1])
@@ -939,7 +942,7 @@ class DenseLinearNTFn(torch.autograd.Function):
                 dw, _ = ops.dense_wgrad_tn_pair(g2, x2, pg, px, dw1=pdw)
                 return gx, dw, gb, None, None, None
             pair.flush()
-        return gx, _wgrad_lib(g2, x2), gb, None, None, None
+        return gx, _wgrad_lib(g2, x2, ctx.wparam), gb, None, None, None
 
 
 class DenseProjResidFn(torch.autograd.Function):
@@ -953,6 +956,7 @@ class DenseProjResidFn(torch.autograd.Function):
         tensor so that autograd sees the in-place edit): x are compact rows of the stream, the result goes back into it."""
         ctx.pair = pair
         ctx.rows_to = rows_to
+        ctx.wparam = w
         x = _c(x)
         ab = _c(a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16))
         wb, wt = cache.get_nt(w, b, "dproj" in DENSE_HIP and ctx.needs_input_grad[1])
@@ -1027,7 +1031,7 @@ class DenseProjResidFn(torch.autograd.Function):
         if _pair_ready(ctx.pair, gy, a2) and ops.dense_wgrad_ok(gy.shape[0], gy.shape[1], a2.shape[1]):
             dw = ctx.pair.park(gy, a2)           # written by the qkv weight gradient's launch (or at the end of the pass)
         else:
-            dw = _wgrad_lib(gy, a2)
+            dw = _wgrad_lib(gy, a2, ctx.wparam)
         gx = None if ctx.rows_to is not None else gout.view(ctx.x_shape)
         return gx, ga, dw, colsum, dgamma, None, None, None, dnw, dnb, None, None, None, None
 
@@ -1044,6 +1048,7 @@ class DenseMlpFn(torch.autograd.Function):
         """neps is not None: also return LayerNorm(out; nw, nb, neps) in bf16 (the NEXT block's norm1) from the row pass
         that adds the residual.  rows_to / stream: as in DenseProjResidFn."""
         ctx.rows_to = rows_to
+        ctx.wparams = (w1, w2)
         x = _c(x)
         yb = _c(y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16))
         need_t = any(ctx.needs_input_grad[:2])            # (an inference pass - the DINOv2 teacher - never transposes)
@@ -1139,8 +1144,8 @@ class DenseMlpFn(torch.autograd.Function):
                 dh, db1 = ops.dense_gemm_nt(gbr, w2t, md, h=h, name="dense_nt_kernel<dgelu>"), None
         else:
             dh, db1 = ops.dense_gelu_bwd(h, _mm_lib(gbr, w2b), want_colsum=has_b1)
-        gw2 = _wgrad_lib(gbr, a)
-        gw1 = _wgrad_lib(dh, y2)
+        gw2 = _wgrad_lib(gbr, a, ctx.wparams[1])
+        gw1 = _wgrad_lib(dh, y2, ctx.wparams[0])
         gy = None
         if ctx.needs_input_grad[0]:
             gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>") if w1t is not None

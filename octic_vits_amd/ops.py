@@ -281,8 +281,24 @@ def dense_wgrad_ok(M, N, K):
     return N % 256 == 0 and (K % 256 == 0 or K % 320 == 0) and (N // 256) * (K // 256) <= 256 and M > 0
 
 
-def dense_wgrad_tn(dy, x, name=None):
-    """dW[N,K] = dy[M,N]^T @ x[M,K] in f32 on csrc/dense_wgrad.hip."""
+# Where a weight gradient is to be WRITTEN (train.Trainer under DistributedDataParallel, one micro-batch): parameter address ->
+# its bucket view.  A gradient produced inside the bucket is an alias of the view: the reducer recognises it and skips its
+# per-tensor copy (reducer.cpp mark_variable_ready_dense).  None = fresh tensors (every other mode).
+GRAD_DEST = None
+
+
+def grad_dest(param, shape):
+    """A fresh tensor object aliasing the registered destination of `param`'s gradient, or None."""
+    if GRAD_DEST is None or param is None:
+        return None
+    d = GRAD_DEST.get(param.data_ptr())
+    if d is None or param.grad is not None or tuple(d.shape) != tuple(shape) or d.dtype != torch.float32 or not d.is_contiguous():
+        return None
+    return d.detach()
+
+
+def dense_wgrad_tn(dy, x, name=None, out=None):
+    """dW[N,K] = dy[M,N]^T @ x[M,K] in f32 on csrc/dense_wgrad.hip (out: write it there)."""
     _require_cuda(dy)
     M, N = dy.shape
     K = x.shape[1]
@@ -292,7 +308,7 @@ def dense_wgrad_tn(dy, x, name=None):
     ws = _DW_WS.get(dy.device)
     if ws is None or ws.numel() < need:          # one workspace per device: launches on a stream are serial
         ws = _DW_WS[dy.device] = torch.zeros(need, dtype=torch.uint8, device=dy.device)
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dy.device)
     t = KERNEL_TIMER.start()
     check(lib().octic_dense_wgrad_tn(_p(dy), _p(x), M, N, K, dy.stride(0), x.stride(0), _p(dw), _p(ws), _stream(dy)))
     KERNEL_TIMER.stop(t, name or f"dense_tn_kernel<{N}x{K}>", 2 * (M * N + M * K) + 4 * N * K, 2.0 * M * N * K)
@@ -350,7 +366,7 @@ def linear_kernel_name(cin, dtype, out_dtype, fused):
 
 
 def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=None, dysum=None, want_bias=False,
-                 may_defer=True):
+                 may_defer=True, wparams=None):
     """Returns (dw5 [f32], dcs5 or None, dbias or None).  may_defer=False: the caller reads the results at once (e.g. casts
     them for non-f32 master weights), so the slab reduction must not be postponed to the end of the backward pass."""
     L = lib()
@@ -368,8 +384,9 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
         # slabs: the two-dimensional irrep (half of the 8*cin*cout weights) uses `splits`, the others splits/2
         slab = (splits + (splits + 1) // 2) * 4 * cin * cout * 4
         KERNEL_TIMER.stop(t, name, M * 8 * (cin + cout) * es + slab, 24.0 * M * cin * cout)
-    dw = [torch.empty((cout, cin), dtype=torch.float32, device=dev) for _ in range(4)]
-    dw.append(torch.empty((2 * cout, 2 * cin), dtype=torch.float32, device=dev))
+    shapes = [(cout, cin)] * 4 + [(2 * cout, 2 * cin)]
+    dests = [grad_dest(w, sh) for w, sh in zip(wparams, shapes)] if wparams is not None else [None] * 5
+    dw = [d if d is not None else torch.empty(sh, dtype=torch.float32, device=dev) for d, sh in zip(dests, shapes)]
     dcs = None
     if cs5 is not None:
         dcs = [torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(4)]

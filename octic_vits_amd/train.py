@@ -31,6 +31,7 @@ DDP_BUCKET_MB = 48
 # all launch cost.  Tensors of at most this many elements are kept OUT of DDP and all-reduced as ONE flat buffer after the
 # backward pass (a handful of launches: concatenate, one collective, copy back); 0 = everything through DDP's buckets.
 DDP_FLAT_SMALL_NUMEL = 100_000
+DDP_GRADS_IN_BUCKETS = True     # the weight-gradient kernels write into DDP's bucket views (no per-tensor bucket copy); A/B switch
 
 
 class Lamb(torch.optim.Optimizer):
@@ -731,11 +732,22 @@ class Trainer:
             self.model, device_ids=[local_rank] if self.device_type == "cuda" else None,
             bucket_cap_mb=bucket_cap_mb or DDP_BUCKET_MB,
             gradient_as_bucket_view=True, find_unused_parameters=False, static_graph=False)
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         if self._proxy is not None:
             self.model.register_comm_hook(None, self._proxy.hook)
         elif bf16_buckets:
-            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
             self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
+        else:
+            # the reducer's own path divides every gradient that already lives in its bucket by the world size with one launch
+            # per tensor; with a communication hook the division is one launch per bucket
+            self.model.register_comm_hook(None, default_hooks.allreduce_hook)
+        # Weight gradients written straight into DDP's bucket views (ops.GRAD_DEST): the views a step's backward leaves in
+        # .grad are where the next step's weight-gradient kernels write - the reducer sees an alias and skips its copy.
+        # Eager single-micro-batch steps on the GPU only (accumulation adds into .grad; graphed slices own their outputs).
+        self._grad_dest = {} if (DDP_GRADS_IN_BUCKETS and self.device_type == "cuda" and self.accum_steps == 1
+                                 and self.segmented is None) else None
+        small_ids = {id(p) for p in self._small}
+        self._ddp_params = [p for p in self.raw_model.parameters() if p.requires_grad and id(p) not in small_ids]
 
     @torch.no_grad()
     def _reduce_small_grads(self):
@@ -838,8 +850,20 @@ class Trainer:
             self.optimizer.zero_grad(set_to_none=True)
         if k == 1:
             loss = self._forward_loss(samples, targets)
-            with self._batched_finishes():
-                loss.backward()
+            dest = getattr(self, "_grad_dest", None)
+            if dest is not None:
+                from . import ops as _ops
+                _ops.GRAD_DEST = dest
+                try:
+                    loss.backward()
+                finally:
+                    _ops.GRAD_DEST = None
+                for p in self._ddp_params:              # (bucket views: DDP re-points .grad at them in its hooks)
+                    if p.grad is not None:
+                        dest[p.data_ptr()] = p.grad
+            else:
+                with self._batched_finishes():
+                    loss.backward()
         else:
             xs, ys = samples.chunk(k), targets.chunk(k)
             loss = None
