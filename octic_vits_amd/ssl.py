@@ -562,11 +562,18 @@ class SSLTrainer:
 
                 def forward(s, g, l, m):
                     return s.backbone([g, l], masks=[m, None], is_training=True)
+            from .train import FlatGradReducer, ddp_ignore_small
+            fwd = _Fwd(arch)
+            # the backbone's small tensors stay out of DistributedDataParallel (one launch per tensor in its reducer) and join
+            # the heads - which are outside the wrapper anyway - in ONE flat all-reduce after the backward pass
+            small = ddp_ignore_small(fwd)
+            self._head_params = [p for k in arch.student if k != "backbone" for p in arch.student[k].parameters()]
+            self._flat_reducer = FlatGradReducer(small + [p for p in self._head_params if p.requires_grad])
+            FlatGradReducer(small).broadcast()                    # (the heads are built identical: ssl_meta_arch seeds them)
             self._ddp = nn.parallel.DistributedDataParallel(
-                _Fwd(arch), device_ids=[local_rank] if self.device_type == "cuda" else None, bucket_cap_mb=128,
+                fwd, device_ids=[local_rank] if self.device_type == "cuda" else None, bucket_cap_mb=128,
                 gradient_as_bucket_view=True)
             arch._student_call = lambda g, l, m: tuple(self._ddp(g, l, m))
-            self._head_params = [p for k in arch.student if k != "backbone" for p in arch.student[k].parameters()]
         else:
             self._ddp, self._head_params = None, []
 
@@ -582,11 +589,8 @@ class SSLTrainer:
                 loss_dict = self.arch.forward_backward(images, teacher_temp, backward_scope=self._finish_scope)
         else:
             loss_dict = self.arch.forward_backward(images, teacher_temp, backward_scope=self._finish_scope)
-        if self._ddp is not None and _world() > 1:                # the heads are outside the DDP wrapper
-            for p in self._head_params:
-                if p.grad is not None:
-                    dist.all_reduce(p.grad)
-                    p.grad.div_(_world())
+        if self._ddp is not None and _world() > 1:                # the heads (outside the DDP wrapper) + the backbone's small tensors
+            self._flat_reducer.reduce()
         if self.fused:
             self._fused_step(momentum)
             return loss_dict

@@ -563,6 +563,65 @@ class SegmentedModel(nn.Module):
         return self
 
 
+def ddp_ignore_small(module, numel=None):
+    """Put the trainable tensors of `module` with at most `numel` elements (default DDP_FLAT_SMALL_NUMEL) on
+    DistributedDataParallel's ignore list - call BEFORE wrapping - and return them ([] when that would leave DDP nothing)."""
+    numel = DDP_FLAT_SMALL_NUMEL if numel is None else numel
+    if numel <= 0:
+        return []
+    small = [p for p in module.parameters() if p.requires_grad and p.numel() <= numel]
+    big = sum(1 for p in module.parameters() if p.requires_grad) - len(small)
+    if not small or big <= 0:
+        return []
+    ids = {id(p) for p in small}
+    # every name a small parameter can be reached by (a module registered twice - train._Segment - has two)
+    names = [f"{mn}.{pn}" if mn else pn for mn, mod in module.named_modules(remove_duplicate=False)
+             for pn, p in mod.named_parameters(recurse=False) if id(p) in ids]
+    nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(module, names)
+    return small
+
+
+class FlatGradReducer:
+    """Parameters outside DistributedDataParallel: rank 0's values brought over once, gradients averaged over the ranks through
+    ONE persistent flat buffer after the backward pass (two multi-tensor copies + one collective)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self._key = self._flat = self._views = None
+
+    @torch.no_grad()
+    def broadcast(self):
+        if not self.params or dist.get_world_size() == 1:
+            return
+        flat = torch.cat([p.detach().reshape(-1) for p in self.params])
+        dist.broadcast(flat, 0)
+        torch._foreach_copy_([p.data for p in self.params],
+                             [t.view_as(p) for t, p in zip(flat.split([p.numel() for p in self.params]), self.params)])
+
+    @torch.no_grad()
+    def reduce(self, proxy=None):
+        world = dist.get_world_size()
+        if not self.params or (world == 1 and proxy is None):
+            return                                      # one rank: the gradients are final as they are
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        key = tuple(id(p) for p in live)
+        if self._key != key:                            # (built once: the set of tensors with gradients does not change)
+            n = sum(p.numel() for p in live)
+            self._flat = torch.empty(n, dtype=live[0].grad.dtype, device=live[0].grad.device)
+            self._views = [t.view_as(p) for t, p in zip(self._flat.split([p.numel() for p in live]), live)]
+            self._key = key
+        grads = [p.grad for p in live]
+        torch._foreach_copy_(self._views, grads)
+        if world > 1:
+            self._flat.div_(world)
+            dist.all_reduce(self._flat)
+        else:
+            proxy.traffic(self._flat)                   # the 1-GPU stand-in for the collective (DdpTrafficProxy)
+        torch._foreach_copy_(grads, self._views)
+
+
 class DdpTrafficProxy:
     """A one-GPU stand-in for what the gradient all-reduce of an N-GPU step does to the step (round-4 review item 5): a DDP
     communication hook that, for every gradient bucket that becomes ready during the backward pass, moves the bucket's bytes
@@ -711,23 +770,9 @@ class Trainer:
     def _wrap_ddp(self):
         local_rank, bucket_cap_mb, bf16_buckets = self._ddp_args
         # every trainable parameter is used each step (frozen cls_token.1-4 are not registered for grads)
-        self._small = []
-        if DDP_FLAT_SMALL_NUMEL > 0:
-            small = [p for p in self.model.parameters() if p.requires_grad and p.numel() <= DDP_FLAT_SMALL_NUMEL]
-            big = sum(1 for p in self.model.parameters() if p.requires_grad) - len(small)
-            if small and big > 0:
-                ids = {id(p) for p in small}
-                # every name a small parameter can be reached by (a module registered twice - train._Segment - has two)
-                names = [f"{mn}.{pn}" if mn else pn for mn, mod in self.model.named_modules(remove_duplicate=False)
-                         for pn, p in mod.named_parameters(recurse=False) if id(p) in ids]
-                nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(self.model, names)
-                self._small = small
-                if dist.get_world_size() > 1:          # DDP broadcasts rank 0's values of the parameters IT manages only
-                    with torch.no_grad():
-                        flat = torch.cat([p.detach().reshape(-1) for p in self._small])
-                        dist.broadcast(flat, 0)
-                        torch._foreach_copy_([p.data for p in self._small],
-                                             [t.view_as(p) for t, p in zip(flat.split([p.numel() for p in self._small]), self._small)])
+        self._small = ddp_ignore_small(self.model)
+        self._flat_reducer = FlatGradReducer(self._small)
+        self._flat_reducer.broadcast()          # DDP broadcasts rank 0's values of the parameters IT manages only
         self.model = nn.parallel.DistributedDataParallel(
             self.model, device_ids=[local_rank] if self.device_type == "cuda" else None,
             bucket_cap_mb=bucket_cap_mb or DDP_BUCKET_MB,
@@ -749,33 +794,11 @@ class Trainer:
         small_ids = {id(p) for p in self._small}
         self._ddp_params = [p for p in self.raw_model.parameters() if p.requires_grad and id(p) not in small_ids]
 
-    @torch.no_grad()
     def _reduce_small_grads(self):
         """The gradients DDP does not manage (DDP_FLAT_SMALL_NUMEL): mean over the ranks through ONE flat buffer."""
-        small = getattr(self, "_small", None)
-        if not small:
-            return
-        world = dist.get_world_size()
-        if world == 1 and self._proxy is None:
-            return                                      # one rank: the gradients are final as they are
-        live = [p for p in small if p.grad is not None]
-        if not live:
-            return
-        key = tuple(id(p) for p in live)
-        if getattr(self, "_small_key", None) != key:    # (built once: the set of tensors with gradients does not change)
-            n = sum(p.numel() for p in live)
-            self._small_flat = torch.empty(n, dtype=live[0].grad.dtype, device=live[0].grad.device)
-            self._small_views = [t.view_as(p) for t, p in zip(self._small_flat.split([p.numel() for p in live]), live)]
-            self._small_key = key
-        grads = [p.grad for p in live]
-        torch._foreach_copy_(self._small_views, grads)
-        flat = self._small_flat
-        if world > 1:
-            flat.div_(world)
-            dist.all_reduce(flat)
-        else:
-            self._proxy.traffic(flat)                   # the 1-GPU stand-in for the collective (DdpTrafficProxy)
-        torch._foreach_copy_(grads, self._small_views)
+        r = getattr(self, "_flat_reducer", None)
+        if r is not None:
+            r.reduce(self._proxy)
 
     def capture_segments(self, samples, warmup=3):
         """hipGraphs for the slices of a ``segment_graphs`` trainer (call once, with ONE micro-batch of the training
