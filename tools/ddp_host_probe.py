@@ -12,8 +12,9 @@ if len(sys.argv) > 1 and sys.argv[1].isdigit():
     TR.DDP_FLAT_SMALL_NUMEL = int(sys.argv[1])
 init_distributed(force=True)
 model = create_model("hybrid_deit_huge_patch14", num_classes=1000, drop_path_rate=0.5, img_size=224).cuda()
-tr = Trainer(model, distributed=True, local_rank=0)
-x, y = synthetic_batch(64, 1000, "cuda", 1)
+tr = Trainer(model, distributed=os.environ.get("PROBE_NO_DDP") is None, local_rank=0)
+BATCH = int(os.environ.get("PROBE_BATCH", "64"))
+x, y = synthetic_batch(BATCH, 1000, "cuda", 1)
 for _ in range(4):
     tr.step(x, y)
 torch.cuda.synchronize()
@@ -23,7 +24,7 @@ for _ in range(8):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"DDP_FLAT_SMALL_NUMEL {TR.DDP_FLAT_SMALL_NUMEL}: small tensors {len(tr._small)}; host issue {1e3 * (t1 - t0) / 8:.1f} ms/step, "
+print(f"DDP_FLAT_SMALL_NUMEL {TR.DDP_FLAT_SMALL_NUMEL}: batch {BATCH}, small tensors {len(getattr(tr, '_small', []))}; host issue {1e3 * (t1 - t0) / 8:.1f} ms/step, "
       f"wall {1e3 * (t2 - t0) / 8:.1f} ms/step")
 if "--profile" in sys.argv:
     import cProfile, pstats
