@@ -784,8 +784,12 @@ class Trainer:
             self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
         else:
             # the reducer's own path divides every gradient that already lives in its bucket by the world size with one launch
-            # per tensor; with a communication hook the division is one launch per bucket
-            self.model.register_comm_hook(None, default_hooks.allreduce_hook)
+            # per tensor; with a communication hook the division is one launch per bucket.  The built-in (C++) hook: no Python
+            # call per bucket on the autograd thread
+            try:
+                self.model._register_builtin_comm_hook(dist.BuiltinCommHookType.ALLREDUCE)
+            except Exception:
+                self.model.register_comm_hook(None, default_hooks.allreduce_hook)
         # Weight gradients written straight into DDP's bucket views (ops.GRAD_DEST): the views a step's backward leaves in
         # .grad are where the next step's weight-gradient kernels write - the reducer sees an alias and skips its copy.
         # Eager single-micro-batch steps on the GPU only (accumulation adds into .grad; graphed slices own their outputs).
