@@ -896,7 +896,8 @@ class WgradPair:
 
 
 def _pair_ready(pair, g2, x2):
-    return (pair is not None and WGRAD_PAIRED and WGRAD_HIP and ops.DEFERRED_FINISHES.enabled and ops._in_backward()
+    return (pair is not None and WGRAD_PAIRED and WGRAD_HIP and ops.DEFERRED_FINISHES.enabled
+            and ops.DEFERRED_FINISHES.allow_pairs and ops._in_backward()
             and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and g2.stride(1) == 1
             and x2.stride(1) == 1)
 

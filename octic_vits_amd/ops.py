@@ -649,6 +649,7 @@ class _DeferredFinishes:
         self.ln_jobs = []       # (partials, nblk, c, [5 dalpha ptrs], dbeta_ptr, keep-alive storages, stream)
         self.wg_jobs = []       # (filled _WgFinishJob, keep-alive tensors / storages, stream)
         self.pairs = []         # functional.WgradPair objects holding a postponed weight gradient (see there)
+        self.allow_pairs = True  # False: weight gradients are never postponed (they are read early: DDP's reducer hooks)
         self.armed = False
 
     def add_pair(self, pair):

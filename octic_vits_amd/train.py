@@ -797,6 +797,9 @@ class Trainer:
                                  and self.segmented is None) else None
         small_ids = {id(p) for p in self._small}
         self._ddp_params = [p for p in self.raw_model.parameters() if p.requires_grad and id(p) not in small_ids]
+        # every parameter whose gradient comes out of a "finish" reduction (vectors: norm, layer scale, bias) is outside DDP
+        self._vectors_outside_ddp = bool(self._small) and all(
+            id(p) in small_ids for p in self.raw_model.parameters() if p.requires_grad and p.dim() <= 1)
 
     def _reduce_small_grads(self):
         """The gradients DDP does not manage (DDP_FLAT_SMALL_NUMEL): mean over the ranks through ONE flat buffer."""
@@ -882,7 +885,9 @@ class Trainer:
                 from . import ops as _ops
                 _ops.GRAD_DEST = dest
                 try:
-                    loss.backward()
+                    # vector gradients (all outside DDP) may still be finished in batches at the end of the pass
+                    with _FinishScope(_ops.DEFERRED_FINISHES, BATCHED_FINISHES and self._vectors_outside_ddp, vectors_only=True):
+                        loss.backward()
                 finally:
                     _ops.GRAD_DEST = None
                 for p in self._ddp_params:              # (bucket views: DDP re-points .grad at them in its hooks)
@@ -953,20 +958,24 @@ BATCHED_FINISHES = True    # `bench.py --no-batched-finishes` for the A/B
 
 
 class _FinishScope:
-    def __init__(self, deferred, on):
-        self.deferred, self.on = deferred, on
+    def __init__(self, deferred, on, vectors_only=False):
+        """vectors_only: postpone only the reductions that produce VECTOR gradients (norm / layer-scale / bias parameters) -
+        the octic weight-gradient slab reductions and the paired weight gradients run at once (DDP reads weight gradients in
+        its hooks; the vectors are outside DDP: train.DDP_FLAT_SMALL_NUMEL)."""
+        self.deferred, self.on, self.vectors_only = deferred, on, vectors_only
 
     def __enter__(self):
         from . import d8_layers as _L
-        self.prev = self.deferred.enabled
+        self.prev = (self.deferred.enabled, self.deferred.allow_pairs)
         self.deferred.enabled = self.on
         # compacted stochastic depth: slab sizes change from step to step, and 3 GB of them held to the end of the backward
         # pass turn the caching allocator's reuse into fresh allocations (measured: +10 ms of host time per step)
-        self.deferred.slabs_too = not _L.COMPACT_DROP_PATH
+        self.deferred.slabs_too = not _L.COMPACT_DROP_PATH and not self.vectors_only
+        self.deferred.allow_pairs = not self.vectors_only
         return self
 
     def __exit__(self, *exc):
-        self.deferred.enabled = self.prev
+        self.deferred.enabled, self.deferred.allow_pairs = self.prev
         self.deferred.flush()            # (the engine's end-of-backward callback has normally emptied the list already)
         return False
 
