@@ -127,12 +127,37 @@ def step_variants(trainer, model, samples, targets, args, n=8):
         if made:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("gloo", rank=0, world_size=1)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1)     # a one-rank RCCL group: real collectives, trivial peers
         try:
+            bkw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
+            # The N > 1 step as bench.py --gpus N runs it (train.GradReducer: gradients written into flat buckets, one RCCL
+            # all-reduce per bucket on the group's stream as it fills), eagerly and captured as ONE hipGraph with the
+            # collectives inside - on a one-rank group every collective is a local pass over the bucket
+            try:
+                tg = Trainer(model, distributed=True, local_rank=samples.device.index or 0, **bkw)
+                ms, host = timed(tg)
+                out["ddp_eager_ms_per_step"], out["ddp_eager_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
+                out["ddp_buckets"] = len(tg._reducer.buckets) + 1
+                out["ddp_buckets_reduced_during_backward"] = tg._reducer.early
+                g = tg.capture(samples, targets, warmup=1)
+                for _ in range(2):
+                    g.replay()
+                torch.cuda.synchronize()
+                w0 = tg._watch.wait_s
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    g.replay(samples, targets)
+                issued = time.perf_counter() - t0 - (tg._watch.wait_s - w0)
+                torch.cuda.synchronize()
+                out["ddp_graph_ms_per_step"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+                out["ddp_graph_host_issue_ms_per_step"] = round(issued / n * 1e3, 2)
+                del g, tg
+            except Exception as e:
+                out["ddp_graph_error"] = f"{type(e).__name__}: {e}"[:300]
             for key, copies in (("ddp_hooks_ms_per_step", 0), ("ddp_proxy_ms_per_step", 2)):
                 proxy = DdpTrafficProxy(samples.device, copies=copies, halve=args.bf16_buckets)
-                tp = Trainer(model, distributed=True, local_rank=samples.device.index or 0, ddp_proxy=proxy,
-                             **({} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}))
+                tp = Trainer(model, distributed=True, local_rank=samples.device.index or 0, ddp_proxy=proxy, **bkw)
                 ms, host = timed(tp)
                 out[key] = round(ms, 3)
                 if copies:
@@ -201,8 +226,12 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
-                    help="launch every step eagerly (default at 1 GPU: the step is captured once with Trainer.capture and "
-                         "replayed as one hipGraph; the kernel-timing steps stay eager.  With DDP the steps are always eager)")
+                    help="launch every step eagerly (default: the step is captured once with Trainer.capture and replayed as "
+                         "one hipGraph - at N > 1 with the bucket all-reduces of train.GradReducer recorded inside it; the "
+                         "kernel-timing steps stay eager.  Also: OCTIC_DDP_GRAPH=0 for the data-parallel step only)")
+    ap.add_argument("--torch-ddp", action="store_true",
+                    help="developer A/B: N > 1 through torch's DistributedDataParallel (eager launches) instead of "
+                         "train.GradReducer")
     ap.add_argument("--no-wgrad-slabs", action="store_true",
                     help="developer A/B: library weight gradients as one GEMM instead of a batched GEMM over row slabs")
     ap.add_argument("--lib-wgrad", action="store_true",
@@ -336,13 +365,14 @@ def main():
     log("model on device")
     tkw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
     ddp = world > 1 or args.force_ddp
-    one_graph = not ddp and args.accum == 1 and not args.no_graph
+    own = ddp and not args.torch_ddp and args.accum == 1 and not args.bf16_buckets and not (args.segment_graphs or 0)
+    one_graph = (not ddp or (own and os.environ.get("OCTIC_DDP_GRAPH", "1") != "0")) and args.accum == 1 and not args.no_graph
     # segment graphs are opt-in: on one MI355X the 2 x 8 replays run the step in 75.7 ms against 67.8 ms for eager launches
     # (gradient clones out of the static buffers, cut fusion links, per-slice mask pools) - they pay once the eager step
     # is host-bound (tools/host_profile.py: ~45 ms of Python / ctypes per step), which at 67 ms of kernels it is not
     nseg = args.segment_graphs or 0
     trainer = Trainer(model, distributed=ddp, local_rank=local_rank, accum_steps=args.accum,
-                      bf16_buckets=args.bf16_buckets, segment_graphs=nseg, **tkw)
+                      bf16_buckets=args.bf16_buckets, segment_graphs=nseg, own_reducer=own if ddp else None, **tkw)
     samples, targets = synthetic_batch(args.batch * args.accum, 1000, dev, 4242 + rank)
     # the timed steps rotate over three resident batches (the graph replays copy each into their input buffers)
     batches = [(samples, targets)] + [synthetic_batch(args.batch * args.accum, 1000, dev, 5000 + 17 * j + rank) for j in (1, 2)]
@@ -373,11 +403,19 @@ def main():
                 trainer.step(samples, targets)
             torch.cuda.synchronize()
         except Exception as e:      # a failed capture can leave the stream unusable: measure eagerly in a fresh child
-            log(f"graph capture failed ({type(e).__name__}: {e}); re-running eagerly in a child process")
+            if world > 1:
+                # (every rank runs the same capture: it fails on all of them or on none; the ranks cannot be re-started from
+                # here, so the eager data-parallel step carries on in this process)
+                log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager data-parallel steps")
+                graphed = None
+                torch.cuda.synchronize()
+            else:
+                log(f"graph capture failed ({type(e).__name__}: {e}); re-running eagerly in a child process")
             import subprocess
             real_stdout.flush()     # fd 1 is stderr in this process (see above): hand the child the real stdout for its line
-            raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"],
-                                            stdout=real_stdout).returncode)
+            if world == 1:
+                raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"],
+                                                stdout=real_stdout).returncode)
     sync()
     log("warm-up done, timing")
     # The timed region is `steps` full iterations and nothing else: graph replays at one GPU (eager DDP steps otherwise),
@@ -472,7 +510,12 @@ def main():
                        "global_batch": world * args.batch * args.accum, "per_gpu_batch": args.batch,
                        "accum_steps": args.accum, "parallelism": f"dp{world}",
                        "library_gemm_table": bool(trainer.tuned_gemms),
-                       "launch": "hipGraph replay (whole step)" if graphed is not None else
+                       "gradient_reduction": (None if not ddp else
+                                              f"train.GradReducer: {len(trainer._reducer.buckets) + 1} flat f32 buckets, one RCCL "
+                                              f"all-reduce (AVG) each, {trainer._reducer.early} issued during the backward pass"
+                                              if trainer._reducer is not None else "torch DistributedDataParallel bucket hooks"),
+                       "launch": ("hipGraph replay (whole step" + (", RCCL all-reduces inside)" if ddp else ")"))
+                                 if graphed is not None else
                                  (f"{len(trainer.segmented._segments)} x 2 segment hipGraphs + eager loss / all-reduce hooks / optimizer"
                                   if nseg else "eager")},
             "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),

@@ -829,7 +829,11 @@ def _wgrad_lib(g2, x2, wparam=None):
     if (WGRAD_HIP and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
             and g2.stride(1) == 1 and x2.stride(1) == 1 and ops.dense_wgrad_ok(M, N, K)
             and M * max(g2.stride(0), x2.stride(0)) * 2 < 2 ** 31):
-        return ops.dense_wgrad_tn(g2, x2, out=ops.grad_dest(wparam, (N, K)))
+        dest = ops.grad_dest(wparam, (N, K))
+        dw = ops.dense_wgrad_tn(g2, x2, out=dest)
+        if dest is not None:
+            ops.grad_written(wparam)
+        return dw
     S = wgrad_slabs(M, N, K)
     if S > 1 and g2.is_contiguous() and x2.is_contiguous():
         with torch.autocast("cuda", enabled=False):
@@ -871,28 +875,35 @@ class WgradPair:
     def __init__(self):
         self.pending = None
 
-    def park(self, g2, x2):
-        """Postpone dW = g2^T x2; returns the (not yet written) result tensor."""
-        dw = torch.empty((g2.shape[1], x2.shape[1]), dtype=torch.float32, device=g2.device)
+    def park(self, g2, x2, wparam=None):
+        """Postpone dW = g2^T x2; returns the (not yet written) result tensor - the registered destination of `wparam`'s
+        gradient where there is one (ops.GRAD_DEST)."""
+        shape = (g2.shape[1], x2.shape[1])
+        dw = ops.grad_dest(wparam, shape)
+        landed = wparam if dw is not None else None
+        if dw is None:
+            dw = torch.empty(shape, dtype=torch.float32, device=g2.device)
         # (storage, not tensor: a second tensor reference would make AccumulateGrad clone the unwritten gradient)
-        self.pending = (g2, x2, dw.untyped_storage(), dw.data_ptr(), tuple(dw.shape))
+        self.pending = (g2, x2, dw.untyped_storage(), dw.data_ptr(), tuple(dw.shape), dw.storage_offset(), landed)
         ops.DEFERRED_FINISHES.add_pair(self)
         return dw
 
     def take(self):
+        """(g2, x2, dw, landed): landed = the parameter whose registered gradient destination dw is, or None."""
         p, self.pending = self.pending, None
         if p is None:
             return None
-        g2, x2, storage, ptr, shape = p
-        dw = torch.empty(0, dtype=torch.float32, device=g2.device).set_(storage, 0, shape)
+        g2, x2, storage, ptr, shape, offset, landed = p
+        dw = torch.empty(0, dtype=torch.float32, device=g2.device).set_(storage, offset, shape)
         assert dw.data_ptr() == ptr
-        return g2, x2, dw
+        return g2, x2, dw, landed
 
     def flush(self):
         p = self.take()
         if p is not None:
-            g2, x2, dw = p
+            g2, x2, dw, landed = p
             dw.copy_(_wgrad_lib(g2, x2))
+            ops.grad_written(landed)
 
 
 def _pair_ready(pair, g2, x2):
@@ -936,11 +947,13 @@ class DenseLinearNTFn(torch.autograd.Function):
                   else g2.sum(0, dtype=torch.float32))
         pair = ctx.pair
         if pair is not None and pair.pending is not None:
-            pg, px, _s, _p, pshape = pair.pending
+            pg, px = pair.pending[0], pair.pending[1]
             if (_pair_ready(pair, g2, x2) and pg.shape[0] == g2.shape[0] and px.shape[1] == x2.shape[1]
                     and ops.dense_wgrad_pair_ok(g2.shape[0], g2.shape[1], pg.shape[1], x2.shape[1])):
-                pg, px, pdw = pair.take()
-                dw, _ = ops.dense_wgrad_tn_pair(g2, x2, pg, px, dw1=pdw)
+                pg, px, pdw, landed = pair.take()
+                dest = ops.grad_dest(ctx.wparam, (g2.shape[1], x2.shape[1]))
+                dw, _ = ops.dense_wgrad_tn_pair(g2, x2, pg, px, dw1=pdw, dw0=dest)
+                ops.grad_written(landed, ctx.wparam if dest is not None else None)
                 return gx, dw, gb, None, None, None
             pair.flush()
         return gx, _wgrad_lib(g2, x2, ctx.wparam), gb, None, None, None
@@ -1030,7 +1043,7 @@ class DenseProjResidFn(torch.autograd.Function):
             ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
                   else _mm_lib(gy, wb)).view(a_shape).to(a_dtype)
         if _pair_ready(ctx.pair, gy, a2) and ops.dense_wgrad_ok(gy.shape[0], gy.shape[1], a2.shape[1]):
-            dw = ctx.pair.park(gy, a2)           # written by the qkv weight gradient's launch (or at the end of the pass)
+            dw = ctx.pair.park(gy, a2, ctx.wparam)   # written by the qkv weight gradient's launch (or at the end of the pass)
         else:
             dw = _wgrad_lib(gy, a2, ctx.wparam)
         gx = None if ctx.rows_to is not None else gout.view(ctx.x_shape)

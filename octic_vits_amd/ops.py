@@ -297,6 +297,16 @@ def grad_dest(param, shape):
     return d.detach()
 
 
+def grad_written(*params):
+    """The launches that write these parameters' gradients into their registered destinations are on the stream: a registry
+    that reduces whole buckets as they fill (train.GradReducer) is told; a plain dict (DDP's bucket views) is not."""
+    w = getattr(GRAD_DEST, "written", None)
+    if w is not None:
+        for prm in params:
+            if prm is not None:
+                w(prm.data_ptr())
+
+
 def dense_wgrad_tn(dy, x, name=None, out=None):
     """dW[N,K] = dy[M,N]^T @ x[M,K] in f32 on csrc/dense_wgrad.hip (out: write it there)."""
     _require_cuda(dy)
@@ -320,9 +330,10 @@ def dense_wgrad_pair_ok(M, N0, N1, K):
             and ((N0 + N1) // 256) * (K // 256) <= 256)
 
 
-def dense_wgrad_tn_pair(dy0, x0, dy1, x1, dw1=None):
+def dense_wgrad_tn_pair(dy0, x0, dy1, x1, dw1=None, dw0=None):
     """(dW0 [N0,K], dW1 [N1,K]) = (dy0^T x0, dy1^T x1) as ONE launch of csrc/dense_wgrad.hip (same M, same K): the qkv and proj
-    weight gradients of a standard block.  dw1: write the second result into this (already handed-out) tensor."""
+    weight gradients of a standard block.  dw1: write the second result into this (already handed-out) tensor; dw0: a
+    registered destination of the first (grad_dest)."""
     _require_cuda(dy0)
     M, N0 = dy0.shape
     N1, K = dy1.shape[1], x0.shape[1]
@@ -332,7 +343,8 @@ def dense_wgrad_tn_pair(dy0, x0, dy1, x1, dw1=None):
     ws = _DW_WS.get(dy0.device)
     if ws is None or ws.numel() < need:
         ws = _DW_WS[dy0.device] = torch.zeros(need, dtype=torch.uint8, device=dy0.device)
-    dw0 = torch.empty((N0, K), dtype=torch.float32, device=dy0.device)
+    if dw0 is None:
+        dw0 = torch.empty((N0, K), dtype=torch.float32, device=dy0.device)
     if dw1 is None:
         dw1 = torch.empty((N1, K), dtype=torch.float32, device=dy0.device)
     t = KERNEL_TIMER.start()
@@ -392,12 +404,14 @@ def linear_wgrad(xv, dyv, M, cin, cout, dtype, ref, w32=None, cs5=None, bias=Non
         dcs = [torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(4)]
         dcs.append(torch.empty(2 * cout, dtype=torch.float32, device=dev))
     dbias = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+    landed = [w for w, d in zip(wparams, dests) if d is not None] if wparams is not None else []
     if may_defer and DEFERRED_FINISHES.enabled and DEFERRED_FINISHES.slabs_too and _in_backward():
-        DEFERRED_FINISHES.add_wg(ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, _stream(ref))
+        DEFERRED_FINISHES.add_wg(ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, _stream(ref), landed)
         return dw, dcs, dbias
     check(L.octic_linear_d8_wgrad_finish(_p(ws), splits, cin, cout, _arr5(w32) if cs5 is not None else None,
                                          _arr5(cs5) if cs5 is not None else None, _p(bias), _p(dysum), _arr5(dw),
                                          _arr5(dcs) if dcs is not None else None, _p(dbias), _stream(ref)))
+    grad_written(*landed)
     return dw, dcs, dbias
 
 
@@ -672,7 +686,7 @@ class _DeferredFinishes:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
-    def add_wg(self, ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, stream):
+    def add_wg(self, ws, splits, cin, cout, w32, cs5, bias, dysum, dw, dcs, dbias, stream, landed=()):
         j = _WgFinishJob()
         j.workspace = ws.data_ptr()
         j.has_cs = 1 if cs5 is not None else 0
@@ -687,7 +701,7 @@ class _DeferredFinishes:
         j.splits, j.cin, j.cout = splits, cin, cout
         outs = list(dw) + (list(dcs) if dcs is not None else []) + ([dbias] if dbias is not None else [])
         keep = (ws, w32 if cs5 is not None else None, cs5, bias, dysum, tuple(t.untyped_storage() for t in outs))
-        self.wg_jobs.append((j, keep, stream))
+        self.wg_jobs.append((j, keep, stream, tuple(landed)))
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
@@ -700,10 +714,12 @@ class _DeferredFinishes:
         ln_jobs, self.ln_jobs = self.ln_jobs, []
         wg_jobs, self.wg_jobs = self.wg_jobs, []
         if wg_jobs:
-            arr = (_WgFinishJob * len(wg_jobs))(*[j for j, _k, _s in wg_jobs])
+            arr = (_WgFinishJob * len(wg_jobs))(*[j[0] for j in wg_jobs])
             t = KERNEL_TIMER.start()
             check(lib().octic_linear_d8_wgrad_finish_batch(ctypes.cast(arr, ctypes.c_void_p), len(wg_jobs), wg_jobs[0][2]))
             KERNEL_TIMER.stop(t, "wgrad_finish_batch_kernel", 0)
+            for j in wg_jobs:                           # gradients that went into registered destinations are there now
+                grad_written(*j[3])
         if ln_jobs:
             arr = (_LnFinishJob * len(ln_jobs))()
             for i, (partials, nblk, c, dal, dbeta, _keep, _s) in enumerate(ln_jobs):

@@ -622,6 +622,163 @@ class FlatGradReducer:
         torch._foreach_copy_(grads, self._views)
 
 
+class GradReducer:
+    """Gradient averaging over the ranks WITHOUT DistributedDataParallel - for the one-micro-batch step of ``Trainer``, eager or
+    captured (deit/main.py:354-359 wraps the model in DDP; deit/engine.py:62-75 is the backward it hooks into).
+
+    Why not DDP: its reducer copies / scales gradients from autograd hooks (one launch per tensor), so nothing may write a
+    parameter gradient late - the batched finishes and the paired weight gradients of the one-GPU step are off under it - and a
+    step that contains it cannot be one hipGraph.  Here the large gradients (more than ``small_numel`` elements) are WRITTEN by
+    their kernels into flat f32 buckets (``ops.GRAD_DEST`` protocol: ``get`` hands out the bucket view, ``written`` is called
+    once the launch that fills it is on the stream), filled in gradient-ready order (reverse registration order) up to
+    ``bucket_mb``; a bucket whose last tensor has been written is all-reduced at once on the process group's own stream
+    (``async_op``: RCCL kernels beside the rest of the backward pass).  Everything else - vectors, the small irrep blocks,
+    whatever did not honour its destination - is gathered into the buckets / one "misc" buffer by multi-tensor copies at the end
+    of the pass.  ``finish`` leaves every ``.grad`` a view of reduced memory and makes the compute stream wait for the
+    collectives: the optimizer reads the views.  No autograd hooks, no per-parameter launches, nothing host-synchronous: the
+    whole sequence is capturable (``Trainer.capture``; torch's NCCL = RCCL process group records its collectives into the
+    capturing graph) and, eagerly, costs the host ~30 collective calls per step.
+    Averaging: ``ReduceOp.AVG`` where the backend has it (RCCL), else pre-divided sums (gloo: the CPU tests)."""
+
+    def __init__(self, params, bucket_mb=None, small_numel=None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.avg = dist.get_backend(group) == "nccl"
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("GradReducer: no trainable parameter")
+        dev = params[0].device
+        cap = int((bucket_mb or DDP_BUCKET_MB) * (1 << 20) // 4)
+        small_numel = DDP_FLAT_SMALL_NUMEL if small_numel is None else small_numel
+        big = [p for p in reversed(params) if p.numel() > small_numel and p.dtype == torch.float32]
+        big_ids = {id(p) for p in big}
+        self.small = [p for p in params if id(p) not in big_ids]
+        groups, cur, n = [], [], 0
+        for p in big:
+            if cur and n + p.numel() > cap:
+                groups.append(cur)
+                cur, n = [], 0
+            cur.append(p)
+            n += (p.numel() + 3) // 4 * 4
+        if cur:
+            groups.append(cur)
+        self.buckets = []                               # [flat, [(param, view)], pending]
+        self._dest, self._bucket_of = {}, {}
+        for k, g in enumerate(groups):
+            flat = torch.zeros(sum((p.numel() + 3) // 4 * 4 for p in g), dtype=torch.float32, device=dev)
+            o, pv = 0, []
+            for p in g:
+                v = flat[o:o + p.numel()].view_as(p)
+                pv.append((p, v))
+                self._dest[p.data_ptr()] = v
+                self._bucket_of[p.data_ptr()] = k
+                o += (p.numel() + 3) // 4 * 4
+            self.buckets.append([flat, pv, 0])
+        self.big = big
+        self._misc = self._misc_views = self._misc_key = None
+        self._works, self._fired, self._seen = [], set(), set()
+        self.active = False
+        self.early = 0                                  # buckets of the last pass whose collective was issued before its end
+
+    # ---- the ops.GRAD_DEST protocol ----------------------------------------------------------------------------------
+    def get(self, ptr):
+        return self._dest.get(ptr) if self.active else None
+
+    def written(self, ptr):
+        k = self._bucket_of.get(ptr)
+        if k is None or not self.active or ptr in self._seen:
+            return
+        self._seen.add(ptr)
+        b = self.buckets[k]
+        b[2] -= 1
+        if b[2] == 0:
+            self._fire(k)
+
+    # ---- one backward pass ---------------------------------------------------------------------------------------------
+    def begin(self):
+        """Call with every .grad None, right before backward(); installs this object as ops.GRAD_DEST."""
+        from . import ops
+        self._works, self._fired, self._seen = [], set(), set()
+        for b in self.buckets:
+            b[2] = len(b[1])
+        self.active = True
+        self._prev_dest, ops.GRAD_DEST = ops.GRAD_DEST, self
+
+    def _fire(self, k):
+        if k in self._fired:
+            return
+        self._fired.add(k)
+        flat = self.buckets[k][0] if k >= 0 else self._misc
+        if not self.avg and self.world > 1:
+            flat.div_(self.world)
+        self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM,
+                                           group=self.group, async_op=True))
+
+    def abort(self):
+        """backward() raised: drop the registry without touching the gradients (collectives already issued are waited for)."""
+        from . import ops
+        if self.active:
+            ops.GRAD_DEST = self._prev_dest
+            self.active = False
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    @torch.no_grad()
+    def broadcast(self, params=None):
+        """Rank 0's parameter values to every rank (what DDP's constructor does), as one flat buffer per dtype."""
+        ps = [p for p in (params if params is not None else self.big + self.small)]
+        if self.world == 1 or not ps:
+            return
+        for dt in {p.dtype for p in ps}:
+            sel = [p for p in ps if p.dtype == dt]
+            flat = torch.cat([p.detach().reshape(-1) for p in sel])
+            dist.broadcast(flat, 0, group=self.group)
+            torch._foreach_copy_([p.data for p in sel],
+                                 [t.view_as(p) for t, p in zip(flat.split([p.numel() for p in sel]), sel)])
+
+    @torch.no_grad()
+    def finish(self):
+        """After backward(): gather what was not written in place, reduce what has not been reduced yet, re-point every .grad
+        at reduced memory, and make the current stream wait for the collectives."""
+        from . import ops
+        ops.GRAD_DEST = self._prev_dest
+        self.active = False
+        self.early = len(self._fired)
+        # large gradients that did not land in their bucket (a route without a destination: library GEMM, CPU, f32 paths)
+        src, dst = [], []
+        for k, (flat, pv, _pending) in enumerate(self.buckets):
+            for p, v in pv:
+                g = p.grad
+                if g is None:
+                    v.zero_()                           # (a parameter that took no part in this pass contributes zeros)
+                elif g.data_ptr() != v.data_ptr():
+                    if k in self._fired:
+                        raise RuntimeError("GradReducer: a bucket was reduced before one of its gradients was written")
+                    src.append(g)
+                    dst.append(v)
+                p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+        for k in range(len(self.buckets)):
+            self._fire(k)
+        live = [p for p in self.small if p.grad is not None]
+        if live:
+            key = tuple(id(p) for p in live)
+            if self._misc_key != key:                   # (built once: the set of tensors with gradients does not change)
+                n = sum(p.numel() for p in live)
+                self._misc = torch.empty(n, dtype=torch.float32, device=live[0].device)
+                self._misc_views = [t.view_as(p) for t, p in zip(self._misc.split([p.numel() for p in live]), live)]
+                self._misc_key = key
+            torch._foreach_copy_(self._misc_views, [p.grad for p in live])
+            for p, v in zip(live, self._misc_views):
+                p.grad = v
+            self._fire(-1)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
 class DdpTrafficProxy:
     """A one-GPU stand-in for what the gradient all-reduce of an N-GPU step does to the step (round-4 review item 5): a DDP
     communication hook that, for every gradient bucket that becomes ready during the backward pass, moves the bucket's bytes
@@ -730,10 +887,15 @@ class Trainer:
 
     def __init__(self, model, lr=3e-3, weight_decay=0.02, ema_decay=0.99996, distributed=False, local_rank=0,
                  fused_optimizer=True, tuned_gemms=True, opt_eps=1e-8, accum_steps=1, bf16_buckets=False,
-                 autocast=True, check_every=1, device_type=None, bucket_cap_mb=None, segment_graphs=0, ddp_proxy=None):
+                 autocast=True, check_every=1, device_type=None, bucket_cap_mb=None, segment_graphs=0, ddp_proxy=None,
+                 own_reducer=None):
         """segment_graphs = n > 0 (GPU only): forward and backward run as 2 n hipGraph replays (``SegmentedModel``), the
-        loss, the gradient all-reduce hooks and the optimizer stay eager - the cheap-on-the-host step for N > 1 GPUs and
-        for gradient accumulation, where the whole-step graph of ``capture`` does not apply."""
+        loss, the gradient all-reduce hooks and the optimizer stay eager - the cheap-on-the-host step for gradient
+        accumulation, where the whole-step graph of ``capture`` does not apply.
+        own_reducer (distributed only): average the gradients with ``GradReducer`` instead of DistributedDataParallel - the
+        step keeps its batched finishes and paired weight gradients and can be captured as ONE hipGraph with the RCCL
+        collectives inside (``capture``).  None = wherever it applies: one micro-batch per step, no segment graphs, f32
+        buckets, f32 master parameters; everything else goes through DistributedDataParallel as before."""
         self.raw_model = model
         self.segmented = None
         if segment_graphs:
@@ -747,6 +909,17 @@ class Trainer:
         self._steps = 0
         self._ddp_args = None
         self._proxy = ddp_proxy                         # a DdpTrafficProxy: its hook replaces the all-reduce (measurement only)
+        self._reducer = None
+        if distributed:
+            can_own = (self.accum_steps == 1 and self.segmented is None and not bf16_buckets and ddp_proxy is None
+                       and all(p.dtype == torch.float32 for p in model.parameters() if p.requires_grad))
+            if own_reducer and not can_own:
+                raise ValueError("Trainer(own_reducer=True) needs accum_steps == 1, no segment graphs, f32 buckets and f32 "
+                                 "master parameters")
+            if can_own if own_reducer is None else own_reducer:
+                self._reducer = GradReducer(list(model.parameters()), bucket_mb=bucket_cap_mb)
+                self._reducer.broadcast(list(model.parameters()) + list(model.buffers()))
+                distributed = False                     # (no DistributedDataParallel wrapper below)
         if distributed:
             self._ddp_args = (local_rank, bucket_cap_mb, bf16_buckets)
             # With segment graphs the slices are captured FIRST and wrapped in DistributedDataParallel afterwards
@@ -857,6 +1030,19 @@ class Trainer:
         safe = (BATCHED_FINISHES and self.device_type == "cuda" and self.model is self.raw_model and self.accum_steps == 1)
         return _FinishScope(ops.DEFERRED_FINISHES, safe)
 
+    def _reduced_backward(self, loss):
+        """backward() with the gradients landing in GradReducer's buckets, bucket all-reduces issued as they fill, and the
+        same batched finishes / paired weight gradients as the one-GPU step (nothing reads a gradient before ``finish``)."""
+        r = self._reducer
+        r.begin()
+        try:
+            with self._batched_finishes():
+                loss.backward()
+        except BaseException:
+            r.abort()
+            raise
+        r.finish()
+
     def step(self, samples, targets):
         if self._ddp_args is not None and self.model is self.segmented:
             raise RuntimeError("Trainer(distributed=True, segment_graphs=n): call capture_segments(micro_batch) before the "
@@ -893,6 +1079,8 @@ class Trainer:
                 for p in self._ddp_params:              # (bucket views: DDP re-points .grad at them in its hooks)
                     if p.grad is not None:
                         dest[p.data_ptr()] = p.grad
+            elif self._reducer is not None:
+                self._reduced_backward(loss)
             else:
                 with self._batched_finishes():
                     loss.backward()
@@ -919,16 +1107,18 @@ class Trainer:
     def capture(self, samples, targets, warmup=3):
         """Record forward + backward + optimizer of ``step`` once (static shapes) and return a ``GraphedStep`` whose
         ``replay(samples, targets)`` re-launches it with one host call: the ~3000 kernel launches of a ViT-H step
-        cost the host nothing any more.  Everything the step needs is already device-side: the bias-correction step
+        cost the host nothing any more.  Data parallel (``own_reducer``): the bucket all-reduces are recorded into the same
+        graph on the process group's stream (fork at the event of the bucket's last write, join in front of the optimizer),
+        so every rank replays ONE graph per step and the collectives overlap the backward kernels exactly as captured.  Everything the step needs is already device-side: the bias-correction step
         and the non-finite-gradient guard live in the optimizer kernels, the drop-path masks come from the device
         generator (advanced per replay by torch's graph support), the prepared weights are refreshed by the captured
         launches themselves.  ``warmup`` eager steps run first (they also build every lazily created cache).
-        Single-process only: with DDP the bucketed all-reduce stays eager."""
+        Under DistributedDataParallel (accumulation, bf16 buckets) the step is not capturable."""
         if self.device_type != "cuda" or not isinstance(self.optimizer, FusedLamb):
             raise RuntimeError("Trainer.capture needs the GPU and the fused optimizer")
         if self.model is not self.raw_model:
-            raise RuntimeError("Trainer.capture: distributed / segmented steps are not captured as one graph "
-                               "(use segment_graphs=n + capture_segments)")
+            raise RuntimeError("Trainer.capture: DistributedDataParallel / segmented steps are not captured as one graph "
+                               "(own_reducer=True, or segment_graphs=n + capture_segments)")
         if self.accum_steps != 1:
             raise RuntimeError("Trainer.capture: accum_steps > 1 is not captured")
         from . import d8_layers as _L
@@ -946,10 +1136,16 @@ class Trainer:
         graph = torch.cuda.CUDAGraph()
         self.optimizer.prepare_capture()
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
+        # with collectives inside, other threads (the process group's watchdog polling its events) must stay legal while the
+        # capture runs: thread-local error mode, as torch documents for whole-network capture with NCCL
+        mode = {"capture_error_mode": "thread_local"} if self._reducer is not None else {}
+        with torch.cuda.graph(graph, **mode):
             loss = self._forward_loss(sx, sy)
-            with self._batched_finishes():
-                loss.backward()
+            if self._reducer is not None:
+                self._reduced_backward(loss)
+            else:
+                with self._batched_finishes():
+                    loss.backward()
             self.optimizer.step()
         return GraphedStep(self, graph, sx, sy, loss.detach())
 

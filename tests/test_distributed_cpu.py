@@ -179,6 +179,105 @@ def test_trainer_accumulation_under_ddp_matches_single_process(tmp_path):
         assert torch.allclose(ddp, single, rtol=1e-4, atol=1e-5), (accum, float((ddp - single).abs().max()))
 
 
+def _reducer_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from octic_vits_amd import train as TR
+    from octic_vits_amd.train import GradReducer, Trainer, init_distributed
+    init_distributed()
+    x, y = _accum_batch()
+    per = 8 // world
+    net = _Net()
+    TR.DDP_FLAT_SMALL_NUMEL = 64            # splits this model's tensors into bucket members and "misc" members
+    if rank == 1:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.37)
+    tr = Trainer(net, distributed=True, fused_optimizer=False, tuned_gemms=False, autocast=False, ema_decay=None,
+                 device_type="cpu", bucket_cap_mb=0.004)           # ~1000 floats per bucket: several buckets
+    assert isinstance(tr._reducer, GradReducer) and tr.model is tr.raw_model      # no DistributedDataParallel wrapper
+    assert len(tr._reducer.buckets) >= 2 and tr._reducer.small
+    for _ in range(3):
+        tr.step(x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per])
+        # every gradient the optimizer read is a view of reduced bucket / misc memory
+        flats = [b[0] for b in tr._reducer.buckets] + [tr._reducer._misc]
+        for p in net.parameters():
+            assert any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in flats)
+    flat = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g) for g in gathered)
+    if rank == 0:
+        torch.save(flat, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_own_reducer_two_ranks_matches_single_process(tmp_path):
+    """train.GradReducer (the reducer behind Trainer(distributed=True) for one-micro-batch steps, the one a captured data-parallel
+    step records its collectives through): 2 ranks x 4 samples, rank 1 starting from other values, buckets of ~1000 floats +
+    the misc buffer == one process on all 8 samples; replicas identical."""
+    out = str(tmp_path / "own.pt")
+    mp.spawn(_reducer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    from octic_vits_amd.train import Trainer
+    x, y = _accum_batch()
+    tr = Trainer(_Net(), distributed=False, fused_optimizer=False, tuned_gemms=False, autocast=False, ema_decay=None,
+                 device_type="cpu")
+    for _ in range(3):
+        tr.step(x, y)
+    single = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
+    assert torch.allclose(got, single, rtol=1e-4, atol=1e-5), float((got - single).abs().max())
+
+
+def test_own_reducer_destination_protocol():
+    """The ops.GRAD_DEST protocol of train.GradReducer on one rank: a gradient written INTO its bucket view (and announced
+    with ops.grad_written) is adopted without a copy and its bucket is reduced as soon as its last member is announced; an
+    unannounced one is gathered at the end; results equal the plain gradients."""
+    from octic_vits_amd import ops
+    from octic_vits_amd.train import GradReducer
+    made = not dist.is_initialized()
+    if made:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        torch.manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(40, 30)), torch.nn.Parameter(torch.randn(7)),
+              torch.nn.Parameter(torch.randn(50, 20)), torch.nn.Parameter(torch.randn(30, 30))]
+        r = GradReducer(ps, bucket_mb=1500 * 4 / (1 << 20), small_numel=10)
+        assert [len(b[1]) for b in r.buckets] == [1, 1, 1] and r.small == [ps[1]]
+        want = [torch.randn_like(p) for p in ps]
+
+        class InPlace(torch.autograd.Function):          # a weight-gradient kernel that honours its destination
+            @staticmethod
+            def forward(ctx, w, g):
+                ctx.w, ctx.g = w, g
+                return w.sum() * 0
+
+            @staticmethod
+            def backward(ctx, _):
+                d = ops.grad_dest(ctx.w, ctx.w.shape)
+                assert d is not None
+                d.copy_(ctx.g)
+                ops.grad_written(ctx.w)
+                return d, None
+
+        r.begin()
+        assert ops.GRAD_DEST is r
+        loss = InPlace.apply(ps[3], want[3]) + (ps[0] * want[0]).sum() + (ps[1] * want[1]).sum() + (ps[2] * want[2]).sum()
+        loss.backward()
+        assert r._fired == {0}                           # ps[3] is bucket 0 (reverse registration order): reduced mid-pass
+        r.finish()
+        assert ops.GRAD_DEST is None and r.early == 1
+        for p, w in zip(ps, want):
+            assert torch.equal(p.grad, w)
+        assert ps[3].grad.data_ptr() == r.buckets[0][0].data_ptr()
+        assert ps[1].grad.data_ptr() == r._misc.data_ptr()
+    finally:
+        if made:
+            dist.destroy_process_group()
+
+
 def test_bench_spawns_its_own_ranks_when_launched_bare(monkeypatch, capsys):
     """`python bench.py --gpus N` with no WORLD_SIZE must start N ranks itself (fresh children, before any GPU call) and
     pass the exit code through; here the child launcher is intercepted."""

@@ -366,6 +366,65 @@ def test_captured_step_replays_like_eager_steps():
     assert float(ta.step(x, y).detach()) == float(gs.replay(x, y))
 
 
+@pytest.mark.timeout(600)
+def test_captured_data_parallel_step_on_a_one_rank_rccl_group():
+    """The N > 1 step of bench.py: Trainer(distributed=True) with train.GradReducer (gradients written into flat buckets, one
+    RCCL all-reduce per bucket on the group's stream as it fills, no DistributedDataParallel), eagerly and captured as ONE
+    hipGraph with the collectives inside.  On a one-rank group the average is the identity, so all three - plain trainer,
+    eager reducer step, replayed graph - must agree BITWISE in losses, weights and EMA (same kernels, same order; the
+    reducer only changes where gradients are written); and the large gradients must really have landed in the buckets, with
+    buckets reduced while the backward pass was still being issued."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from octic_vits_amd import train as TR
+    from octic_vits_amd.train import GradReducer, Trainer, synthetic_batch
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    old = TR.DDP_FLAT_SMALL_NUMEL
+    TR.DDP_FLAT_SMALL_NUMEL = 20_000          # this model's 384 x 128 / 512 x 128 weights become bucket members
+    try:
+        ma, mb, mc = _small_hybrid(), _small_hybrid(), _small_hybrid()
+        ta = Trainer(ma, lr=1e-3)
+        tb = Trainer(mb, lr=1e-3, distributed=True, local_rank=0, bucket_cap_mb=1)
+        tc = Trainer(mc, lr=1e-3, distributed=True, local_rank=0, bucket_cap_mb=1)
+        assert isinstance(tb._reducer, GradReducer) and tb.model is mb and len(tb._reducer.buckets) >= 2
+        batches = [synthetic_batch(8, 100, "cuda", seed=s, img_size=56) for s in range(5)]
+        warm = batches[0]
+        gs = tc.capture(*warm, warmup=2)
+        for _ in range(2):
+            ta.step(*warm)
+            tb.step(*warm)
+        la, lb, lc = [], [], []
+        for x, y in batches[1:] + batches[1:]:
+            la.append(float(ta.step(x, y).detach()))
+            lb.append(float(tb.step(x, y).detach()))
+            lc.append(float(gs.replay(x, y)))
+        assert la == lb == lc, (la, lb, lc)
+        assert len(set(la)) == len(la)
+        for (n, pa), pb, pc in zip(ma.named_parameters(), mb.parameters(), mc.parameters()):
+            assert torch.equal(pa, pb) and torch.equal(pa, pc), n
+        for ea, eb, ec in zip(ta.optimizer.ema_state(), tb.optimizer.ema_state(), tc.optimizer.ema_state()):
+            assert torch.equal(ea, eb) and torch.equal(ea, ec)
+        r = tb._reducer
+        assert r.early >= 1                    # at least one bucket was handed to RCCL before the end of the pass
+        flats = [b[0] for b in r.buckets] + [r._misc]
+        for p in mb.parameters():
+            if p.requires_grad:
+                assert any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in flats)
+        # an eager reducer step after the replays continues from the same state
+        x, y = batches[0]
+        assert float(ta.step(x, y).detach()) == float(tc.step(x, y).detach())
+    finally:
+        TR.DDP_FLAT_SMALL_NUMEL = old
+        dist.destroy_process_group()
+
+
 def test_captured_step_draws_fresh_drop_path_masks():
     """The drop-path masks come from the device generator: replays of one graph must not repeat the captured draw."""
     from octic_vits_amd.model import OcticVisionTransformer
