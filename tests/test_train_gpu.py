@@ -387,9 +387,18 @@ def test_captured_data_parallel_step_on_a_one_rank_rccl_group():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     old = TR.DDP_FLAT_SMALL_NUMEL
-    TR.DDP_FLAT_SMALL_NUMEL = 20_000          # this model's 384 x 128 / 512 x 128 weights become bucket members
+    TR.DDP_FLAT_SMALL_NUMEL = 20_000          # this model's 768 x 256 ... 1024 x 256 weights become bucket members
     try:
-        ma, mb, mc = _small_hybrid(), _small_hybrid(), _small_hybrid()
+        from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8
+        from octic_vits_amd.model import OcticVisionTransformer
+        from octic_vits_amd.vit import Layer_scale_init_Block
+
+        def make():        # embed_dim 256: the standard half's weight gradients run on csrc/dense_wgrad.hip (destinations honoured)
+            torch.manual_seed(5)
+            return OcticVisionTransformer(img_size=56, patch_size=14, num_classes=100, embed_dim=256, depth=4, num_heads=4,
+                                          qkv_bias=True, drop_path_rate=0.0, octic_block_layers=Layer_scale_init_BlockD8,
+                                          standard_block_layers=Layer_scale_init_Block).cuda()
+        ma, mb, mc = make(), make(), make()
         ta = Trainer(ma, lr=1e-3)
         tb = Trainer(mb, lr=1e-3, distributed=True, local_rank=0, bucket_cap_mb=1)
         tc = Trainer(mc, lr=1e-3, distributed=True, local_rank=0, bucket_cap_mb=1)
