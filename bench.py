@@ -309,6 +309,9 @@ def main():
     from octic_vits_amd.train import Trainer, init_distributed, synthetic_batch
     import torch.distributed as dist
 
+    if os.environ.get("OCTIC_NO_IMAGE"):             # developer A/B: classic row panels for every dense GEMM
+        from octic_vits_amd import _lib as _L0
+        _L0.route_override(_L0.ROUTE_DENSE_IMAGE, 2)
     if args.resid_fused:
         import octic_vits_amd.functional as _OF2
         _OF2.DENSE_RESID_FUSED = True

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OCTIC_ABI_VERSION 19
+#define OCTIC_ABI_VERSION 20
 
 enum { OCTIC_F32 = 0, OCTIC_BF16 = 1 };
 
@@ -72,7 +72,8 @@ enum {
   OCTIC_ROUTE_ATTN_LEGACY = 6,     /* octic_attn_*: 1 = the two-kernel online-softmax family for every shape              */
   OCTIC_ROUTE_ATTN_ONLINE = 7,     /* octic_attn_fwd*: 1 = persistent online-softmax forward instead of the one-shot one  */
   OCTIC_ROUTE_ATTN_BWD_PAIR = 8,   /* octic_attn_bwd*: 1 = the dq + dkv kernel pair instead of the single-pass backward   */
-  OCTIC_ROUTE_COUNT = 9
+  OCTIC_ROUTE_DENSE_IMAGE = 9,     /* octic_dense_gemm_nt_tokens: 1 = per-image panels wherever legal, 2 = never (0: model) */
+  OCTIC_ROUTE_COUNT = 10
 };
 int octic_route_override(int knob, int value);
 
@@ -454,6 +455,22 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
                         void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs,
                         int64_t rows_per_sample, const float* X, float* OUT, const void* H, float* colsum,
                         void* workspace, void* stream);
+/* The same GEMM for token rows that are whole images: A / C / C2 / H rows are [B, tokens, .] flattened (M = B * tokens), as every
+ * projection of deit/vit.py's blocks sees them (x: [B, N, C], vit.py:31-32).  tokens = 257 (ViT-H/14 at 224 x 224: one class
+ * token + 256 patches) lets the launch take per-image row panels - panel b = the 256 patch rows of image b, so M = 64 x 257
+ * is 64 full panels instead of 64 + a 64-row last panel whose tiles are split along K - and run the B class-token rows
+ * (row stride tokens * lda) as a skinny [B, K] x [K, N] launch of their own, wherever the launch model says that is shorter
+ * (all modes but 2; K % 128 == 0).  Same results up to the f32 summation order of the class-token rows (bitwise reproducible
+ * from launch to launch).  tokens = 0 (or any other value): exactly octic_dense_gemm_nt.  The column-sum slabs of modes 3 / 5
+ * then have octic_dense_gemm_plan()'s out[1] rows.  Workspace: octic_dense_gemm_workspace_bytes covers both plans. */
+int octic_dense_gemm_nt_tokens(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
+                               void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs,
+                               int64_t rows_per_sample, const float* X, float* OUT, const void* H, float* colsum,
+                               void* workspace, int tokens, void* stream);
+/* What octic_dense_gemm_nt_tokens will do for this problem: out[0] = output tile width (256 | 320), out[1] = rows of the
+ * column-sum slabs of modes 3 / 5, out[2] = 1 when the launch uses per-image panels + the class-token kernel, out[3] =
+ * workgroups of the main launch. */
+int octic_dense_gemm_plan(int M, int N, int K, int mode, int tokens, int* out4);
 
 /* Weight gradient of an nn.Linear of the standard half (the autograd of deit/vit.py:33,46 and of timm Mlp.fc1 / fc2):
  *     dW[N,K] = dY[M,N]^T . X[M,K]     f32, nn.Linear layout

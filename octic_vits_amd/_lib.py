@@ -12,10 +12,10 @@ LIB_PATH = os.environ.get("OCTIC_LIB") or os.path.join(HERE, "liboctic_hip.so") 
 HEADER_PATH = os.path.join(HERE, "..", "include", "octic_hip.h")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 # knobs of octic_route_override (include/octic_hip.h)
 (ROUTE_DENSE_TILE, ROUTE_DENSE_SPLIT, ROUTE_WGRAD_SLABS, ROUTE_WGRAD_TILE, ROUTE_LINEAR_RING, ROUTE_RING_EVEN,
- ROUTE_ATTN_LEGACY, ROUTE_ATTN_ONLINE, ROUTE_ATTN_BWD_PAIR) = range(9)
+ ROUTE_ATTN_LEGACY, ROUTE_ATTN_ONLINE, ROUTE_ATTN_BWD_PAIR, ROUTE_DENSE_IMAGE) = range(10)
 
 c_i64, c_int, c_float, c_void_p = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -118,6 +118,10 @@ _PROTOS = {
     "octic_dense_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p, c_void_p, c_i64,
                                     c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
+    "octic_dense_gemm_nt_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p, c_void_p,
+                                           c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_void_p]),
+    "octic_dense_gemm_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     "octic_dense_colsum": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p]),
     "octic_dense_wgrad_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "octic_dense_wgrad_tile": (c_int, [c_int, c_int, c_int]),

@@ -37,6 +37,16 @@
 // units of a K-tile are 16 / 24 / 16 / 16 KiB (2 / 3 / 2 / 2 DMA instructions per wave; the four units in flight behind
 // every landed-wait are always one of each kind: vmcnt(9)), two K-tiles of 72 KiB fill the ring, and the epilogue stages
 // the tile in two 64-row passes.
+//
+// Round 6: per-image row panels.  The token rows of ViT-H/14 come as B images x 257 tokens (1 class token + 256 patches), so
+// M = 16 448 = 64 x 256 + 64: classic panels (rows 256 tm ..) leave a 64-row last panel whose tiles go through the split-K
+// front of the grid and cost their CUs 17-22 us (tools/dense_phases.py) - on every one of the 80 N = 1280 launches of a step,
+// whose 256 full tiles are otherwise exactly one round.  With `tokens` = 257 known (octic_dense_gemm_nt_tokens) panel tm is
+// the 256 PATCH rows of image tm (rows 257 tm + 1 ..): N = 1280 is exactly 64 x 4 tiles, N = 5120 exactly five rounds, no
+// panel is ragged, nothing is split - and the B class-token rows (row stride 257 lda) are a skinny [B, K] x [K, N] problem
+// for dense_cls_kernel below (a few microseconds: one 16 x 16 MFMA tile per wave, K cut over the eight waves of a
+// workgroup, the same epilogue math per element).  dense_plan_tokens() takes it where its launch model is shorter.
+#include <cmath>
 #include <type_traits>
 #include "octic_common.hpp"
 
@@ -86,6 +96,7 @@ struct DgArgs {
   const bf16* H;      // [M, N] saved pre-activation     (DGELU)
   float* colsum;      // [tiles_m * 2][N] partial column sums of the output (DGELU, optional; see the epilogue)
   // schedule
+  int m_stride, m_base;   // first token row of row panel tm = tm * m_stride + m_base: (256, 0), or (tokens, 1) for per-image panels
   int tiles_m, tiles_n;
   int full_tiles;     // tiles computed by one workgroup each
   int split;          // K-split factor of the remaining tiles (>= 1)
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
     tm = first_m + in_g % gsz;
     tn = in_g / gsz;
   }
-  const int m0 = tm * DG_BM, n0 = tn * DG_BN;
+  const int m0 = tm * a.m_stride + a.m_base, n0 = tn * DG_BN;
   const int nkt = kt_end - kt_begin;          // >= 2
   const int nunits = 4 * nkt;
 
@@ -726,6 +737,109 @@ __global__ __launch_bounds__(512, 1) void dense_nt_kernel(DgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The class-token rows of per-image launches: C[b * tokens][n] for b < nrows.  One workgroup = 16 rows x 16 columns; its
+// blockDim / 64 waves (1 .. 16, chosen by the host so that a wave contracts 320 of K where K allows: 4 / 12 / 16 waves for
+// K = 1280 / 3840 / 5120) each contract K / waves (a multiple of 32) straight from global memory - operands are tiny, no LDS
+// staging, ONE batch of loads per wave so a workgroup lives one memory round trip -, partial tiles are summed through LDS in
+// wave order (fixed order: bitwise reproducible), wave 0 runs the mode's epilogue with the same per-element math as
+// dense_nt_kernel (bias added in f32, one rounding to bf16, GELU / factor on the rounded value; its operands are requested
+// before the contraction).  The grid is (N / 16) x ceil(nrows / 16) workgroups = 320 for N = 1280, B = 64: all resident at once.
+template <int MODE>
+__global__ __launch_bounds__(1024) void dense_cls_kernel(DgArgs a, int tokens, int nrows, int colsum_row0) {
+  __shared__ f32x4 part[16][64];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  const int ntn = a.N >> 4;
+  const int tn = blockIdx.x % ntn, tb = blockIdx.x / ntn;
+  const int n0 = tn * 16, b0 = tb * 16;
+  const int kw = a.K / nw;                                  // K range of this wave (host: a multiple of 32)
+  const int nks = kw >> 5;
+  int brow = b0 + fr;
+  const bool rok = brow < nrows;
+  brow = rok ? brow : nrows - 1;                            // rows past the batch read a valid row and are dropped at the end
+  const bf16* wp = a.B + (int64_t)(n0 + fr) * a.ldb + wid * kw + kg * 8;
+  const bf16* xp = a.A + (int64_t)brow * tokens * a.lda + wid * kw + kg * 8;
+  // epilogue operands of wave 0: lane (fr, kg) = token row b0 + fr, output columns n0 + 4 kg .. + 3
+  const int n = n0 + 4 * kg;
+  const int64_t m = (int64_t)(b0 + fr) * tokens;
+  f32x4 bv = {0, 0, 0, 0};
+  bf16x4 hv = {0, 0, 0, 0};
+  if (wid == 0) {
+    if (a.bias) bv = *(const f32x4*)(a.bias + n);
+    if ((MODE == DG_DGELU || MODE == DG_DFACT) && rok) hv = *(const bf16x4*)(a.H + m * a.ldc + n);
+  }
+  f32x4 acc = {0, 0, 0, 0};
+  // k-steps per batch of loads.  Static register indices only: a runtime-selected double buffer put the fragments in scratch
+  // memory (first version of this kernel: 34-49 us per launch)
+  constexpr int U = 10;
+  bf16x8 wf[U], xf[U];
+#pragma unroll 1
+  for (int ks0 = 0; ks0 < nks; ks0 += U) {
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (ks0 + j < nks) {
+        wf[j] = *(const bf16x8*)(wp + (ks0 + j) * 32);
+        xf[j] = *(const bf16x8*)(xp + (ks0 + j) * 32);
+      }
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (ks0 + j < nks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[j], acc, 0, 0, 0);
+  }
+  part[wid][lane] = acc;
+  __syncthreads();
+  if (wid != 0) return;
+  f32x4 v = part[0][lane];
+  for (int w = 1; w < nw; ++w) v = v + part[w][lane];
+  v = v + bv;
+  const bf16x4 cb = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  bf16* cp = a.C + m * a.ldc + n;
+  float cs[4] = {0, 0, 0, 0};
+  if (rok) {
+    if (MODE == DG_PLAIN) {
+      *(bf16x4*)cp = cb;
+    } else if (MODE == DG_GELU || MODE == DG_GELUO || MODE == DG_GELUF) {
+      bf16x4 y, f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gv, dv;
+        if (MODE == DG_GELUF) dg_gelu_both((float)cb[e], gv, dv);
+        else { gv = dg_gelu((float)cb[e]); dv = 0.0f; }
+        y[e] = (bf16)gv;
+        f[e] = (bf16)dv;
+      }
+      if (MODE == DG_GELUO) *(bf16x4*)cp = y;
+      else {
+        *(bf16x4*)cp = MODE == DG_GELUF ? f : cb;
+        *(bf16x4*)(a.C2 + m * a.ldc + n) = y;
+      }
+    } else if (MODE == DG_DGELU || MODE == DG_DFACT) {
+      const bf16x4 h = hv;
+      bf16x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d[e] = (bf16)((MODE == DG_DFACT ? (float)h[e] : dg_gelu_grad((float)h[e])) * (float)cb[e]);
+        cs[e] = (float)d[e];
+      }
+      *(bf16x4*)cp = d;
+    }
+  }
+  if ((MODE == DG_DGELU || MODE == DG_DFACT) && a.colsum != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = cs[e];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      t += __shfl_xor(t, 8, 64);
+      cs[e] = t;
+    }
+    if (fr == 0) *(f32x4*)(a.colsum + (int64_t)(colsum_row0 + tb) * a.N + n) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Schedule: `full` tiles get one workgroup each; the remaining r = tiles - full tiles (the partial last round on the
 // `cus` workgroup slots) are split along K over `split` workgroups each, so the last round also fills the chip.
 struct DgPlan { int nt, tiles_m, tiles_n, full, rem, split, tail_pad, grid; double cost; };
@@ -810,6 +924,47 @@ inline DgPlan dense_plan(int M, int N, int K, int cus, int mode) {
   return p5.cost < p4.cost ? p5 : p4;
 }
 
+// Waves of a class-token workgroup: K / waves a multiple of 32, 320 per wave where K allows, at most 16 waves.
+inline int dense_cls_waves(int K) {
+  if (K % 320 == 0 && K / 320 <= 16) return K / 320;
+  for (int w = 16; w > 1; --w)
+    if (K % (32 * w) == 0) return w;
+  return 1;
+}
+
+// Per-image panels (see the file header): taken when the batch is whole images of 256 q + 1 tokens with q = 1 (ViT-H/14's 257),
+// the class-token kernel takes the shape (K % 128 == 0, N % 16 == 0, no fused residual tail) and the launch model says so:
+// the panels' plan + ~4 K-tile units for the class-token launch against the classic plan.
+// OCTIC_ROUTE_DENSE_IMAGE: 0 = by the model, 1 = always where legal, 2 = never.
+struct DgTokPlan { DgPlan p; bool image; int images; };
+// What the class-token launch costs, in the plan's unit (one K-tile of the 256-wide tile, ~1.54 us): measured on MI355X at
+// B = 64 (rocprofv3, round 6): 7.0 us for N = K = 1280, 11.4 (N 3840), 13.7-16.2 (N 5120), 16.2 (K 3840), 21.1 us (K 5120) -
+// bound by L2 -> CU operand traffic of 16 x 16 output tiles ((16 + 16) K bytes per 512 flops) and by its one memory round trip;
+// fitted as 7 us x (N / 1280)^0.5 x (K / 1280)^0.8, scaled by the batch.
+inline double dense_cls_cost(int B, int N, int K) {
+  const double us = 7.0 * sqrt((double)N / 1280.0) * pow((double)K / 1280.0, 0.8) * (B <= 64 ? 1.0 : (double)B / 64.0);
+  return us / 1.54;
+}
+inline DgTokPlan dense_plan_tokens(int M, int N, int K, int cus, int mode, int tokens) {
+  DgTokPlan t;
+  t.p = dense_plan(M, N, K, cus, mode);
+  t.image = false;
+  t.images = 0;
+  const int force = route(OCTIC_ROUTE_DENSE_IMAGE);
+  if (tokens != 257 || M % tokens != 0 || mode == DG_RESID || (K % 128) != 0 || (N % 16) != 0 || force == 2) return t;
+  const int B = M / tokens;
+  const DgPlan pi = dense_plan(B * DG_BM, N, K, cus, mode);
+  // (modes 3 / 5 - the fc2 input gradient with its column sums - measured no shorter on per-image panels: 221.2 against
+  // 221.8 us at ViT-H; their class-token launch would be a pure loss)
+  const bool pays = mode != DG_DGELU && mode != DG_DFACT && pi.cost + dense_cls_cost(B, N, K) + 1.0 < t.p.cost;
+  if (force == 1 || (force == 0 && pays)) {
+    t.p = pi;
+    t.image = true;
+    t.images = B;
+  }
+  return t;
+}
+
 }  // namespace octic
 
 using namespace octic;
@@ -823,15 +978,33 @@ static int dense_cus() { return device_cus(); }
 // enough for either tile width (the plain mode may pick the 320-wide tile, the fused tails use the 256-wide one)
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K) {
   int64_t need = 256;
-  for (int nt = 4; nt <= 5; ++nt) {
-    if (nt == 5 && (N % 320) != 0) continue;
-    DgPlan p = dense_plan_nt(M, N, K, dense_cus(), nt);
-    if (dense_force_split() > 1) p = dense_plan_nt(M, N, K, dense_cus(), nt, 8);     // developer switch: room for any split
-    if (p.split <= 1) continue;
-    const int64_t b = (int64_t)p.rem * p.split * DG_BM * (64 * nt) * 4 + DG_TICKET_BYTES + 256;
-    need = b > need ? b : need;
+  // (the per-image panels of a 257-token batch are planned as 256 rows per image: room for either plan)
+  const int Ms[2] = {M, (M % 257) == 0 ? M / 257 * DG_BM : 0};
+  for (int i = 0; i < 2; ++i) {
+    if (Ms[i] <= 0) continue;
+    for (int nt = 4; nt <= 5; ++nt) {
+      if (nt == 5 && (N % 320) != 0) continue;
+      DgPlan p = dense_plan_nt(Ms[i], N, K, dense_cus(), nt);
+      if (dense_force_split() > 1) p = dense_plan_nt(Ms[i], N, K, dense_cus(), nt, 8);     // developer switch: room for any split
+      if (p.split <= 1) continue;
+      const int64_t b = (int64_t)p.rem * p.split * DG_BM * (64 * nt) * 4 + DG_TICKET_BYTES + 256;
+      need = b > need ? b : need;
+    }
   }
   return need;
+}
+
+// out[0] = tile width (256 | 320), out[1] = colsum slab rows of modes 3 / 5, out[2] = 1 if the launch uses per-image panels
+// + the class-token kernel, out[3] = workgroups of the main launch
+int octic_dense_gemm_plan(int M, int N, int K, int mode, int tokens, int* out) {
+  if (!out) return OCTIC_ENULL;
+  if (M <= 0 || N <= 0 || K < 2 * DG_BK) { out[0] = 256; out[1] = 0; out[2] = 0; out[3] = 0; return OCTIC_OK; }
+  const DgTokPlan t = dense_plan_tokens(M, N, K, dense_cus(), mode, tokens);
+  out[0] = t.p.nt == 5 ? 320 : 256;
+  out[1] = t.image ? 2 * t.images + (t.images + 15) / 16 : 2 * ((M + DG_BM - 1) / DG_BM);
+  out[2] = t.image ? 1 : 0;
+  out[3] = t.p.grid;
+  return OCTIC_OK;
 }
 
 int octic_dense_gemm_tile(int M, int N, int K, int mode) {
@@ -848,9 +1021,10 @@ int octic_dense_gemm_colsum_rows(int M, int N, int K) {
 // 3 DGELU (C = gelu'(H) * (A B^T); colsum != NULL: octic_dense_gemm_colsum_rows() slabs [N] of column sums of C),
 // 4 GELUF (C = gelu'(pre-activation), C2 = gelu(pre-activation)), 5 DFACT (C = H * (A B^T), H = the factor of mode 4),
 // 6 GELUO (C = gelu(pre-activation) only: passes without a backward).
-int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
-                        void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs, int64_t rps,
-                        const float* X, float* OUT, const void* H, float* colsum, void* workspace, void* stream) {
+int octic_dense_gemm_nt_tokens(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
+                               void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs, int64_t rps,
+                               const float* X, float* OUT, const void* H, float* colsum, void* workspace, int tokens,
+                               void* stream) {
   if (!A || !B || !C) return OCTIC_ENULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % DG_BK) || K < 2 * DG_BK || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 4)) return OCTIC_ESHAPE;
   // buffer descriptors and per-lane offsets are 32-bit: operands of 2 GiB or more are refused (callers fall back to
@@ -864,8 +1038,11 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.lda = lda; a.ldb = ldb; a.M = M; a.N = N; a.K = K;
   a.C = (bf16*)C; a.C2 = (bf16*)C2; a.ldc = ldc; a.bias = bias; a.gamma = gamma; a.rs = rs; a.rps = rs ? rps : 1;
   a.X = X; a.OUT = OUT; a.H = (const bf16*)H; a.colsum = (mode == DG_DGELU || mode == DG_DFACT) ? colsum : nullptr;
-  const DgPlan p = dense_plan(M, N, K, dense_cus(), mode);
+  const DgTokPlan tp = dense_plan_tokens(M, N, K, dense_cus(), mode, tokens);
+  const DgPlan p = tp.p;
   a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.full_tiles = p.full; a.split = p.split; a.tail_pad = p.tail_pad;
+  a.m_stride = tp.image ? tokens : DG_BM;
+  a.m_base = tp.image ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (p.split > 1) {
     if (!workspace) return OCTIC_ENULL;
@@ -899,7 +1076,27 @@ int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64
     case DG_GELUO: dense_nt_kernel<DG_GELUO, 4><<<p.grid, 512, smem, s>>>(a); break;
     default: return OCTIC_ESHAPE;
   }
+  if (tp.image) {
+    // the class-token rows: row b * tokens of A / C / C2 / H, colsum slab rows behind the panels' 2 * images
+    const int grid = (N / 16) * ((tp.images + 15) / 16), cr0 = 2 * tp.images, thr = 64 * dense_cls_waves(K);
+    switch (mode) {
+      case DG_PLAIN: dense_cls_kernel<DG_PLAIN><<<grid, thr, 0, s>>>(a, tokens, tp.images, cr0); break;
+      case DG_GELU: dense_cls_kernel<DG_GELU><<<grid, thr, 0, s>>>(a, tokens, tp.images, cr0); break;
+      case DG_DGELU: dense_cls_kernel<DG_DGELU><<<grid, thr, 0, s>>>(a, tokens, tp.images, cr0); break;
+      case DG_GELUF: dense_cls_kernel<DG_GELUF><<<grid, thr, 0, s>>>(a, tokens, tp.images, cr0); break;
+      case DG_DFACT: dense_cls_kernel<DG_DFACT><<<grid, thr, 0, s>>>(a, tokens, tp.images, cr0); break;
+      case DG_GELUO: dense_cls_kernel<DG_GELUO><<<grid, thr, 0, s>>>(a, tokens, tp.images, cr0); break;
+      default: return OCTIC_ESHAPE;
+    }
+  }
   return launch_status();
+}
+
+int octic_dense_gemm_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb, int mode, void* C,
+                        void* C2, int64_t ldc, const float* bias, const float* gamma, const float* rs, int64_t rps,
+                        const float* X, float* OUT, const void* H, float* colsum, void* workspace, void* stream) {
+  return octic_dense_gemm_nt_tokens(A, B, M, N, K, lda, ldb, mode, C, C2, ldc, bias, gamma, rs, rps, X, OUT, H, colsum,
+                                    workspace, 0, stream);
 }
 
 }  // extern "C"

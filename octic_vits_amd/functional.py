@@ -913,6 +913,12 @@ def _pair_ready(pair, g2, x2):
             and x2.stride(1) == 1)
 
 
+def _tok(shape):
+    """Tokens per image of a [B, tokens, C] activation (0 = not known to be whole images): lets csrc/dense_gemm.hip take
+    per-image row panels for ViT-H/14's 257-token images (octic_dense_gemm_nt_tokens)."""
+    return int(shape[-2]) if len(shape) >= 3 else 0
+
+
 class DenseLinearNTFn(torch.autograd.Function):
     """nn.Linear (bf16 operands, f32 accumulate, f32 bias added before the one rounding to bf16): forward and input
     gradient on csrc/dense_gemm.hip.  deit/vit.py:33 (``self.qkv(x)``)."""
@@ -925,7 +931,7 @@ class DenseLinearNTFn(torch.autograd.Function):
         wb, wt = cache.get_nt(w, b, ("d" + tag) in DENSE_HIP and ctx.needs_input_grad[0])
         x2 = xb.reshape(-1, wb.shape[1])
         if tag in DENSE_HIP:
-            y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b), name="dense_nt_kernel<plain>")
+            y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b), name="dense_nt_kernel<plain>", tokens=_tok(x.shape))
         else:
             y = _linear_lib(x2, wb, None if b is None else cache.b)
         ctx.save_for_backward(x2, wb, wt)          # wt is None unless the input gradient is routed to the HIP kernel
@@ -939,7 +945,7 @@ class DenseLinearNTFn(torch.autograd.Function):
         g2 = _c(gy).reshape(-1, wb.shape[0])
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (ops.dense_gemm_nt(g2, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
+            gx = (ops.dense_gemm_nt(g2, wt, 0, name="dense_nt_kernel<dgrad>", tokens=_tok(x_shape)) if wt is not None
                   else _mm_lib(g2, wb)).view(x_shape).to(x_dtype)
         gb = None
         if has_b:
@@ -979,7 +985,7 @@ class DenseProjResidFn(torch.autograd.Function):
         ctx.norm = neps is not None
         ctx.x_shape = x.shape
         if ctx.norm:
-            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>")
+            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>", tokens=_tok(a.shape))
             nw32, nb32 = _f32(nw), _f32(nb)
             out, yn, stats = ops.dense_resid_layernorm_fwd(x.view(-1, wb.shape[0]), y, g32, rs32, rps, nw32, nb32, neps,
                                                            torch.bfloat16)
@@ -988,7 +994,7 @@ class DenseProjResidFn(torch.autograd.Function):
             ctx.set_materialize_grads(False)
             return out.view(x.shape), yn.view(x.shape)
         if rows_to is not None:
-            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>")
+            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>", tokens=_tok(a.shape))
             ops.scale_residual_fwd_rows_(stream, rows_to.rowmap, x.view(-1, wb.shape[0]), y, g32, rs32, rps)
             ctx.save_for_backward(a2, wb, wt, y, g32, rs32, rows_to.rowmap)
             ctx.meta = (rps, b is not None, gamma is not None, a.dtype, a.shape)
@@ -998,7 +1004,7 @@ class DenseProjResidFn(torch.autograd.Function):
             y, out = ops.dense_gemm_nt(a2, wb, 2, bias=_f32(b), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, wb.shape[0]),
                                        name="dense_nt_kernel<resid>")
         else:
-            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>")
+            y = ops.dense_gemm_nt(a2, wb, 0, bias=_f32(b), name="dense_nt_kernel<proj>", tokens=_tok(a.shape))
             out = ops.scale_residual_fwd(x.view(-1, wb.shape[0]), y, g32, rs32, rps)
         ctx.save_for_backward(a2, wb, wt, y, g32, rs32)
         ctx.meta = (rps, b is not None, gamma is not None, a.dtype, a.shape)
@@ -1040,7 +1046,7 @@ class DenseProjResidFn(torch.autograd.Function):
                                                         want_colsum=has_b)
         ga = None
         if ctx.needs_input_grad[1]:
-            ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>") if wt is not None
+            ga = (ops.dense_gemm_nt(gy, wt, 0, name="dense_nt_kernel<dgrad>", tokens=_tok(a_shape)) if wt is not None
                   else _mm_lib(gy, wb)).view(a_shape).to(a_dtype)
         if _pair_ready(ctx.pair, gy, a2) and ops.dense_wgrad_ok(gy.shape[0], gy.shape[1], a2.shape[1]):
             dw = ctx.pair.park(gy, a2, ctx.wparam)   # written by the qkv weight gradient's launch (or at the end of the pass)
@@ -1076,17 +1082,18 @@ class DenseMlpFn(torch.autograd.Function):
         ctx.factor = factor
         if "fc1" in DENSE_HIP and not any(ctx.needs_input_grad):
             # no backward will come (inference, the DINOv2 teacher): gelu(h) only, nothing kept (mode 6)
-            a = ops.dense_gemm_nt(y2, w1b, 6, bias=_f32(b1), name="dense_nt_kernel<gelu-only>")
+            a = ops.dense_gemm_nt(y2, w1b, 6, bias=_f32(b1), name="dense_nt_kernel<gelu-only>", tokens=_tok(y.shape))
             h = a
         elif "fc1" in DENSE_HIP:
-            h, a = ops.dense_gemm_nt(y2, w1b, 4 if factor else 1, bias=_f32(b1), name="dense_nt_kernel<gelu>")
+            h, a = ops.dense_gemm_nt(y2, w1b, 4 if factor else 1, bias=_f32(b1), name="dense_nt_kernel<gelu>",
+                                     tokens=_tok(y.shape))
         else:
             h = _linear_lib(y2, w1b, None if b1 is None else c1.b)
             a = torch.nn.functional.gelu(h)
         ctx.norm = neps is not None
         ctx.x_shape = x.shape
         if ctx.norm:
-            br = (ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>") if "fc2" in DENSE_HIP
+            br = (ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>", tokens=_tok(y.shape)) if "fc2" in DENSE_HIP
                   else _linear_lib(a, w2b, None if b2 is None else c2.b))
             nw32, nb32 = _f32(nw), _f32(nb)
             out, yn, stats = ops.dense_resid_layernorm_fwd(x.view(-1, w2b.shape[0]), br, g32, rs32, rps, nw32, nb32, neps,
@@ -1096,7 +1103,7 @@ class DenseMlpFn(torch.autograd.Function):
             ctx.set_materialize_grads(False)
             return out.view(x.shape), yn.view(x.shape)
         if rows_to is not None:
-            br = (ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>") if "fc2" in DENSE_HIP
+            br = (ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>", tokens=_tok(y.shape)) if "fc2" in DENSE_HIP
                   else _linear_lib(a, w2b, None if b2 is None else c2.b))
             ops.scale_residual_fwd_rows_(stream, rows_to.rowmap, x.view(-1, w2b.shape[0]), br, g32, rs32, rps)
             ctx.save_for_backward(y2, h, a, br, w1b, w1t, w2b, w2t, g32, rs32, rows_to.rowmap)
@@ -1107,7 +1114,7 @@ class DenseMlpFn(torch.autograd.Function):
             br, out = ops.dense_gemm_nt(a, w2b, 2, bias=_f32(b2), gamma=g32, rs=rs32, rps=rps, x=x.view(-1, w2b.shape[0]),
                                         name="dense_nt_kernel<resid>")
         elif "fc2" in DENSE_HIP:
-            br = ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>")
+            br = ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), name="dense_nt_kernel<fc2>", tokens=_tok(y.shape))
             out = ops.scale_residual_fwd(x.view(-1, w2b.shape[0]), br, g32, rs32, rps)
         else:
             br = _linear_lib(a, w2b, None if b2 is None else c2.b)
@@ -1153,16 +1160,17 @@ class DenseMlpFn(torch.autograd.Function):
         if w2t is not None:
             md = 5 if ctx.factor else 3
             if has_b1:                                                                  # gelu'(h) * (gbr W2), + db1
-                dh, db1 = ops.dense_gemm_nt(gbr, w2t, md, h=h, name="dense_nt_kernel<dgelu>", want_colsum=True)
+                dh, db1 = ops.dense_gemm_nt(gbr, w2t, md, h=h, name="dense_nt_kernel<dgelu>", want_colsum=True,
+                                            tokens=_tok(y_shape))
             else:
-                dh, db1 = ops.dense_gemm_nt(gbr, w2t, md, h=h, name="dense_nt_kernel<dgelu>"), None
+                dh, db1 = ops.dense_gemm_nt(gbr, w2t, md, h=h, name="dense_nt_kernel<dgelu>", tokens=_tok(y_shape)), None
         else:
             dh, db1 = ops.dense_gelu_bwd(h, _mm_lib(gbr, w2b), want_colsum=has_b1)
         gw2 = _wgrad_lib(gbr, a, ctx.wparams[1])
         gw1 = _wgrad_lib(dh, y2, ctx.wparams[0])
         gy = None
         if ctx.needs_input_grad[0]:
-            gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>") if w1t is not None
+            gy = (ops.dense_gemm_nt(dh, w1t, 0, name="dense_nt_kernel<dgrad>", tokens=_tok(y_shape)) if w1t is not None
                   else _mm_lib(dh, w1b)).view(y_shape).to(y_dtype)
         gx = None if ctx.rows_to is not None else gout.view(ctx.x_shape)
         return gy, gx, gw1, db1, gw2, db2, dgamma, None, None, None, None, dnw, dnb, None, None, None

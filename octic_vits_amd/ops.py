@@ -1041,12 +1041,21 @@ def dense_colsum(g):
     return out
 
 
-def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None, want_colsum=False):
+def dense_plan(M, N, K, mode, tokens):
+    """(tile width, colsum slab rows, per-image panels?, main-launch workgroups) of octic_dense_gemm_nt_tokens."""
+    out = (ctypes.c_int * 4)()
+    check(lib().octic_dense_gemm_plan(M, N, K, mode, int(tokens), out))
+    return out[0], out[1], bool(out[2]), out[3]
+
+
+def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h=None, name=None, want_colsum=False,
+                  tokens=0):
     """C[M,N] = a[M,K] @ b[N,K]^T on the hand-written MFMA kernel (csrc/dense_gemm.hip) with a fused tail:
     mode 0 -> c ; 1 -> (c, gelu(c)) ; 2 -> (c, x + rs*gamma*c) ; 3 -> gelu'(h) * c (want_colsum: also the f32 column
     sums of that result) ; 4 -> (gelu'(c), gelu(c)) ; 5 -> h * c with h = the factor of mode 4 (want_colsum as 3) ;
     6 -> gelu(c) only.
-    a, b bf16 2-D, K contiguous."""
+    a, b bf16 2-D, K contiguous.  tokens: the rows are whole images of that many tokens ([B, tokens, K] flattened) - 257 lets the
+    launch use per-image row panels + the class-token kernel (octic_dense_gemm_nt_tokens); 0 = unknown."""
     _require_cuda(a)
     M, K = a.shape
     N = b.shape[0]
@@ -1056,15 +1065,18 @@ def dense_gemm_nt(a, b, mode=0, bias=None, gamma=None, rs=None, rps=1, x=None, h
     c2 = torch.empty_like(c) if mode in (1, 4) else None
     out = torch.empty((M, N), dtype=torch.float32, device=a.device) if mode == 2 else None
     ws = _dense_ws(M, N, K, a.device)
-    cs_rows = lib().octic_dense_gemm_colsum_rows(M, N, K) if (mode in (3, 5) and want_colsum) else 0
+    tokens = int(tokens) if (tokens and M % int(tokens) == 0) else 0
+    cs_rows = dense_plan(M, N, K, mode, tokens)[1] if (mode in (3, 5) and want_colsum) else 0
     cs = torch.empty((cs_rows, N), dtype=torch.float32, device=a.device) if cs_rows else None
     t = KERNEL_TIMER.start()
-    check(lib().octic_dense_gemm_nt(_p(a), _p(b), M, N, K, a.stride(0), b.stride(0), mode, _p(c), _p(c2), N, _p(bias),
-                                    _p(gamma), _p(rs), int(rps), _p(x), _p(out), _p(h), _p(cs), _p(ws), _stream(a)))
+    check(lib().octic_dense_gemm_nt_tokens(_p(a), _p(b), M, N, K, a.stride(0), b.stride(0), mode, _p(c), _p(c2), N, _p(bias),
+                                           _p(gamma), _p(rs), int(rps), _p(x), _p(out), _p(h), _p(cs), _p(ws), tokens,
+                                           _stream(a)))
     if t is not None:
         nb = 2 * (M * K + N * K + M * N * (2 if mode in (1, 3, 4, 5) else 1)) + (8 * M * N if mode == 2 else 0)
         # "@320": the launch ran the 256 x 320 tile (kernel symbol dense_nt_kernel<0, 5>), else <mode, 4>
-        wide = "@320" if lib().octic_dense_gemm_tile(M, N, K, mode) == 320 else ""
+        # (with per-image panels the timed interval also holds the class-token launch behind the panels')
+        wide = "@320" if dense_plan(M, N, K, mode, tokens)[0] == 320 else ""
         KERNEL_TIMER.stop(t, (name or f"dense_nt_kernel<{mode}>") + wide, nb, 2.0 * M * N * K)
     if mode in (1, 4):
         return c, c2

@@ -483,3 +483,118 @@ def test_paired_qkv_proj_weight_gradients_in_a_block_backward():
             assert float((a_ - b_).norm()) <= 1e-5 * float(a_.norm()), n
         else:
             assert torch.equal(a_, b_), n
+
+
+# ---- round 6: per-image row panels + the class-token kernel (octic_dense_gemm_nt_tokens, tokens = 257) ----------------
+def _force_image(v):
+    """routing override: 0 = launch model, 1 = per-image panels wherever legal, 2 = never"""
+    from octic_vits_amd import _lib
+    _lib.route_override(_lib.ROUTE_DENSE_IMAGE, v)
+
+
+IMG = [(64, 1280, 1280), (64, 1280, 5120), (64, 5120, 1280), (64, 3840, 1280), (3, 512, 256), (17, 320, 768), (33, 1280, 256),
+       (1, 256, 256), (130, 1280, 512)]
+
+
+@pytest.mark.parametrize("B,N,K", IMG)
+def test_dense_nt_per_image_panels_integer_exact_and_equal_to_classic_panels(B, N, K):
+    """M = B x 257 token rows, the per-image route forced on and off.  Integer-valued operands: every product and partial sum
+    is exact, so a mis-addressed panel row (the +1 / x 257 row map), a dropped class-token row or a wrong K slice of the
+    eight-wave class-token contraction is a wrong integer - bit-exact against torch and against the classic panels.  Random
+    operands: both routes within the bf16 output tolerance of fp64; patch rows bitwise equal wherever the classic panel was
+    not a split-K tail (full K in one workgroup either way); two launches of the per-image route bitwise equal."""
+    o = ops()
+    M = B * 257
+    g = torch.Generator(device=DEV).manual_seed(21)
+    a = torch.randint(-3, 4, (M, K), generator=g, device=DEV).to(torch.bfloat16)
+    b = torch.randint(-2, 3, (N, K), generator=g, device=DEV).to(torch.bfloat16)
+    bias = torch.randint(-4, 5, (N,), generator=g, device=DEV).float()
+    want = (a.float() @ b.float().t() + bias).to(torch.bfloat16)
+    try:
+        _force_image(1)
+        assert o.dense_plan(M, N, K, 0, 257)[2] is True
+        c1 = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        _force_image(2)
+        assert o.dense_plan(M, N, K, 0, 257)[2] is False
+        c2 = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        assert torch.equal(c1, want), f"per-image: {int((c1 != want).sum())} wrong elements"
+        assert torch.equal(c2, want)
+        a, b = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+        bias = rnd((N,), 3, dtype=torch.float32)
+        ref = a.double() @ b.double().t() + bias.double()
+        _force_image(1)
+        c1 = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        c1b = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        _force_image(2)
+        c2 = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        close(c1, ref, 1e-2, "per-image")
+        close(c2, ref, 1e-2, "classic")
+        assert torch.equal(c1, c1b)
+        # without tokens the call is the classic launch, whatever the override says
+        _force_image(1)
+        assert torch.equal(o.dense_gemm_nt(a, b, 0, bias=bias), c2)
+    finally:
+        _force_image(0)
+
+
+@pytest.mark.parametrize("B,N,K", [(64, 5120, 1280), (5, 512, 256), (20, 1024, 512)])
+def test_dense_nt_per_image_fused_tails(B, N, K):
+    """Modes 1 / 4 / 6 (GELU tails) and 3 / 5 (GELU' / stored factor times the product, + column sums) on per-image panels:
+    against the classic panels (elementwise tails of identical pre-activations on the patch rows; class-token rows within
+    one bf16 ulp of the differently ordered f32 sum) and the column sums against a float64 sum of the bf16 result."""
+    o = ops()
+    M = B * 257
+    a, b = rnd((M, K), 31), rnd((N, K), 32, K ** -0.5)
+    bias = rnd((N,), 33, dtype=torch.float32)
+    hpre = rnd((M, N), 34)
+    try:
+        res = {}
+        for force in (1, 2):
+            _force_image(force)
+            r = {}
+            r["h1"], r["g1"] = o.dense_gemm_nt(a, b, 1, bias=bias, tokens=257)
+            r["f4"], r["g4"] = o.dense_gemm_nt(a, b, 4, bias=bias, tokens=257)
+            r["g6"] = o.dense_gemm_nt(a, b, 6, bias=bias, tokens=257)
+            r["d3"], r["s3"] = o.dense_gemm_nt(a, b, 3, h=hpre, want_colsum=True, tokens=257)
+            r["d5"], r["s5"] = o.dense_gemm_nt(a, b, 5, h=r["f4"], want_colsum=True, tokens=257)
+            r["d3n"] = o.dense_gemm_nt(a, b, 3, h=hpre, tokens=257)
+            res[force] = r
+        img, cls = res[1], res[2]
+        pre = (a.double() @ b.double().t() + bias.double())
+        close(img["h1"], pre, 1e-2, "mode 1 pre-activation")
+        assert torch.equal(img["g1"], img["g6"]) and torch.equal(img["g1"], img["g4"])      # one gelu, three modes
+        rows = torch.arange(M, device=DEV)
+        patch = rows % 257 != 0
+        for k in ("h1", "g1", "f4", "g4", "g6", "d3", "d5", "d3n"):
+            x, y = img[k].float(), cls[k].float()
+            # patch rows of full panels run the same K order in both routes unless the classic panel was a split-K tail
+            scale = max(1.0, float(y.abs().max()))
+            assert float((x - y).abs().max()) <= 2 ** -7 * scale, k
+            assert float((x[~patch] - y[~patch]).abs().max()) <= 2 ** -7 * scale, k + " (class-token rows)"
+        assert torch.equal(img["d3"], img["d3n"])
+        for k, d in (("s3", "d3"), ("s5", "d5")):
+            want = img[d].double().sum(0)
+            close(img[k], want, 2e-5, f"column sums {k}")
+            close(cls[k], cls[d].double().sum(0), 2e-5, f"classic column sums {k}")
+        # gelu / gelu' of the bf16-rounded pre-activation, as the row kernels see it
+        hb = img["h1"].float()
+        close(img["g1"], torch.nn.functional.gelu(hb.double()), 1e-2, "gelu")
+        want_f = 0.5 * (1 + torch.erf(hb.double() / 2 ** 0.5)) + hb.double() * torch.exp(-0.5 * hb.double() ** 2) / (2 * torch.pi) ** 0.5
+        close(img["f4"], want_f, 1e-2, "gelu'")
+    finally:
+        _force_image(0)
+
+
+def test_dense_nt_launch_model_takes_per_image_panels_for_vit_huge():
+    """At the bench's shape (64 images x 257 tokens) the launch model picks per-image panels where the saved split-K front of
+    the grid is worth more than the class-token launch costs (N = 1280 with K = 1280 / 3840: proj and the input gradients of
+    proj / qkv - exactly one round of 256 workgroups) and says what it does through octic_dense_gemm_plan."""
+    o = ops()
+    M = 64 * 257
+    for N, K in ((1280, 1280), (1280, 3840)):
+        tile, cs_rows, image, grid = o.dense_plan(M, N, K, 0, 257)
+        assert image and tile == 320 and grid == 256, (N, K, tile, image, grid)
+        assert cs_rows == 2 * 64 + 4
+    assert o.dense_plan(M, 1280, 1280, 0, 0)[2] is False and o.dense_plan(M, 1280, 1280, 2, 257)[2] is False
+    assert o.dense_plan(M, 5120, 1280, 5, 257)[2] is False            # measured: no shorter on per-image panels
+    assert o.dense_plan(8 * 257, 1280, 1280, 0, 257)[2] is False      # one partial round either way: no extra launch
