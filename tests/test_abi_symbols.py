@@ -34,7 +34,7 @@ def test_route_override_is_the_only_switch_and_round_trips():
 
 def test_loader_checks_abi_version_and_errors_render():
     L = _lib.lib()
-    assert L.octic_abi_version() == _lib.ABI_VERSION == 19
+    assert L.octic_abi_version() == _lib.ABI_VERSION == 20
     assert b"shape" in L.octic_strerror(-1)
     assert b"align" in L.octic_strerror(-2)
 
