@@ -343,6 +343,9 @@ class FusedLamb:
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.m.device).cuda_stream)
         fn = self._lib.lib().octic_adamw_step if self.adam else self._lib.lib().octic_lamb_step
+        from . import ops as _ops
+        nparam = int(self.m.numel())
+        kt = _ops.KERNEL_TIMER.start()
         self._lib.check(fn(
             vp(self.p_ptrs), vp(self.g_ptrs), vp(self.m_ptrs), vp(self.v_ptrs), vp(self.e_ptrs), vp(self.wd),
             vp(self.chunk_tensor), vp(self.chunk_off), vp(self.chunk_len), vp(self.tensor_chunk_begin),
@@ -350,6 +353,10 @@ class FusedLamb:
             float(self.eps), float(self.max_grad_norm or 0.0), 0 if self.device_step else self.step_count,
             float(self.ema_decay or 0.0),
             vp(self.s_ptrs), stream))
+        # algorithmic bytes per parameter: gradient norm 4 + (g, m, v, p in; m, v, u out) 28 + (u, p, ema in; p, ema out) 20
+        # + the bf16 copies of the standard half's weights 2 (csrc/lamb.hip)
+        _ops.KERNEL_TIMER.stop(kt, "adamw_step<gradsq+stage1+stage2>" if self.adam else "lamb_step<gradsq+stage1+ratio+stage2>",
+                               (54 if self.ema is not None or self._ema_ext is not None else 46) * nparam)
         # the kernels wrote the parameters behind autograd's back: advance their version counters so that every
         # cache keyed on them (the compute-dtype weight copies of functional.WeightPrep) is refreshed
         torch._C._autograd._unsafe_set_version_counter(
@@ -358,15 +365,19 @@ class FusedLamb:
             torch._C._autograd._unsafe_set_version_counter(
                 tuple(self._ema_ext), tuple(e._version + 1 for e in self._ema_ext))
         if self._wt_items is not None:
+            kt = _ops.KERNEL_TIMER.start()
             self._lib.check(self._lib.lib().octic_dense_prep_batch(vp(self._wt_items), self._wt_count, self._wt_blocks,
                                                                    self._lib.BF16, stream))
+            _ops.KERNEL_TIMER.stop(kt, "dense_prep_batch_kernel", 4 * sum(w.numel() for w in self._wt if w is not None))
         for (lin, cache, wb, bb, _), wt in zip(self._shadows, self._wt):   # the bf16 copies are current for the new versions
             cache.adopt(lin.weight, lin.bias, wb, bb, torch.bfloat16, wt_copy=wt)
         if self._prep_source is not None:
             if self._prep_batch is None or self._prep_batch.stale():
                 from .functional import PrepBatch
                 self._prep_batch = PrepBatch(self._prep_source())
+            kt = _ops.KERNEL_TIMER.start()
             self._prep_batch.run()
+            _ops.KERNEL_TIMER.stop(kt, "linear_prep_batch_kernel", 0)
 
 
 def param_groups_weight_decay(model, weight_decay, no_decay_names=()):
