@@ -640,9 +640,10 @@ def main():
                                       "other_ms": round(ms - timed_us / 1e3, 2),
                                       "note": "per-launch HIP events are recorded in 2 eager steps run right AFTER the timed region "
                                               "(same process, same weights; ~1800 event pairs stretch such a step by ~20 % - gaps "
-                                              "between launches, not kernel time: a bracketed kernel reads 1-3 % longer than in "
-                                              "rocprof); every engine launch incl. the fused optimizer is timed, other = ATen glue "
-                                              "(loss, head GEMMs, copies) minus that inflation - it can come out slightly negative; "
+                                              "between launches, not kernel time; what an EMPTY event pair reads, "
+                                              f"{ops.KERNEL_TIMER.overhead_us:.2f} us here, is subtracted from every bracket); every "
+                                              "engine launch incl. the fused optimizer is timed, other = ATen glue (loss, head "
+                                              "GEMMs, copies); "
                                               "the timed region itself is `steps` full iterations with no event records, no host read"}
         if fwd_only is not None:
             line["extra"] = {"forward_only": fwd_only}

@@ -315,7 +315,10 @@ class LinearD8(nn.Module):
             # being traced: the same kernels through the dispatcher (dispatch.py), no Python-side weight cache
             from . import dispatch as _D   # noqa: F401
             xq = xp if xp.dtype == dtype else xp.to(dtype)
-            y = torch.ops.octic.linear_d8(xq, *self.weights(), self.lin_A1.bias, resid, rs, *cs5, cin, cout, rps)
+            # (the flat prepared copies functional.PrepBatch keeps current in place, where the fused optimizer owns them)
+            fl = self._prep.flat if dtype == torch.bfloat16 else None
+            pwb, pwt = fl if fl is not None else (None, None)
+            y = torch.ops.octic.linear_d8(xq, *self.weights(), self.lin_A1.bias, resid, rs, *cs5, cin, cout, rps, pwb, pwt)
             return Octic(y, cout) if next_norm is None else (Octic(y, cout), None)
         if (next_norm is not None and resid is not None and OF.OCTIC_NEXT_NORM and xp.is_cuda and dtype == torch.bfloat16
                 and resid.dtype == torch.float32 and type(next_norm) is LayerNormD8):

@@ -17,12 +17,16 @@ Python, but opaque to Dynamo - every ctypes call is a graph break.  The ops belo
                  torch.ops.octic.power_spectrum / _bwd    PowerSpectrumInvariant        d8_invariantization.py:49-64
     standard half torch.ops.octic.dense_layernorm / _bwd  nn.LayerNorm (f32 stream -> bf16)    deit/vit.py:131-134
                  torch.ops.octic.dense_linear / _bwd      nn.Linear (+ exact GELU) on csrc/dense_gemm.hip, dense_wgrad.hip   deit/vit.py:14-56
+                 torch.ops.octic.dense_mlp / _bwd         timm Mlp: fc1 + GELU + fc2, gelu'(h) kept as a factor (round 6)   deit/vit.py:131-134
                  torch.ops.octic.attn_qkv / _bwd          SDPA on the fused [B,T,3,H,hd] projection   deit/vit.py:38-45
                  torch.ops.octic.scale_residual / _bwd    x + drop_path(gamma * y)      deit/vit.py:131-134
 
-The weight preparation (bf16 casts, the transposed operand of the input gradient) happens inside the ops, per call: a traced
-graph has no place for a cache keyed on parameter versions.  That, and the fusions that need Python state, is what the traced
-path gives up against the eager one (numbers in DESIGN.md); the arithmetic is identical kernel for kernel.
+Weight preparation (bf16 casts, the transposed operand of the input gradient): a traced graph has no place for a cache keyed on
+parameter versions, so by default it happens inside the ops, per call.  Round 6: where ``train.FusedLamb`` owns the compute-dtype
+copies - it rewrites the SAME buffers in place after every step (DenseWeightCache.static_nt, WeightPrep.flat) - the modules hand
+those buffers to the ops as plain tensor inputs (``wb`` / ``wt``, ``pwb`` / ``pwt``) and no preparation launch is left in the
+traced step.  The fusions that need Python state are what the traced path still gives up against the eager one (numbers in
+DESIGN.md); the arithmetic is identical kernel for kernel.
 There is no CPU kernel: a CPU tensor raises, like every product op."""
 from typing import Optional, Tuple
 
@@ -120,15 +124,21 @@ def _lin_dtype(x):
 @_lib.custom_op("octic::linear_d8", mutates_args=())
 def linear_d8(x: Tensor, wA1: Tensor, wA2: Tensor, wB1: Tensor, wB2: Tensor, wE: Tensor, bias: Optional[Tensor],
               resid: Optional[Tensor], rs: Optional[Tensor], sA1: Optional[Tensor], sA2: Optional[Tensor],
-              sB1: Optional[Tensor], sB2: Optional[Tensor], sE: Optional[Tensor], cin: int, cout: int, rps: int) -> Tensor:
-    """y = resid + rs[row / rps] * cs * (x W^T + bias)   (resid, rs, cs optional); operands in x's dtype (f32 | bf16)."""
+              sB1: Optional[Tensor], sB2: Optional[Tensor], sE: Optional[Tensor], cin: int, cout: int, rps: int,
+              pwb: Optional[Tensor] = None, pwt: Optional[Tensor] = None) -> Tensor:
+    """y = resid + rs[row / rps] * cs * (x W^T + bias)   (resid, rs, cs optional); operands in x's dtype (f32 | bf16).
+    pwb / pwt: the flat prepared bf16 copies of the weights (forward operand / transposed, layer-scale folded in) that
+    functional.PrepBatch refreshes in place after every fused optimizer step - given, no preparation launches run here."""
     x = _c(x)
     dtype = _lin_dtype(x)
-    w32 = [_f32(w) for w in (wA1, wA2, wB1, wB2, wE)]
     cs32 = None if sA1 is None else [_f32(s) for s in (sA1, sA2, sB1, sB2, sE)]
-    wb, _wt = ops.linear_prep(w32, None, cin, cout, dtype, want_wb=(dtype != torch.float32))
-    if wb is None:
-        wb = w32
+    if pwb is not None and dtype == torch.bfloat16 and pwb.dtype == torch.bfloat16:
+        wb = ops.prep_views(pwb, cin, cout, False)
+    else:
+        w32 = [_f32(w) for w in (wA1, wA2, wB1, wB2, wE)]
+        wb, _wt = ops.linear_prep(w32, None, cin, cout, dtype, want_wb=(dtype != torch.float32))
+        if wb is None:
+            wb = w32
     fused = resid is not None
     out_dtype = resid.dtype if fused else dtype
     M = x.numel() // (8 * cin)
@@ -139,7 +149,7 @@ def linear_d8(x: Tensor, wA1: Tensor, wA2: Tensor, wB1: Tensor, wB2: Tensor, wE:
 
 
 @linear_d8.register_fake
-def _(x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps):
+def _(x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps, pwb=None, pwt=None):
     if x.shape[-1] != 8 * cin:
         raise ValueError(f"linear_d8: expected {8 * cin} channels, got {x.shape[-1]}")
     return x.new_empty(x.shape[:-1] + (8 * cout,), dtype=resid.dtype if resid is not None else x.dtype)
@@ -149,7 +159,7 @@ def _(x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, c
 def linear_d8_bwd(dy: Tensor, x: Tensor, wA1: Tensor, wA2: Tensor, wB1: Tensor, wB2: Tensor, wE: Tensor,
                   bias: Optional[Tensor], rs: Optional[Tensor], sA1: Optional[Tensor], sA2: Optional[Tensor],
                   sB1: Optional[Tensor], sB2: Optional[Tensor], sE: Optional[Tensor], cin: int, cout: int, rps: int,
-                  fused: bool, need_dx: bool
+                  fused: bool, need_dx: bool, pwt: Optional[Tensor] = None
                   ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     """-> (dx, dW x 5, dbias, dcs x 5): the chain rule of linear_d8 for dy = dL/dy (f32 when the tail is fused)."""
     x = _c(x)
@@ -166,7 +176,10 @@ def linear_d8_bwd(dy: Tensor, x: Tensor, wA1: Tensor, wA2: Tensor, wB1: Tensor, 
         g = dy
     gv, xv = ops.pview(g, cout), ops.pview(x, cin)
     if need_dx:
-        _wb, wt = ops.linear_prep(w32, cs32, cin, cout, dtype, want_wb=False)
+        if pwt is not None and dtype == torch.bfloat16 and pwt.dtype == torch.bfloat16:
+            wt = ops.prep_views(pwt, cin, cout, True)
+        else:
+            _wb, wt = ops.linear_prep(w32, cs32, cin, cout, dtype, want_wb=False)
         dx = torch.empty(x.shape, dtype=dtype, device=x.device)
         ops.linear_fwd(gv, wt, None, ops.pview(dx, cin), M, cout, cin, dtype, dtype, x)
     else:
@@ -181,7 +194,7 @@ def linear_d8_bwd(dy: Tensor, x: Tensor, wA1: Tensor, wA2: Tensor, wB1: Tensor, 
 
 
 @linear_d8_bwd.register_fake
-def _(dy, x, wA1, wA2, wB1, wB2, wE, bias, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps, fused, need_dx):
+def _(dy, x, wA1, wA2, wB1, wB2, wE, bias, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps, fused, need_dx, pwt=None):
     f = lambda t: t.new_empty(t.shape, dtype=torch.float32)
     e = lambda: x.new_empty(0, dtype=torch.float32)
     dx = x.new_empty(x.shape) if need_dx else x.new_empty(0)
@@ -190,9 +203,9 @@ def _(dy, x, wA1, wA2, wB1, wB2, wE, bias, rs, sA1, sA2, sB1, sB2, sE, cin, cout
 
 
 def _lin_setup(ctx, inputs, output):
-    x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps = inputs
-    ctx.has = (bias is not None, resid is not None, rs is not None, sA1 is not None)
-    opt = [t for t in (bias, rs, sA1, sA2, sB1, sB2, sE) if t is not None]
+    x, wA1, wA2, wB1, wB2, wE, bias, resid, rs, sA1, sA2, sB1, sB2, sE, cin, cout, rps, _pwb, pwt = inputs
+    ctx.has = (bias is not None, resid is not None, rs is not None, sA1 is not None, pwt is not None)
+    opt = [t for t in (bias, rs, sA1, sA2, sB1, sB2, sE, pwt) if t is not None]
     ctx.save_for_backward(x, wA1, wA2, wB1, wB2, wE, *opt)
     ctx.meta = (cin, cout, rps)
     ctx.wdtypes = tuple(w.dtype for w in (wA1, wA2, wB1, wB2, wE))
@@ -200,18 +213,19 @@ def _lin_setup(ctx, inputs, output):
 
 def _lin_backward(ctx, dy):
     x, wA1, wA2, wB1, wB2, wE, *opt = ctx.saved_tensors
-    has_bias, fused, has_rs, has_cs = ctx.has
+    has_bias, fused, has_rs, has_cs, has_pwt = ctx.has
     opt = list(opt)
     bias = opt.pop(0) if has_bias else None
     rs = opt.pop(0) if has_rs else None
+    pwt = opt.pop() if has_pwt else None
     cs = opt if has_cs else [None] * 5
     cin, cout, rps = ctx.meta
     outs = torch.ops.octic.linear_d8_bwd(dy, x, wA1, wA2, wB1, wB2, wE, bias, rs, *cs, cin, cout, rps, fused,
-                                         ctx.needs_input_grad[0])
+                                         ctx.needs_input_grad[0], pwt)
     dx = outs[0] if ctx.needs_input_grad[0] else None
     dw = [d.to(t) for d, t in zip(outs[1:6], ctx.wdtypes)]
     dcs = list(outs[7:12]) if has_cs else [None] * 5
-    return (dx, *dw, outs[6] if has_bias else None, dy if fused else None, None, *dcs, None, None, None)
+    return (dx, *dw, outs[6] if has_bias else None, dy if fused else None, None, *dcs, None, None, None, None, None)
 
 
 linear_d8.register_autograd(_lin_backward, setup_context=_lin_setup)
@@ -322,6 +336,95 @@ def _lift_backward(ctx, dout, _gp):
 lift.register_autograd(_lift_backward, setup_context=_lift_setup)
 
 
+
+# ------------------------------------------------------------------------------------------------ timm Mlp (fc1 + GELU + fc2)
+def _mlp_hip_ok(rows, D, Hd):
+    return (_hip_gemm_ok(rows, Hd, D) and _hip_gemm_ok(rows, D, Hd) and ops.dense_wgrad_ok(rows, Hd, D)
+            and ops.dense_wgrad_ok(rows, D, Hd))
+
+
+@_lib.custom_op("octic::dense_mlp", mutates_args=())
+def dense_mlp(y: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], w1b: Optional[Tensor] = None,
+              w1t: Optional[Tensor] = None, w2b: Optional[Tensor] = None, w2t: Optional[Tensor] = None
+              ) -> Tuple[Tensor, Tensor, Tensor]:
+    """fc2(gelu(fc1(y))) of timm's Mlp (deit/vit.py:131-134 `self.mlp(self.norm2(x))`) on bf16 rows -> (out, factor, a):
+    fc1's epilogue leaves a = gelu(h) and factor = gelu'(h) (one erf for both, mode 4 of octic_dense_gemm_nt); the backward
+    multiplies by the stored factor inside fc2's input-gradient epilogue (mode 5) - no separate GELU-backward pass, as in the
+    eager path (functional.DenseMlpFn).  w?b / w?t: the optimizer's static bf16 / transposed copies (see dense_linear)."""
+    Hd, D = w1.shape
+    y2 = _c(y).reshape(-1, D)
+    if y2.dtype != torch.bfloat16 or not _mlp_hip_ok(y2.shape[0], D, Hd):
+        raise RuntimeError("octic::dense_mlp runs bf16 rows of shapes csrc/dense_gemm.hip and dense_wgrad.hip take; "
+                           "other shapes go through octic::dense_linear")
+    tok = int(y.shape[-2]) if y.dim() >= 3 else 0
+    if w1b is None or w1b.dtype != torch.bfloat16:
+        w1b = w1.detach().to(torch.bfloat16)
+    if w2b is None or w2b.dtype != torch.bfloat16:
+        w2b = w2.detach().to(torch.bfloat16)
+    f, a = ops.dense_gemm_nt(y2, w1b, 4, bias=_f32(b1), tokens=tok)
+    out = ops.dense_gemm_nt(a, w2b, 0, bias=_f32(b2), tokens=tok)
+    return out.view(y.shape), f, a
+
+
+@dense_mlp.register_fake
+def _(y, w1, b1, w2, b2, w1b=None, w1t=None, w2b=None, w2t=None):
+    rows = y.numel() // y.shape[-1]
+    return (torch.empty_like(y, memory_format=torch.contiguous_format), y.new_empty((rows, w1.shape[0])),
+            y.new_empty((rows, w1.shape[0])))
+
+
+@_lib.custom_op("octic::dense_mlp_bwd", mutates_args=())
+def dense_mlp_bwd(dout: Tensor, y: Tensor, f: Tensor, a: Tensor, w1: Tensor, w2: Tensor, need_dy: bool,
+                  w1t: Optional[Tensor] = None, w2t: Optional[Tensor] = None
+                  ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """-> (dy, dW1, db1, dW2, db2), all parameter gradients f32."""
+    Hd, D = w1.shape
+    y2 = _c(y).reshape(-1, D)
+    g2 = _c(dout.to(torch.bfloat16)).reshape(-1, D)
+    tok = int(y.shape[-2]) if y.dim() >= 3 else 0
+    if w2t is None or w2t.dtype != torch.bfloat16:
+        w2t = w2.detach().to(torch.bfloat16).t().contiguous()
+    db2 = ops.dense_colsum(g2)
+    dh, db1 = ops.dense_gemm_nt(g2, w2t, 5, h=f, want_colsum=True, tokens=tok)       # factor * (dout W2), + fc1's bias gradient
+    dw2 = ops.dense_wgrad_tn(g2, a)
+    dw1 = ops.dense_wgrad_tn(dh, y2)
+    if need_dy:
+        if w1t is None or w1t.dtype != torch.bfloat16:
+            w1t = w1.detach().to(torch.bfloat16).t().contiguous()
+        dy = ops.dense_gemm_nt(dh, w1t, 0, tokens=tok).view(y.shape)
+    else:
+        dy = y.new_empty(0)
+    return dy, dw1, db1, dw2, db2
+
+
+@dense_mlp_bwd.register_fake
+def _(dout, y, f, a, w1, w2, need_dy, w1t=None, w2t=None):
+    f32 = lambda t: t.new_empty(t.shape, dtype=torch.float32)
+    return ((torch.empty_like(y, memory_format=torch.contiguous_format) if need_dy else y.new_empty(0)), f32(w1),
+            w1.new_empty(w1.shape[0], dtype=torch.float32), f32(w2), w2.new_empty(w2.shape[0], dtype=torch.float32))
+
+
+def _mlp_setup(ctx, inputs, output):
+    y, w1, b1, w2, b2, _w1b, w1t, _w2b, w2t = inputs
+    ctx.has_t = (w1t is not None, w2t is not None)
+    ctx.save_for_backward(y, output[1], output[2], w1, w2, *[t for t in (w1t, w2t) if t is not None])
+    ctx.meta = (b1 is not None, b2 is not None, w1.dtype, w2.dtype, None if b1 is None else b1.dtype,
+                None if b2 is None else b2.dtype)
+
+
+def _mlp_backward(ctx, dout, _gf, _ga):
+    y, f, a, w1, w2, *rest = ctx.saved_tensors
+    rest = list(rest)
+    w1t = rest.pop(0) if ctx.has_t[0] else None
+    w2t = rest.pop(0) if ctx.has_t[1] else None
+    has_b1, has_b2, w1d, w2d, b1d, b2d = ctx.meta
+    dy, dw1, db1, dw2, db2 = torch.ops.octic.dense_mlp_bwd(dout, y, f, a, w1, w2, ctx.needs_input_grad[0], w1t, w2t)
+    return ((dy if ctx.needs_input_grad[0] else None), dw1.to(w1d), (db1.to(b1d) if has_b1 else None), dw2.to(w2d),
+            (db2.to(b2d) if has_b2 else None), None, None, None, None)
+
+
+dense_mlp.register_autograd(_mlp_backward, setup_context=_mlp_setup)
+
 # ------------------------------------------------------------------------------------------------ hand-off
 @_lib.custom_op("octic::handoff_cat", mutates_args=())
 def handoff_cat(x: Tensor, c: int, out_bf16: bool) -> Tensor:
@@ -423,18 +526,23 @@ def _hip_gemm_ok(rows, N, K):
 
 
 @_lib.custom_op("octic::dense_linear", mutates_args=())
-def dense_linear(x: Tensor, w: Tensor, b: Optional[Tensor], gelu: bool) -> Tuple[Tensor, Tensor]:
+def dense_linear(x: Tensor, w: Tensor, b: Optional[Tensor], gelu: bool, wb: Optional[Tensor] = None,
+                 wt: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """nn.Linear on bf16 rows: (x W^T + b, -) or, with gelu, (gelu(h), h) with h = x W^T + b from ONE epilogue
-    (deit/vit.py Mlp: fc1 + act).  csrc/dense_gemm.hip where the shape allows, the BLAS library otherwise."""
+    (deit/vit.py Mlp: fc1 + act).  csrc/dense_gemm.hip where the shape allows, the BLAS library otherwise.
+    wb / wt: the bf16 copy of w and its transposed copy that train.FusedLamb rewrites in place after every step
+    (functional.DenseWeightCache.static_nt) - given, no cast / transpose launches run here or in the backward."""
     N, K = w.shape
     x2 = _c(x).reshape(-1, K)
-    wb = w.detach().to(torch.bfloat16)
+    if wb is None or wb.dtype != torch.bfloat16:
+        wb = w.detach().to(torch.bfloat16)
     lead = x.shape[:-1]
+    tok = int(x.shape[-2]) if x.dim() >= 3 else 0
     if x2.dtype == torch.bfloat16 and _hip_gemm_ok(x2.shape[0], N, K) and N % 8 == 0:
         if gelu:
-            h, y = ops.dense_gemm_nt(x2, wb, 1, bias=_f32(b))
+            h, y = ops.dense_gemm_nt(x2, wb, 1, bias=_f32(b), tokens=tok)
             return y.view(lead + (N,)), h.view(lead + (N,))
-        y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b))
+        y = ops.dense_gemm_nt(x2, wb, 0, bias=_f32(b), tokens=tok)
         return y.view(lead + (N,)), y.new_empty(0)
     h = torch.nn.functional.linear(x2, wb.to(x2.dtype), None if b is None else b.detach().to(x2.dtype))
     if gelu:
@@ -443,13 +551,14 @@ def dense_linear(x: Tensor, w: Tensor, b: Optional[Tensor], gelu: bool) -> Tuple
 
 
 @dense_linear.register_fake
-def _(x, w, b, gelu):
+def _(x, w, b, gelu, wb=None, wt=None):
     y = x.new_empty(x.shape[:-1] + (w.shape[0],))
     return y, (torch.empty_like(y) if gelu else x.new_empty(0))
 
 
 @_lib.custom_op("octic::dense_linear_bwd", mutates_args=())
-def dense_linear_bwd(dy: Tensor, x: Tensor, w: Tensor, h: Tensor, gelu: bool, need_dx: bool) -> Tuple[Tensor, Tensor, Tensor]:
+def dense_linear_bwd(dy: Tensor, x: Tensor, w: Tensor, h: Tensor, gelu: bool, need_dx: bool,
+                     wt: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """-> (dx, dW f32, db f32): input gradient on the NT kernel (GELU' in its epilogue when gelu), weight gradient on the TN
     kernel, bias gradient as the column sums of the cotangent."""
     N, K = w.shape
@@ -457,7 +566,8 @@ def dense_linear_bwd(dy: Tensor, x: Tensor, w: Tensor, h: Tensor, gelu: bool, ne
     g2 = _c(dy.to(x2.dtype)).reshape(-1, N)
     M = x2.shape[0]
     hip = x2.dtype == torch.bfloat16 and _hip_gemm_ok(M, N, K) and _hip_gemm_ok(M, K, N)
-    wt = w.detach().to(torch.bfloat16).t().contiguous()            # [K, N]: the input gradient is an NT problem too
+    if need_dx and (wt is None or wt.dtype != torch.bfloat16):
+        wt = w.detach().to(torch.bfloat16).t().contiguous()        # [K, N]: the input gradient is an NT problem too
     if gelu:
         h2 = _c(h).reshape(-1, N)
         if x2.dtype == torch.bfloat16:
@@ -472,7 +582,8 @@ def dense_linear_bwd(dy: Tensor, x: Tensor, w: Tensor, h: Tensor, gelu: bool, ne
         dh = g2
         db = ops.dense_colsum(g2) if (g2.dtype == torch.bfloat16 and N % 2 == 0) else g2.float().sum(0)
     if need_dx:
-        dx = ops.dense_gemm_nt(dh, wt, 0) if hip else (dh @ wt.t().to(dh.dtype))
+        dx = (ops.dense_gemm_nt(dh, wt, 0, tokens=int(x.shape[-2]) if x.dim() >= 3 else 0) if hip
+              else (dh @ wt.t().to(dh.dtype)))
         dx = dx.view(x.shape)
     else:
         dx = x.new_empty(0)
@@ -484,22 +595,22 @@ def dense_linear_bwd(dy: Tensor, x: Tensor, w: Tensor, h: Tensor, gelu: bool, ne
 
 
 @dense_linear_bwd.register_fake
-def _(dy, x, w, h, gelu, need_dx):
+def _(dy, x, w, h, gelu, need_dx, wt=None):
     return ((torch.empty_like(x, memory_format=torch.contiguous_format) if need_dx else x.new_empty(0)),
             w.new_empty(w.shape, dtype=torch.float32), w.new_empty(w.shape[0], dtype=torch.float32))
 
 
 def _dl_setup(ctx, inputs, output):
-    x, w, b, gelu = inputs
-    ctx.save_for_backward(x, w, output[1])
+    x, w, b, gelu, _wb, wt = inputs
+    ctx.save_for_backward(x, w, output[1], *(() if wt is None else (wt,)))
     ctx.meta = (gelu, b is not None, w.dtype, None if b is None else b.dtype)
 
 
 def _dl_backward(ctx, dy, _gh):
-    x, w, h = ctx.saved_tensors
+    x, w, h, *rest = ctx.saved_tensors
     gelu, has_b, wdt, bdt = ctx.meta
-    dx, dw, db = torch.ops.octic.dense_linear_bwd(dy, x, w, h, gelu, ctx.needs_input_grad[0])
-    return (dx if ctx.needs_input_grad[0] else None), dw.to(wdt), (db.to(bdt) if has_b else None), None
+    dx, dw, db = torch.ops.octic.dense_linear_bwd(dy, x, w, h, gelu, ctx.needs_input_grad[0], rest[0] if rest else None)
+    return (dx if ctx.needs_input_grad[0] else None), dw.to(wdt), (db.to(bdt) if has_b else None), None, None, None
 
 
 dense_linear.register_autograd(_dl_backward, setup_context=_dl_setup)

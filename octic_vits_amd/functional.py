@@ -162,6 +162,8 @@ class WeightPrep:
         self.key = None
         self.wb = self.wt = None
         self.last = None            # (w5, cs5, dtype, cin, cout) of the latest call: what a PrepBatch needs
+        self.flat = None            # (wb, wt) flat bf16 buffers a PrepBatch refreshes IN PLACE after every optimizer step: what a
+                                    # traced graph may read as plain inputs (dispatch.py) - None while this object prepares itself
 
     @staticmethod
     def _key(w5, cs5, dtype):
@@ -177,14 +179,16 @@ class WeightPrep:
                 wb, self.wt = ops.linear_prep(w32, cs32, cin, cout, dtype, want_wb=(dtype != torch.float32))
                 self.wb = wb if wb is not None else w32   # f32: the master weights are the forward operand
             self.key = key
+            self.flat = None
         self.last = (w5, cs5, dtype, cin, cout)
         return self.wb, self.wt
 
-    def adopt(self, wb, wt):
+    def adopt(self, wb, wt, flat=None):
         """Copies produced elsewhere (PrepBatch) are current for the parameters' present versions."""
         w5, cs5, dtype, _, _ = self.last
         self.wb, self.wt = wb, wt
         self.key = self._key(w5, cs5, dtype)
+        self.flat = flat
 
 
 class PrepBatch:
@@ -203,13 +207,14 @@ class PrepBatch:
         dt = np.dtype([("w", "<u8", 5), ("cs", "<u8", 5), ("wb", "<u8"), ("wt", "<u8"), ("cin", "<i4"), ("cout", "<i4"),
                        ("block_begin", "<i4"), ("block_count", "<i4")])
         tab = np.zeros(len(self.preps), dtype=dt)
-        self.bufs, blocks = [], 0
+        self.bufs, self.flats, blocks = [], [], 0
         for i, p in enumerate(self.preps):
             w5, cs5, dtype, cin, cout = p.last
             n = 8 * cin * cout
             wb = torch.empty(n, dtype=dtype, device=dev)
             wt = torch.empty(n, dtype=dtype, device=dev)
             self.bufs.append((ops.prep_views(wb, cin, cout, False), ops.prep_views(wt, cin, cout, True)))
+            self.flats.append((wb, wt))
             cnt = ops.lib().octic_linear_d8_prep_batch_blocks(cin, cout)   # one 64 x 64 tile per workgroup
             tab[i]["w"] = [t.data_ptr() for t in w5]
             tab[i]["cs"] = [0] * 5 if cs5 is None else [t.data_ptr() for t in cs5]
@@ -234,8 +239,8 @@ class PrepBatch:
             return
         ops.check(ops.lib().octic_linear_d8_prep_batch(ops._p(self.items), len(self.preps), self.total_blocks,
                                                        ops.dt_code(torch.bfloat16), ops._stream(self.items)))
-        for p, (wb, wt) in zip(self.preps, self.bufs):
-            p.adopt(wb, wt)
+        for p, (wb, wt), flat in zip(self.preps, self.bufs, self.flats):
+            p.adopt(wb, wt, flat)
 
 
 class LinearD8Fn(torch.autograd.Function):
@@ -493,6 +498,14 @@ class DenseWeightCache:
         self.key = None
         self.w = self.b = None
         self.wt = self.wt_key = None
+        self.static = False         # the copies are refreshed IN PLACE by their producer after every optimizer step (adopt):
+                                    # a traced graph may read them as plain inputs (dispatch.py)
+
+    def static_nt(self):
+        """(bf16 W, bf16 W^T or None) when the fused optimizer keeps them current in place, else (None, None)."""
+        if self.static and self.w is not None and self.w.dtype == torch.bfloat16:
+            return self.w, (self.wt if self.wt_key == self.key else None)
+        return None, None
 
     @staticmethod
     def _key(w, b, dtype):
@@ -506,6 +519,7 @@ class DenseWeightCache:
                 self.b = None if b is None else _c(b.detach().to(dtype))
             self.key = key
             self.wt, self.wt_key = None, None     # a transposed copy of the old cast is stale with it
+            self.static = False
         return self.w, self.b
 
     def adopt(self, w, b, w_copy, b_copy, dtype, wt_copy=None):
@@ -513,6 +527,7 @@ class DenseWeightCache:
         current cache content for the parameters' present versions."""
         self.w, self.b = w_copy, b_copy
         self.key = self._key(w, b, dtype)
+        self.static = True
         if wt_copy is not None:
             self.wt, self.wt_key = wt_copy, self.key
 

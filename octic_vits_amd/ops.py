@@ -51,7 +51,7 @@ class KernelTimer:
         for name, e0, e1, b, f in self.records:
             a = agg.setdefault(name, {"name": name, "launches": 0, "total_us": 0.0, "bytes": 0.0, "flops": 0.0})
             a["launches"] += 1
-            a["total_us"] += e0.elapsed_time(e1) * 1e3
+            a["total_us"] += max(0.0, e0.elapsed_time(e1) * 1e3 - self.overhead_us)
             a["bytes"] += b
             a["flops"] += f
         for a in agg.values():

@@ -246,14 +246,21 @@ def _traced_block(x, norm1, attn, gamma1, dp1, norm2, mlp, gamma2, dp2):
     B, N, C = x.shape
     H = attn.num_heads
     hd = C // H
+    # the bf16 / transposed weight copies the fused optimizer keeps current in place (None, None: the ops cast per call)
     y = o.dense_layernorm(x, norm1.weight, norm1.bias, norm1.eps, True)[0]
-    qkv = o.dense_linear(y, attn.qkv.weight, attn.qkv.bias, False)[0]
+    qkv = o.dense_linear(y, attn.qkv.weight, attn.qkv.bias, False, *attn._c1.static_nt())[0]
     a = o.attn_qkv(qkv.view(B, N, 3, H, hd), hd ** -0.5)[0]
-    p = o.dense_linear(a, attn.proj.weight, attn.proj.bias, False)[0]
+    p = o.dense_linear(a, attn.proj.weight, attn.proj.bias, False, *attn._c2.static_nt())[0]
     x = o.scale_residual(x, p, gamma1, _drop_path_scale(dp1, x), N)
     y = o.dense_layernorm(x, norm2.weight, norm2.bias, norm2.eps, True)[0]
-    h = o.dense_linear(y, mlp.fc1.weight, mlp.fc1.bias, True)[0]
-    f = o.dense_linear(h, mlp.fc2.weight, mlp.fc2.bias, False)[0]
+    Hd = mlp.fc1.weight.shape[0]
+    if _D._mlp_hip_ok(B * N, C, Hd):
+        # fc1 + GELU + fc2 as one op: gelu'(h) is kept as a bf16 factor and applied inside fc2's input-gradient epilogue
+        f = o.dense_mlp(y, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, *mlp._c1.static_nt(),
+                        *mlp._c2.static_nt())[0]
+    else:
+        h = o.dense_linear(y, mlp.fc1.weight, mlp.fc1.bias, True, *mlp._c1.static_nt())[0]
+        f = o.dense_linear(h, mlp.fc2.weight, mlp.fc2.bias, False, *mlp._c2.static_nt())[0]
     return o.scale_residual(x, f, gamma2, _drop_path_scale(dp2, x), N)
 
 

@@ -91,6 +91,48 @@ def test_dense_ops_pass_opcheck():
     rs = torch.rand(B, generator=g, device=DEV) + 0.5
     torch.library.opcheck(o.scale_residual, (x, y, gamma, rs, T))
     torch.library.opcheck(o.scale_residual, (x, y, None, None, T))
+    # round 6: prepared weight copies as plain inputs, and the fused Mlp op (shapes the TN weight-gradient kernel takes)
+    Wb = W.detach().to(torch.bfloat16)
+    torch.library.opcheck(o.dense_linear, (xb, W, bias, True, Wb, Wb.t().contiguous()))
+    d2 = 256
+    xm = torch.randn(B, T, d2, generator=g, device=DEV).bfloat16().requires_grad_(True)
+    W1 = (torch.randn(512, d2, generator=g, device=DEV) * d2 ** -0.5).requires_grad_(True)
+    b1 = torch.randn(512, generator=g, device=DEV).requires_grad_(True)
+    Wm2 = (torch.randn(d2, 512, generator=g, device=DEV) * 512 ** -0.5).requires_grad_(True)
+    b2 = torch.randn(d2, generator=g, device=DEV).requires_grad_(True)
+    torch.library.opcheck(o.dense_mlp, (xm, W1, b1, Wm2, b2))
+    w1b, w2b = W1.detach().bfloat16(), Wm2.detach().bfloat16()
+    torch.library.opcheck(o.dense_mlp, (xm, W1, b1, Wm2, None, w1b, w1b.t().contiguous(), w2b, w2b.t().contiguous()))
+
+
+def test_dense_mlp_op_equals_the_two_linear_ops():
+    """octic::dense_mlp against fc1 (gelu) + fc2 through octic::dense_linear: same forward bits (gelu of the same rounded
+    pre-activation, same fc2 GEMM); gradients differ only by the bf16 rounding of the stored gelu' factor."""
+    from octic_vits_amd import dispatch  # noqa: F401
+    o = torch.ops.octic
+    g = torch.Generator(device=DEV).manual_seed(4)
+    B, T, d, hd = 3, 257, 256, 1024
+    W1 = (torch.randn(hd, d, generator=g, device=DEV) * d ** -0.5).requires_grad_(True)
+    b1 = torch.randn(hd, generator=g, device=DEV).mul(0.1).requires_grad_(True)
+    W2 = (torch.randn(d, hd, generator=g, device=DEV) * hd ** -0.5).requires_grad_(True)
+    b2 = torch.randn(d, generator=g, device=DEV).mul(0.1).requires_grad_(True)
+    x = torch.randn(B, T, d, generator=g, device=DEV).bfloat16()
+    cot = torch.randn(B, T, d, generator=g, device=DEV)
+    res = []
+    for fused in (True, False):
+        xin = x.clone().requires_grad_(True)
+        for p in (W1, b1, W2, b2):
+            p.grad = None
+        if fused:
+            out = o.dense_mlp(xin, W1, b1, W2, b2)[0]
+        else:
+            out = o.dense_linear(o.dense_linear(xin, W1, b1, True)[0], W2, b2, False)[0]
+        (out.float() * cot).sum().backward()
+        res.append((out.detach().float(), [t.grad.detach().float().clone() for t in (xin, W1, b1, W2, b2)]))
+    (oa, ga), (ob, gb) = res
+    assert torch.equal(oa, ob)
+    for a_, b_ in zip(ga, gb):
+        assert float((a_ - b_).norm()) <= 2e-2 * float(b_.norm()) + 1e-9
 
 
 def test_linear_d8_op_equals_the_eager_function_bitwise():
@@ -205,3 +247,45 @@ def test_whole_model_compiles_and_its_train_step_equals_eager():
     assert set(g1) == set(g2)
     for n in g1:
         assert float((g1[n] - g2[n]).norm()) <= 3e-2 * float(g1[n].norm()) + 1e-9, n
+
+
+def test_compiled_step_reads_the_optimizers_static_weight_copies_and_tracks_eager_over_steps():
+    """Round 6: under train.Trainer the dispatcher ops get the bf16 / prepared weight copies the fused optimizer rewrites in
+    place as plain inputs (DenseWeightCache.static_nt, WeightPrep.flat) - no preparation launch in the traced step.  Two
+    identically initialised trainers, one stepping eagerly and one through torch.compile(model), must stay together over
+    several optimizer steps (a graph that kept reading stale copies would fall behind at once); and the traced calls must
+    really have been handed the static buffers."""
+    from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8, LinearD8
+    from octic_vits_amd.model import OcticVisionTransformer
+    from octic_vits_amd.train import Trainer, synthetic_batch
+    from octic_vits_amd.vit import Attention, Layer_scale_init_Block
+
+    def make():
+        torch.manual_seed(0)
+        return OcticVisionTransformer(img_size=56, patch_size=14, num_classes=10, embed_dim=640, depth=4, num_heads=8,
+                                      qkv_bias=True, init_scale=0.1, octic_block_layers=Layer_scale_init_BlockD8,
+                                      standard_block_layers=Layer_scale_init_Block, drop_path_rate=0.0).to(DEV)
+    ma, mb = make(), make()
+    ta, tb = Trainer(ma, lr=2e-3), Trainer(mb, lr=2e-3)
+    x, y = synthetic_batch(4, 10, DEV, seed=3, img_size=56)
+    for _ in range(2):                                   # eager steps: the caches are adopted by the optimizer
+        ta.step(x, y)
+        tb.step(x, y)
+    att = next(m for m in mb.modules() if isinstance(m, Attention))
+    lin = next(m for m in mb.modules() if isinstance(m, LinearD8))
+    wb, wt = att._c1.static_nt()
+    assert wb is not None and wt is not None and lin._prep.flat is not None
+    ptrs = (wb.data_ptr(), wt.data_ptr(), lin._prep.flat[0].data_ptr())
+    tb.model = torch.compile(mb, backend="aot_eager")
+    la, lb = [], []
+    for _ in range(4):
+        la.append(float(ta.step(x, y).detach()))
+        lb.append(float(tb.step(x, y).detach()))
+    # same buffers, rewritten in place, still current
+    wb2, wt2 = att._c1.static_nt()
+    assert (wb2.data_ptr(), wt2.data_ptr(), lin._prep.flat[0].data_ptr()) == ptrs
+    assert torch.equal(wb2, att.qkv.weight.detach().to(torch.bfloat16))
+    assert la == pytest.approx(lb, rel=2e-2), (la, lb)
+    assert la[-1] < la[0]
+    for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert float((pa - pb).norm()) <= 5e-2 * float(pa.norm()) + 1e-6, n
