@@ -499,12 +499,14 @@ class DenseWeightCache:
         self.w = self.b = None
         self.wt = self.wt_key = None
         self.static = False         # the copies are refreshed IN PLACE by their producer after every optimizer step (adopt):
-                                    # a traced graph may read them as plain inputs (dispatch.py)
+        self.static_wt = False      # a traced graph may read them as plain inputs (dispatch.py)
 
     def static_nt(self):
         """(bf16 W, bf16 W^T or None) when the fused optimizer keeps them current in place, else (None, None)."""
+        # (reads nothing that changes from step to step - no keys, no version counters: torch.compile guards on what a traced
+        # function reads, and a guard on a version counter would recompile the block after every optimizer step)
         if self.static and self.w is not None and self.w.dtype == torch.bfloat16:
-            return self.w, (self.wt if self.wt_key == self.key else None)
+            return self.w, (self.wt if self.static_wt else None)
         return None, None
 
     @staticmethod
@@ -519,7 +521,7 @@ class DenseWeightCache:
                 self.b = None if b is None else _c(b.detach().to(dtype))
             self.key = key
             self.wt, self.wt_key = None, None     # a transposed copy of the old cast is stale with it
-            self.static = False
+            self.static = self.static_wt = False
         return self.w, self.b
 
     def adopt(self, w, b, w_copy, b_copy, dtype, wt_copy=None):
@@ -528,6 +530,7 @@ class DenseWeightCache:
         self.w, self.b = w_copy, b_copy
         self.key = self._key(w, b, dtype)
         self.static = True
+        self.static_wt = wt_copy is not None
         if wt_copy is not None:
             self.wt, self.wt_key = wt_copy, self.key
 
