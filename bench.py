@@ -368,8 +368,8 @@ def main():
     log("model on device")
     tkw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
     ddp = world > 1 or args.force_ddp
-    own = ddp and not args.torch_ddp and args.accum == 1 and not args.bf16_buckets and not (args.segment_graphs or 0)
-    one_graph = (not ddp or (own and os.environ.get("OCTIC_DDP_GRAPH", "1") != "0")) and args.accum == 1 and not args.no_graph
+    own = ddp and not args.torch_ddp and not args.bf16_buckets and not (args.segment_graphs or 0)
+    one_graph = (not ddp or (own and os.environ.get("OCTIC_DDP_GRAPH", "1") != "0")) and not args.no_graph
     # segment graphs are opt-in: on one MI355X the 2 x 8 replays run the step in 75.7 ms against 67.8 ms for eager launches
     # (gradient clones out of the static buffers, cut fusion links, per-slice mask pools) - they pay once the eager step
     # is host-bound (tools/host_profile.py: ~45 ms of Python / ctypes per step), which at 67 ms of kernels it is not

@@ -693,6 +693,7 @@ class GradReducer:
         self._misc = self._misc_views = self._misc_key = None
         self._works, self._fired, self._seen = [], set(), set()
         self.active = False
+        self._hold = False
         self.early = 0                                  # buckets of the last pass whose collective was issued before its end
 
     # ---- the ops.GRAD_DEST protocol ----------------------------------------------------------------------------------
@@ -701,7 +702,7 @@ class GradReducer:
 
     def written(self, ptr):
         k = self._bucket_of.get(ptr)
-        if k is None or not self.active or ptr in self._seen:
+        if k is None or not self.active or self._hold or ptr in self._seen:
             return
         self._seen.add(ptr)
         b = self.buckets[k]
@@ -710,13 +711,16 @@ class GradReducer:
             self._fire(k)
 
     # ---- one backward pass ---------------------------------------------------------------------------------------------
-    def begin(self):
-        """Call with every .grad None, right before backward(); installs this object as ops.GRAD_DEST."""
+    def begin(self, hold=False):
+        """Call with every .grad None, right before backward(); installs this object as ops.GRAD_DEST.
+        hold: more micro-batches follow (gradient accumulation) - gradients still land in the buckets, but nothing is reduced
+        before ``reduce_all``."""
         from . import ops
         self._works, self._fired, self._seen = [], set(), set()
         for b in self.buckets:
             b[2] = len(b[1])
         self.active = True
+        self._hold = bool(hold)
         self._prev_dest, ops.GRAD_DEST = ops.GRAD_DEST, self
 
     def _fire(self, k):
@@ -753,9 +757,10 @@ class GradReducer:
                                  [t.view_as(p) for t, p in zip(flat.split([p.numel() for p in sel]), sel)])
 
     @torch.no_grad()
-    def finish(self):
-        """After backward(): gather what was not written in place, reduce what has not been reduced yet, re-point every .grad
-        at reduced memory, and make the current stream wait for the collectives."""
+    def settle(self):
+        """After the (first) backward(): gather what was not written in place and re-point every .grad at bucket / misc memory -
+        no collective.  With gradient accumulation the later micro-batches then ADD into those views (autograd accumulates in
+        place into an existing .grad)."""
         from . import ops
         ops.GRAD_DEST = self._prev_dest
         self.active = False
@@ -775,9 +780,8 @@ class GradReducer:
                 p.grad = v
         if src:
             torch._foreach_copy_(dst, src)
-        for k in range(len(self.buckets)):
-            self._fire(k)
         live = [p for p in self.small if p.grad is not None]
+        self._misc_live = bool(live)
         if live:
             key = tuple(id(p) for p in live)
             if self._misc_key != key:                   # (built once: the set of tensors with gradients does not change)
@@ -788,11 +792,23 @@ class GradReducer:
             torch._foreach_copy_(self._misc_views, [p.grad for p in live])
             for p, v in zip(live, self._misc_views):
                 p.grad = v
+
+    @torch.no_grad()
+    def reduce_all(self):
+        """Reduce what has not been reduced yet and make the current stream wait for every collective of the pass."""
+        for k in range(len(self.buckets)):
+            self._fire(k)
+        if self._misc_live:
             self._fire(-1)
         for w in self._works:
             w.wait()
         self._works = []
 
+    def finish(self):
+        """After backward() of a one-micro-batch step: ``settle`` + ``reduce_all`` - every .grad a view of reduced memory, the
+        current stream behind the collectives."""
+        self.settle()
+        self.reduce_all()
 
 class DdpTrafficProxy:
     """A one-GPU stand-in for what the gradient all-reduce of an N-GPU step does to the step (round-4 review item 5): a DDP
@@ -909,8 +925,9 @@ class Trainer:
         accumulation, where the whole-step graph of ``capture`` does not apply.
         own_reducer (distributed only): average the gradients with ``GradReducer`` instead of DistributedDataParallel - the
         step keeps its batched finishes and paired weight gradients and can be captured as ONE hipGraph with the RCCL
-        collectives inside (``capture``).  None = wherever it applies: one micro-batch per step, no segment graphs, f32
-        buckets, f32 master parameters; everything else goes through DistributedDataParallel as before."""
+        collectives inside (``capture``), gradient accumulation included (the first micro-batch lands in the buckets, the
+        others add to them, the collectives follow the last one).  None = wherever it applies: f32 buckets, f32 master
+        parameters, no segment graphs; everything else goes through DistributedDataParallel as before."""
         self.raw_model = model
         self.segmented = None
         if segment_graphs:
@@ -926,11 +943,10 @@ class Trainer:
         self._proxy = ddp_proxy                         # a DdpTrafficProxy: its hook replaces the all-reduce (measurement only)
         self._reducer = None
         if distributed:
-            can_own = (self.accum_steps == 1 and self.segmented is None and not bf16_buckets and ddp_proxy is None
+            can_own = (self.segmented is None and not bf16_buckets and ddp_proxy is None
                        and all(p.dtype == torch.float32 for p in model.parameters() if p.requires_grad))
             if own_reducer and not can_own:
-                raise ValueError("Trainer(own_reducer=True) needs accum_steps == 1, no segment graphs, f32 buckets and f32 "
-                                 "master parameters")
+                raise ValueError("Trainer(own_reducer=True) needs f32 buckets, f32 master parameters and no segment graphs")
             if can_own if own_reducer is None else own_reducer:
                 self._reducer = GradReducer(list(model.parameters()), bucket_mb=bucket_cap_mb)
                 self._reducer.broadcast(list(model.parameters()) + list(model.buffers()))
@@ -1037,26 +1053,54 @@ class Trainer:
                 return self.criterion(outputs.float(), targets)
         return self.criterion(self.model(samples).float(), targets)
 
-    def _batched_finishes(self):
+    def _batched_finishes(self, first_of_many=False):
         """The parameter-gradient slab reductions of the backward pass as one batched launch at its end
         (ops._DeferredFinishes) - only where nothing can read those gradients earlier: one micro-batch into .grad = None,
-        no DDP bucket hooks, no graphed slices."""
+        no DDP bucket hooks, no graphed slices.  first_of_many: the FIRST micro-batch of an accumulated step under the own
+        reducer also qualifies (every .grad is None; the later ones add into existing gradients and do not)."""
         from . import ops
-        safe = (BATCHED_FINISHES and self.device_type == "cuda" and self.model is self.raw_model and self.accum_steps == 1)
+        safe = (BATCHED_FINISHES and self.device_type == "cuda" and self.model is self.raw_model
+                and (self.accum_steps == 1 or first_of_many))
         return _FinishScope(ops.DEFERRED_FINISHES, safe)
 
-    def _reduced_backward(self, loss):
+    def _reduced_backward(self, loss, hold=False):
         """backward() with the gradients landing in GradReducer's buckets, bucket all-reduces issued as they fill, and the
         same batched finishes / paired weight gradients as the one-GPU step (nothing reads a gradient before ``finish``)."""
         r = self._reducer
-        r.begin()
+        r.begin(hold=hold)
         try:
-            with self._batched_finishes():
+            with self._batched_finishes(first_of_many=hold):
                 loss.backward()
         except BaseException:
             r.abort()
             raise
-        r.finish()
+        if hold:
+            r.settle()
+        else:
+            r.finish()
+
+    def _accumulate(self, samples, targets):
+        """k micro-batches into one gradient (mean of the micro-batch mean losses).  Own reducer: the first backward writes into
+        the buckets, the others add to them in place, ONE round of collectives follows the last; DDP: ``no_sync`` before the last."""
+        k = self.accum_steps
+        xs, ys = samples.chunk(k), targets.chunk(k)
+        loss = None
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            last = i == len(xs) - 1
+            ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and not last) else _null()
+            with ctx:
+                li = self._forward_loss(x, y) / len(xs)
+                if self._reducer is not None and i == 0:
+                    self._reduced_backward(li, hold=True)
+                elif i == 0:
+                    with self._batched_finishes(first_of_many=True):   # (every .grad is None: as in a one-micro-batch step)
+                        li.backward()
+                else:
+                    li.backward()
+            loss = li.detach() if loss is None else loss + li.detach()
+        if self._reducer is not None:
+            self._reducer.reduce_all()
+        return loss
 
     def step(self, samples, targets):
         if self._ddp_args is not None and self.model is self.segmented:
@@ -1100,15 +1144,7 @@ class Trainer:
                 with self._batched_finishes():
                     loss.backward()
         else:
-            xs, ys = samples.chunk(k), targets.chunk(k)
-            loss = None
-            for i, (x, y) in enumerate(zip(xs, ys)):
-                last = i == len(xs) - 1
-                ctx = self.model.no_sync() if (hasattr(self.model, "no_sync") and not last) else _null()
-                with ctx:
-                    li = self._forward_loss(x, y) / len(xs)
-                    li.backward()
-                loss = li.detach() if loss is None else loss + li.detach()
+            loss = self._accumulate(samples, targets)
         self._reduce_small_grads()
         if self._proxy is not None:
             self._proxy.join()                          # the optimizer reads the "reduced" buckets
@@ -1122,7 +1158,8 @@ class Trainer:
     def capture(self, samples, targets, warmup=3):
         """Record forward + backward + optimizer of ``step`` once (static shapes) and return a ``GraphedStep`` whose
         ``replay(samples, targets)`` re-launches it with one host call: the ~3000 kernel launches of a ViT-H step
-        cost the host nothing any more.  Data parallel (``own_reducer``): the bucket all-reduces are recorded into the same
+        cost the host nothing any more.  ``accum_steps`` = k: the k forward / backward passes over the chunks of the static batch
+        and the one optimizer step are ONE graph.  Data parallel (``own_reducer``): the bucket all-reduces are recorded into the same
         graph on the process group's stream (fork at the event of the bucket's last write, join in front of the optimizer),
         so every rank replays ONE graph per step and the collectives overlap the backward kernels exactly as captured.  Everything the step needs is already device-side: the bias-correction step
         and the non-finite-gradient guard live in the optimizer kernels, the drop-path masks come from the device
@@ -1134,8 +1171,6 @@ class Trainer:
         if self.model is not self.raw_model:
             raise RuntimeError("Trainer.capture: DistributedDataParallel / segmented steps are not captured as one graph "
                                "(own_reducer=True, or segment_graphs=n + capture_segments)")
-        if self.accum_steps != 1:
-            raise RuntimeError("Trainer.capture: accum_steps > 1 is not captured")
         from . import d8_layers as _L
         if _L.COMPACT_DROP_PATH:
             raise RuntimeError("Trainer.capture: d8_layers.COMPACT_DROP_PATH launches every branch on the samples its mask "
@@ -1155,12 +1190,15 @@ class Trainer:
         # capture runs: thread-local error mode, as torch documents for whole-network capture with NCCL
         mode = {"capture_error_mode": "thread_local"} if self._reducer is not None else {}
         with torch.cuda.graph(graph, **mode):
-            loss = self._forward_loss(sx, sy)
-            if self._reducer is not None:
-                self._reduced_backward(loss)
+            if self.accum_steps > 1:
+                loss = self._accumulate(sx, sy)           # (k forward / backward passes over the chunks of the static batch)
             else:
-                with self._batched_finishes():
-                    loss.backward()
+                loss = self._forward_loss(sx, sy)
+                if self._reducer is not None:
+                    self._reduced_backward(loss)
+                else:
+                    with self._batched_finishes():
+                        loss.backward()
             self.optimizer.step()
         return GraphedStep(self, graph, sx, sy, loss.detach())
 

@@ -108,7 +108,7 @@ def _accum_batch():
     return x, y
 
 
-def _accum_worker(rank, world, port, out, flat_numel=None):
+def _accum_worker(rank, world, port, out, flat_numel=None, own=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from octic_vits_amd import train as TR
@@ -126,8 +126,10 @@ def _accum_worker(rank, world, port, out, flat_numel=None):
                 for p in net.parameters():
                     p.add_(0.37)
     tr = Trainer(net, distributed=True, fused_optimizer=False, tuned_gemms=False, autocast=False, accum_steps=2,
-                 ema_decay=None, device_type="cpu", bucket_cap_mb=1)
-    if flat_numel is not None:
+                 ema_decay=None, device_type="cpu", bucket_cap_mb=0.004 if own else 1, own_reducer=own)
+    if own:
+        assert tr._reducer is not None and tr.model is tr.raw_model and len(tr._reducer.buckets) >= 2
+    elif flat_numel is not None:
         assert 0 < len(tr._small) < sum(1 for p in net.parameters() if p.requires_grad)
     for _ in range(3):
         tr.step(x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per])
@@ -276,6 +278,24 @@ def test_own_reducer_destination_protocol():
     finally:
         if made:
             dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_own_reducer_with_accumulation_matches_single_process(tmp_path):
+    """configs[2]'s shape in miniature through train.GradReducer: 2 ranks x 2 accumulated micro-batches x 2 samples, rank 1
+    starting from other values: the first micro-batch lands in the buckets, the second adds to them in place, ONE round of
+    collectives follows - equal to one process on all 8 samples."""
+    out = str(tmp_path / "own_accum.pt")
+    mp.spawn(_accum_worker, args=(2, _free_port(), out, 64, True), nprocs=2, join=True)
+    got = torch.load(out)
+    from octic_vits_amd.train import Trainer
+    x, y = _accum_batch()
+    tr = Trainer(_Net(), distributed=False, fused_optimizer=False, tuned_gemms=False, autocast=False, accum_steps=1,
+                 ema_decay=None, device_type="cpu")
+    for _ in range(3):
+        tr.step(x, y)
+    single = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
+    assert torch.allclose(got, single, rtol=1e-4, atol=1e-5), float((got - single).abs().max())
 
 
 def test_bench_spawns_its_own_ranks_when_launched_bare(monkeypatch, capsys):

@@ -434,6 +434,65 @@ def test_captured_data_parallel_step_on_a_one_rank_rccl_group():
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
+def test_captured_accumulated_step_also_under_the_own_reducer():
+    """accum_steps = 2 (BASELINE configs[2]'s shape in miniature): the two forward / backward passes and the optimizer step as
+    ONE hipGraph, without and with train.GradReducer on a one-rank RCCL group (first micro-batch written into the buckets, the
+    second added in place, the collectives after it) - all bitwise equal to the eager accumulated step of the plain trainer."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from octic_vits_amd import train as TR
+    from octic_vits_amd.train import Trainer, synthetic_batch
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    old = TR.DDP_FLAT_SMALL_NUMEL
+    TR.DDP_FLAT_SMALL_NUMEL = 20_000
+    try:
+        from octic_vits_amd.d8_layers import Layer_scale_init_BlockD8
+        from octic_vits_amd.model import OcticVisionTransformer
+        from octic_vits_amd.vit import Layer_scale_init_Block
+
+        def make():
+            torch.manual_seed(5)
+            return OcticVisionTransformer(img_size=56, patch_size=14, num_classes=100, embed_dim=256, depth=4, num_heads=4,
+                                          qkv_bias=True, drop_path_rate=0.0, octic_block_layers=Layer_scale_init_BlockD8,
+                                          standard_block_layers=Layer_scale_init_Block).cuda()
+        ma, mb, mc = make(), make(), make()
+        ta = Trainer(ma, lr=1e-3, accum_steps=2)
+        tb = Trainer(mb, lr=1e-3, accum_steps=2)
+        tc = Trainer(mc, lr=1e-3, accum_steps=2, distributed=True, local_rank=0, bucket_cap_mb=1)
+        assert tc._reducer is not None and tc.model is mc
+        batches = [synthetic_batch(8, 100, "cuda", seed=s, img_size=56) for s in range(4)]
+        gb = tb.capture(*batches[0], warmup=2)
+        gc = tc.capture(*batches[0], warmup=2)
+        for _ in range(2):
+            ta.step(*batches[0])
+        la, lb, lc = [], [], []
+        for x, y in batches[1:] + batches[1:]:
+            la.append(float(ta.step(x, y).detach()))
+            lb.append(float(gb.replay(x, y)))
+            lc.append(float(gc.replay(x, y)))
+        assert la == lb == lc, (la, lb, lc)
+        for (n, pa), pb, pc in zip(ma.named_parameters(), mb.parameters(), mc.parameters()):
+            assert torch.equal(pa, pb) and torch.equal(pa, pc), n
+        # and the accumulated step equals the one-micro-batch step on the whole batch up to f32 summation order
+        md = make()
+        td = Trainer(md, lr=1e-3)
+        for _ in range(2):
+            td.step(*batches[0])
+        ld = [float(td.step(x, y).detach()) for x, y in batches[1:] + batches[1:]]
+        assert la == pytest.approx(ld, rel=2e-2)
+    finally:
+        TR.DDP_FLAT_SMALL_NUMEL = old
+        dist.destroy_process_group()
+
+
 def test_captured_step_draws_fresh_drop_path_masks():
     """The drop-path masks come from the device generator: replays of one graph must not repeat the captured draw."""
     from octic_vits_amd.model import OcticVisionTransformer
