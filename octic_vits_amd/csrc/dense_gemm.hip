@@ -935,7 +935,7 @@ inline int dense_cls_waves(int K) {
 // Per-image panels (see the file header): taken when the batch is whole images of 256 q + 1 tokens with q = 1 (ViT-H/14's 257),
 // the class-token kernel takes the shape (K % 128 == 0, N % 16 == 0, no fused residual tail) and the launch model says so:
 // the panels' plan + ~4 K-tile units for the class-token launch against the classic plan.
-// OCTIC_ROUTE_DENSE_IMAGE: 0 = by the model, 1 = always where legal, 2 = never.
+// OCTIC_ROUTE_DENSE_IMAGE: 0 = by the model, 1 = always where legal, 2 = never, 3 = by the model for plain launches only (A/B).
 struct DgTokPlan { DgPlan p; bool image; int images; };
 // What the class-token launch costs, in the plan's unit (one K-tile of the 256-wide tile, ~1.54 us): measured on MI355X at
 // B = 64 (rocprofv3, round 6): 7.0 us for N = K = 1280, 11.4 (N 3840), 13.7-16.2 (N 5120), 16.2 (K 3840), 21.1 us (K 5120) -
@@ -956,8 +956,11 @@ inline DgTokPlan dense_plan_tokens(int M, int N, int K, int cus, int mode, int t
   const DgPlan pi = dense_plan(B * DG_BM, N, K, cus, mode);
   // (modes 3 / 5 - the fc2 input gradient with its column sums - measured no shorter on per-image panels: 221.2 against
   // 221.8 us at ViT-H; their class-token launch would be a pure loss)
-  const bool pays = mode != DG_DGELU && mode != DG_DFACT && pi.cost + dense_cls_cost(B, N, K) + 1.0 < t.p.cost;
-  if (force == 1 || (force == 0 && pays)) {
+  // (fc1 with its GELU tails: the panels save 20 us, the class-token launch costs 14-16 - and in the step the pair measured
+  // 0.13 ms per step SLOWER than leaving fc1 on classic panels (A/B/C of alternating processes, round 6): the margin keeps it out)
+  const double margin = 1.0;
+  const bool pays = mode != DG_DGELU && mode != DG_DFACT && pi.cost + dense_cls_cost(B, N, K) + margin < t.p.cost;
+  if (force == 1 || (force == 0 && pays) || (force == 3 && pays && mode == DG_PLAIN)) {
     t.p = pi;
     t.image = true;
     t.images = B;
