@@ -127,37 +127,12 @@ def step_variants(trainer, model, samples, targets, args, n=8):
         if made:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29541")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", rank=0, world_size=1)     # a one-rank RCCL group: real collectives, trivial peers
+            dist.init_process_group("gloo", rank=0, world_size=1)
         try:
             bkw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
-            # The N > 1 step as bench.py --gpus N runs it (train.GradReducer: gradients written into flat buckets, one RCCL
-            # all-reduce per bucket on the group's stream as it fills), eagerly and captured as ONE hipGraph with the
-            # collectives inside - on a one-rank group every collective is a local pass over the bucket
-            try:
-                tg = Trainer(model, distributed=True, local_rank=samples.device.index or 0, **bkw)
-                ms, host = timed(tg)
-                out["ddp_eager_ms_per_step"], out["ddp_eager_host_issue_ms_per_step"] = round(ms, 3), round(host, 2)
-                out["ddp_buckets"] = len(tg._reducer.buckets) + 1
-                out["ddp_buckets_reduced_during_backward"] = tg._reducer.early
-                g = tg.capture(samples, targets, warmup=1)
-                for _ in range(2):
-                    g.replay()
-                torch.cuda.synchronize()
-                w0 = tg._watch.wait_s
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    g.replay(samples, targets)
-                issued = time.perf_counter() - t0 - (tg._watch.wait_s - w0)
-                torch.cuda.synchronize()
-                out["ddp_graph_ms_per_step"] = round((time.perf_counter() - t0) / n * 1e3, 3)
-                out["ddp_graph_host_issue_ms_per_step"] = round(issued / n * 1e3, 2)
-                del g, tg
-            except Exception as e:
-                out["ddp_graph_error"] = f"{type(e).__name__}: {e}"[:300]
             for key, copies in (("ddp_hooks_ms_per_step", 0), ("ddp_proxy_ms_per_step", 2)):
                 proxy = DdpTrafficProxy(samples.device, copies=copies, halve=args.bf16_buckets)
-                tp = Trainer(model, distributed=True, local_rank=samples.device.index or 0, ddp_proxy=proxy, **bkw)
+                tp = Trainer(model, distributed=True, local_rank=samples.device.index or 0, ddp_proxy=proxy, own_reducer=False, **bkw)
                 ms, host = timed(tp)
                 out[key] = round(ms, 3)
                 if copies:
@@ -192,6 +167,40 @@ def _baseline_metric():
 
 
 METRIC = _baseline_metric()
+
+
+def ddp_side_figure(args):
+    """The N > 1 step as `bench.py --gpus N` runs it, on ONE GPU with a one-rank RCCL group, in a CHILD process (an RCCL problem
+    there cannot cost this line its `value`): `bench.py --force-ddp` - eager steps of train.GradReducer first, then the step
+    captured as one hipGraph with the collectives inside."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, os.path.join(here, "bench.py"), "--force-ddp", "--steps", "8", "--warmup", "3", "--no-cpu-baseline",
+           "--no-forward-only", "--no-ssl-side", "--no-step-variants", "--no-kernel-timing", "--batch", str(args.batch),
+           "--model", args.model]
+    if args.bucket_mb is not None:
+        cmd += ["--bucket-mb", str(args.bucket_mb)]
+    try:
+        env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300))
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=here, env=env)
+        lines = [ln for ln in (r.stdout or "").strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"ddp_graph_error": ((r.stderr or "no output").strip().splitlines() or ["?"])[-1][:300]}
+        d = json.loads(lines[-1])
+        out = {"ddp_launch": d["config"]["launch"], "ddp_gradient_reduction": d["config"].get("gradient_reduction"),
+               "ddp_note": "side figures, never `value`: child process `bench.py --force-ddp` (one-rank RCCL group on this GPU: every "
+                           "collective is RCCL's one-rank AVG kernel over the bucket)"}
+        if "hipGraph" in d["config"]["launch"]:
+            out["ddp_graph_ms_per_step"], out["ddp_graph_host_issue_ms_per_step"] = d["ms_per_step"], d["host_issue_ms_per_step"]
+            out["ddp_eager_ms_per_step"] = d.get("eager_reducer_ms_per_step")
+            out["ddp_eager_host_issue_ms_per_step"] = d.get("eager_reducer_host_issue_ms_per_step")
+        else:
+            out["ddp_eager_ms_per_step"], out["ddp_eager_host_issue_ms_per_step"] = d["ms_per_step"], d["host_issue_ms_per_step"]
+        return out
+    except Exception as e:
+        return {"ddp_graph_error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def ssl_side_figure():
@@ -394,19 +403,92 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             log("first warm-up step done")
+    def timed_region(step_fn):
+        """`steps` full iterations between barrier + synchronize, a new batch every step as a loader would deliver it (a graph's
+        static input buffers are refilled by a device-to-device copy - 38.5 MB of images + targets - that is part of the step);
+        no host read of the loss inside (train._LossWatch checks two steps late on a pinned copy).  -> (seconds: max over the
+        ranks, host seconds spent ENQUEUEING - the loop's wall time minus the loss watch's waits -, last loss)."""
+        sync()
+        w0 = trainer._watch.wait_s
+        t0 = time.perf_counter()
+        loss_ = None
+        for i in range(args.steps):
+            bx, by = batches[i % len(batches)]
+            loss_ = step_fn(bx, by).detach()       # (never hold an iteration's autograd graph: see train.Trainer.step)
+        issued_ = time.perf_counter() - t0 - (trainer._watch.wait_s - w0)
+        sync()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), issued_, loss_
+
+    def core_line(elapsed_, issued_, loss_, launch):
+        ms_ = elapsed_ / args.steps * 1e3
+        ips_ = world * args.batch * args.accum * args.steps / elapsed_
+        n_oct_ = model.octic_equi_break_layer
+        n_std_ = len(model.blocks) - n_oct_
+        return {
+            "metric": METRIC, "value": round(ips_, 2),
+            "unit": "images/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (randn images, multi-hot targets; random-init weights)",
+            "config": {"workload": f"{args.model} ({n_oct_} octic + {n_std_} standard blocks"
+                                   f"{', invariant hand-off' if getattr(model, 'invariant', False) else ''}, drop_path 0.5) "
+                                   "DeiT-III train step: "
+                                   f"bf16-autocast fwd + bwd + LAMB + EMA, 224x224, batch {args.batch}/GPU "
+                                   + (f"x {args.accum} accumulated micro-batches (BASELINE configs[2] shape), "
+                                      if args.accum > 1 else "(BASELINE configs[1]), ")
+                                   + f"data parallel over {world} GPU(s)",
+                       "global_batch": world * args.batch * args.accum, "per_gpu_batch": args.batch,
+                       "accum_steps": args.accum, "parallelism": f"dp{world}",
+                       "library_gemm_table": bool(trainer.tuned_gemms),
+                       "gradient_reduction": (None if not ddp else
+                                              f"train.GradReducer: {len(trainer._reducer.buckets) + 1} flat f32 buckets, one RCCL "
+                                              f"all-reduce (AVG) each, {trainer._reducer.early} issued during the backward pass"
+                                              if trainer._reducer is not None else "torch DistributedDataParallel bucket hooks"),
+                       "launch": launch},
+            "loss": float(loss_.item()), "host_issue_ms_per_step": round(issued_ / args.steps * 1e3, 2),
+            # (FLOP_PER_IMG_STEP is the ViT-H/14 count of SURVEY 8d: other --model choices are development figures)
+            "step_mfma_frac": round(ips_ * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4) if "huge_patch14" in args.model else None,
+        }
+
+    # Data parallel with the captured step (the default at N > 1): the collectives inside a hipGraph have never run on more than
+    # one GPU of this pool (no multi-GPU node in six rounds), so the SAFE measurement comes first - `steps` eager steps of the same
+    # reducer - and the captured one runs under a watchdog: if capture + replays do not finish within OCTIC_BENCH_WATCHDOG_S
+    # (default 240 s), rank 0 prints the eager line and every rank leaves.  A line is produced either way.
+    eager_dp = None
+    watchdog = None
+    if ddp and own and one_graph and not nseg and (world > 1 or args.force_ddp):
+        eager_dp = timed_region(trainer.step)
+        log(f"eager data-parallel steps: {eager_dp[0] / args.steps * 1e3:.2f} ms per step; now the captured step")
+        import threading
+        fallback = core_line(eager_dp[0], eager_dp[1], eager_dp[2],
+                             "eager (the captured data-parallel step did not finish in time: watchdog)") if rank == 0 else None
+
+        def _bail():
+            log("WATCHDOG: the captured data-parallel step did not finish; reporting the eager steps measured before it")
+            if rank == 0:
+                print(json.dumps(fallback), file=real_stdout, flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("OCTIC_BENCH_WATCHDOG_S", "240")), _bail)
+        watchdog.daemon = True
+        watchdog.start()
     graphed = None
     if one_graph and not nseg:
         try:
             graphed = trainer.capture(samples, targets, warmup=1)
             for _ in range(2):
                 graphed.replay()
+            if os.environ.get("OCTIC_BENCH_FAKE_HANG") and watchdog is not None:     # developer: exercise the watchdog
+                time.sleep(1e6)
             # torch.cuda.graph() empties the caching allocator before it captures: one more eager step here lets the
             # eager kernel-timing steps of the timed region reuse cached blocks instead of calling hipMalloc
             if not args.no_kernel_timing:
                 trainer.step(samples, targets)
             torch.cuda.synchronize()
         except Exception as e:      # a failed capture can leave the stream unusable: measure eagerly in a fresh child
-            if world > 1:
+            if ddp:
                 # (every rank runs the same capture: it fails on all of them or on none; the ranks cannot be re-started from
                 # here, so the eager data-parallel step carries on in this process)
                 log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager data-parallel steps")
@@ -414,29 +496,20 @@ def main():
                 torch.cuda.synchronize()
             else:
                 log(f"graph capture failed ({type(e).__name__}: {e}); re-running eagerly in a child process")
-            import subprocess
-            real_stdout.flush()     # fd 1 is stderr in this process (see above): hand the child the real stdout for its line
-            if world == 1:
+                import subprocess
+                real_stdout.flush()     # fd 1 is stderr in this process (see above): hand the child the real stdout for its line
                 raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"],
                                                 stdout=real_stdout).returncode)
-    sync()
     log("warm-up done, timing")
-    # The timed region is `steps` full iterations and nothing else: graph replays at one GPU (eager DDP steps otherwise),
-    # no host read of the loss inside it (train._LossWatch checks two steps late on a pinned copy).  The per-kernel HIP
-    # events (~1800 records per step, which slow a step by ~20 %) are taken AFTER it, in the same process on the same
-    # weights: see `step_breakdown.note`.
-    w0 = trainer._watch.wait_s
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # a new batch every step, as a loader would deliver it: the graph's static input buffers are refilled by a
-        # device-to-device copy (38.5 MB of images + targets) that is part of the timed step
-        bx, by = batches[i % len(batches)]
-        loss = graphed.replay(bx, by) if graphed is not None else trainer.step(bx, by)
-    # host time to ENQUEUE the steps: wall time of the loop minus the time the loss watch spent waiting for the event of
-    # the step two back (that wait only keeps the host from running more than two steps ahead).  Host-bound if ~ elapsed.
-    issued = time.perf_counter() - t0 - (trainer._watch.wait_s - w0)
-    sync()
-    elapsed = time.perf_counter() - t0
+    # The timed region is `steps` full iterations and nothing else: graph replays (eager steps where nothing was captured).  The
+    # per-kernel HIP events (~1800 records per step, which stretch a step by ~20 %) are taken AFTER it, in the same process on
+    # the same weights: see `step_breakdown.note`.
+    if graphed is None and eager_dp is not None:
+        elapsed, issued, loss = eager_dp            # (already measured; the capture failed)
+    else:
+        elapsed, issued, loss = timed_region(graphed.replay if graphed is not None else trainer.step)
+    if watchdog is not None:
+        watchdog.cancel()
     sampled = []
     if not args.no_kernel_timing:
         ops.KERNEL_TIMER.enable()
@@ -446,10 +519,6 @@ def main():
         sync()
         ops.KERNEL_TIMER.disable()
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
     ms = elapsed / args.steps * 1e3
     ips = world * args.batch * args.accum * args.steps / elapsed
 
@@ -495,36 +564,14 @@ def main():
     if world > 1:
         dist.barrier()
 
-    n_oct = model.octic_equi_break_layer
-    n_std = len(model.blocks) - n_oct
     if rank == 0:
-        line = {
-            "metric": METRIC, "value": round(ips, 2),
-            "unit": "images/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (randn images, multi-hot targets; random-init weights)",
-            "config": {"workload": f"{args.model} ({n_oct} octic + {n_std} standard blocks"
-                                   f"{', invariant hand-off' if getattr(model, 'invariant', False) else ''}, drop_path 0.5) "
-                                   "DeiT-III train step: "
-                                   f"bf16-autocast fwd + bwd + LAMB + EMA, 224x224, batch {args.batch}/GPU "
-                                   + (f"x {args.accum} accumulated micro-batches (BASELINE configs[2] shape), "
-                                      if args.accum > 1 else "(BASELINE configs[1]), ")
-                                   + f"data parallel over {world} GPU(s)",
-                       "global_batch": world * args.batch * args.accum, "per_gpu_batch": args.batch,
-                       "accum_steps": args.accum, "parallelism": f"dp{world}",
-                       "library_gemm_table": bool(trainer.tuned_gemms),
-                       "gradient_reduction": (None if not ddp else
-                                              f"train.GradReducer: {len(trainer._reducer.buckets) + 1} flat f32 buckets, one RCCL "
-                                              f"all-reduce (AVG) each, {trainer._reducer.early} issued during the backward pass"
-                                              if trainer._reducer is not None else "torch DistributedDataParallel bucket hooks"),
-                       "launch": ("hipGraph replay (whole step" + (", RCCL all-reduces inside)" if ddp else ")"))
-                                 if graphed is not None else
-                                 (f"{len(trainer.segmented._segments)} x 2 segment hipGraphs + eager loss / all-reduce hooks / optimizer"
-                                  if nseg else "eager")},
-            "loss": float(loss.item()), "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2),
-            # (FLOP_PER_IMG_STEP is the ViT-H/14 count of SURVEY 8d: other --model choices are development figures)
-            "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / (world * MFMA_PEAK_BF16), 4) if "huge_patch14" in args.model else None,
-        }
+        line = core_line(elapsed, issued, loss,
+                         ("hipGraph replay (whole step" + (", RCCL all-reduces inside)" if ddp else ")")) if graphed is not None else
+                         (f"{len(trainer.segmented._segments)} x 2 segment hipGraphs + eager loss / all-reduce hooks / optimizer"
+                          if nseg else "eager"))
+        if eager_dp is not None and graphed is not None:
+            line["eager_reducer_ms_per_step"] = round(eager_dp[0] / args.steps * 1e3, 3)
+            line["eager_reducer_host_issue_ms_per_step"] = round(eager_dp[1] / args.steps * 1e3, 2)
         kern = ops.KERNEL_TIMER.summary()
         if kern:
             traffic_db = {}
@@ -652,6 +699,8 @@ def main():
                 line.update(step_variants(trainer, model, samples, targets, args))
             except Exception as e:                    # side figures only: the line and its `value` are complete without them
                 line["step_variants_error"] = f"{type(e).__name__}: {e}"[:300]
+        if world == 1 and not ddp and not args.no_step_variants:
+            line.update(ddp_side_figure(args))
         if world == 1 and not args.no_ssl_side and not args.no_step_variants:
             line.update(ssl_side_figure())
         if world == 1 and not args.no_cpu_baseline:

@@ -692,6 +692,8 @@ class GradReducer:
         self.big = big
         self._misc = self._misc_views = self._misc_key = None
         self._works, self._fired, self._seen = [], set(), set()
+        self._captured_works = []
+        self.capturing = False                          # set by Trainer.capture around the captured pass
         self.active = False
         self._hold = False
         self.early = 0                                  # buckets of the last pass whose collective was issued before its end
@@ -725,6 +727,14 @@ class GradReducer:
 
     def _fire(self, k):
         if k in self._fired:
+            return
+        if self.capturing and not torch.cuda.is_current_stream_capturing():
+            # Inside Trainer.capture, on a thread / stream that is not (yet) part of the capture - autograd runs a node on the
+            # stream it was created on, and an AccumulateGrad node kept alive from an eager iteration is bound to the eager
+            # stream.  A collective issued from here would count as an EAGER one (its work object goes to the process group's
+            # watchdog thread) while the group's stream is capturing: the watchdog's poll of its end event then fails with
+            # hipErrorCapturedEvent and terminates the process (seen once in ~30 captured runs, round 6).  Leave the bucket to
+            # reduce_all(), which runs on the capturing stream.
             return
         self._fired.add(k)
         flat = self.buckets[k][0] if k >= 0 else self._misc
@@ -800,8 +810,17 @@ class GradReducer:
             self._fire(k)
         if self._misc_live:
             self._fire(-1)
+        if len(self._fired) != len(self.buckets) + (1 if self._misc_live else 0):
+            raise RuntimeError("GradReducer.reduce_all: called inside Trainer.capture from a stream that is not capturing")
         for w in self._works:
             w.wait()
+        if self._works and self._works[0] is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # Work objects made under capture are kept for the life of this reducer.  Dropping them returns their HIP events
+            # to ProcessGroupNCCL's event cache; the next EAGER collective re-records such an event, the group's watchdog
+            # thread polls it - and HIP still answers "operation not permitted on an event last recorded in a capturing
+            # stream" (hipErrorCapturedEvent), which terminates the process from the watchdog thread.  Seen once in ~30
+            # captured runs in round 6, only in flows with eager steps after a capture.
+            self._captured_works.extend(self._works)
         self._works = []
 
     def finish(self):
@@ -1152,7 +1171,11 @@ class Trainer:
         if self.ema is not None:
             self.ema.update(self.raw_model)
         self._watch.push(loss)
-        return loss
+        # DETACHED: a caller that keeps the returned loss must not keep this iteration's autograd graph - and with it the
+        # AccumulateGrad nodes bound to this iteration's stream - alive: a later Trainer.capture on another stream then re-uses
+        # those nodes across streams ("AccumulateGrad node's stream does not match") and hipGraphInstantiate crashed (round 6:
+        # bench.py held the last loss of its eager data-parallel measurement while capturing)
+        return loss.detach()
 
     # ---- the whole iteration as one hipGraph -----------------------------------------------------------------------
     def capture(self, samples, targets, warmup=3):
@@ -1189,6 +1212,16 @@ class Trainer:
         # with collectives inside, other threads (the process group's watchdog polling its events) must stay legal while the
         # capture runs: thread-local error mode, as torch documents for whole-network capture with NCCL
         mode = {"capture_error_mode": "thread_local"} if self._reducer is not None else {}
+        if self._reducer is not None:
+            self._reducer.capturing = True
+        try:
+            loss = self._capture_body(graph, mode, sx, sy)
+        finally:
+            if self._reducer is not None:
+                self._reducer.capturing = False
+        return GraphedStep(self, graph, sx, sy, loss.detach())
+
+    def _capture_body(self, graph, mode, sx, sy):
         with torch.cuda.graph(graph, **mode):
             if self.accum_steps > 1:
                 loss = self._accumulate(sx, sy)           # (k forward / backward passes over the chunks of the static batch)
@@ -1200,7 +1233,7 @@ class Trainer:
                     with self._batched_finishes():
                         loss.backward()
             self.optimizer.step()
-        return GraphedStep(self, graph, sx, sy, loss.detach())
+        return loss
 
 
 BATCHED_FINISHES = True    # `bench.py --no-batched-finishes` for the A/B
@@ -1269,6 +1302,9 @@ def init_distributed(force=False):
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # no re-use of HIP events between collectives (see GradReducer.reduce_all: an event once recorded under capture stays
+        # "captured" for hipEventQuery on this stack)
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
