@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 6: the bench flows of the data-parallel step on a one-rank RCCL group (captured step x3, the watchdog via OCTIC_BENCH_FAKE_HANG, the default line with its child-process side figures)
 set -u
 O=gpurun_out; mkdir -p $O
 timeout 900 python -m pytest tests/test_train_gpu.py -x -q -k "captured_data_parallel or captured_accumulated or ddp_wrapped" 2>&1 | tail -3
