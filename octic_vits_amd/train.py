@@ -728,7 +728,7 @@ class GradReducer:
     def _fire(self, k):
         if k in self._fired:
             return
-        if self.capturing and not torch.cuda.is_current_stream_capturing():
+        if self.capturing and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             # Inside Trainer.capture, on a thread / stream that is not (yet) part of the capture - autograd runs a node on the
             # stream it was created on, and an AccumulateGrad node kept alive from an eager iteration is bound to the eager
             # stream.  A collective issued from here would count as an EAGER one (its work object goes to the process group's

@@ -298,6 +298,87 @@ def test_own_reducer_with_accumulation_matches_single_process(tmp_path):
     assert torch.allclose(got, single, rtol=1e-4, atol=1e-5), float((got - single).abs().max())
 
 
+def test_own_reducer_edge_cases():
+    """train.GradReducer on one rank: (a) a bucket member that takes no part in a pass contributes zeros and still gets a
+    gradient view; (b) backward() raising leaves ops.GRAD_DEST as it was and the reducer usable for the next pass; (c) with
+    hold=True (gradient accumulation) nothing is reduced before reduce_all, announcements included; (d) inside a capture-marked
+    pass a collective is never issued from a non-capturing context (CPU: no stream is ever capturing), and reduce_all then
+    refuses instead of leaving gradients unreduced."""
+    from octic_vits_amd import ops
+    from octic_vits_amd.train import GradReducer
+    made = not dist.is_initialized()
+    if made:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        torch.manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(30, 30)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(40, 20))]
+        r = GradReducer(ps, bucket_mb=1000 * 4 / (1 << 20), small_numel=10)
+        assert len(r.buckets) == 2
+        # (a)
+        r.begin()
+        (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
+        r.finish()
+        assert torch.equal(ps[2].grad, torch.zeros_like(ps[2])) and torch.equal(ps[0].grad, torch.full_like(ps[0], 2.0))
+        assert ps[2].grad.data_ptr() == r.buckets[0][0].data_ptr()
+        # (b)
+        for p in ps:
+            p.grad = None
+
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x.sum()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise ValueError("boom")
+        r.begin()
+        with pytest.raises(ValueError):
+            try:
+                Boom.apply(ps[0]).backward()
+            except BaseException:
+                r.abort()
+                raise
+        assert ops.GRAD_DEST is None and not r.active
+        for p in ps:
+            p.grad = None
+        r.begin()
+        sum(p.sum() for p in ps).backward()
+        r.finish()
+        assert all(torch.equal(p.grad, torch.ones_like(p)) for p in ps)
+        # (c)
+        for p in ps:
+            p.grad = None
+        r.begin(hold=True)
+        d = ops.grad_dest(ps[2], ps[2].shape)
+        assert d is not None
+        ops.grad_written(ps[2])
+        assert not r._fired
+        sum(p.sum() for p in ps).backward()
+        r.settle()
+        assert not r._fired and ps[0].grad.data_ptr() == r.buckets[1][0].data_ptr()
+        sum(p.sum() for p in ps).backward()                  # second micro-batch: added in place
+        r.reduce_all()
+        assert all(torch.equal(p.grad, torch.full_like(p, 2.0)) for p in ps)
+        # (d)
+        for p in ps:
+            p.grad = None
+        r.capturing = True
+        try:
+            r.begin()
+            sum(p.sum() for p in ps).backward()
+            r.settle()
+            with pytest.raises(RuntimeError, match="not capturing"):
+                r.reduce_all()
+            assert not r._fired
+        finally:
+            r.capturing = False
+            r.abort()
+    finally:
+        if made:
+            dist.destroy_process_group()
+
+
 def test_bench_spawns_its_own_ranks_when_launched_bare(monkeypatch, capsys):
     """`python bench.py --gpus N` with no WORLD_SIZE must start N ranks itself (fresh children, before any GPU call) and
     pass the exit code through; here the child launcher is intercepted."""
