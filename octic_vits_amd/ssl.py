@@ -538,11 +538,15 @@ class SSLTrainer:
     autocast student, ssl_default_config.yaml:25-31) -> clip_grad_norm_(3.0) per sub-model -> AdamW -> teacher EMA."""
 
     def __init__(self, arch: SSLMetaArch, lr=1e-3, weight_decay=0.04, betas=(0.9, 0.999), clip_grad=3.0, autocast=True,
-                 distributed=False, local_rank=0, fused_optimizer=None):
+                 distributed=False, local_rank=0, fused_optimizer=None, own_reducer=True):
         """fused_optimizer (default: on the GPU): clip_grad_norm_ per sub-model, AdamW and the teacher's EMA as the fused
         multi-tensor HIP step (train.FusedLamb(adam=True) = octic_adamw_step: two streaming passes per sub-model that also
         leave the bf16 weight copies of the standard half and the prepared LinearD8 weights behind) instead of ~60 foreach
-        launches + two more passes over the teacher; False: torch.optim.AdamW + foreach EMA, as the reference runs it."""
+        launches + two more passes over the teacher; False: torch.optim.AdamW + foreach EMA, as the reference runs it.
+        own_reducer (distributed only, round 6): average every student gradient (backbone and heads) with train.GradReducer
+        instead of a DistributedDataParallel wrapper around the backbone + a flat all-reduce for the rest - no autograd hooks,
+        so the step keeps its batched finishes and paired weight gradients at N > 1; a pass that uses its modules more than once
+        (the set-by-set crop loop) reduces everything after the backward pass."""
         self.arch, self.clip_grad, self.autocast = arch, clip_grad, autocast
         self.device_type = next(arch.parameters()).device.type
         self.lr, self.weight_decay, self.betas = lr, weight_decay, betas
@@ -554,7 +558,15 @@ class SSLTrainer:
             self.optimizer = torch.optim.AdamW(arch.get_params_groups(weight_decay), lr=lr, betas=betas)
             from .functional import track_optimizer
             track_optimizer(arch.student, self.optimizer)         # AdamW's foreach path updates parameters in place
-        if distributed:
+        self._reducer = None
+        self._ddp, self._head_params = None, []
+        if distributed and own_reducer:
+            from .train import GradReducer
+            ps = [p for p in arch.student.parameters() if p.requires_grad]
+            if all(p.dtype == torch.float32 for p in ps):
+                self._reducer = GradReducer(ps)
+                self._reducer.broadcast(list(arch.student.parameters()) + list(arch.student.buffers()))
+        if distributed and self._reducer is None:
             class _Fwd(nn.Module):
                 def __init__(s, a):
                     super().__init__()
@@ -574,8 +586,6 @@ class SSLTrainer:
                 fwd, device_ids=[local_rank] if self.device_type == "cuda" else None, bucket_cap_mb=128,
                 gradient_as_bucket_view=True)
             arch._student_call = lambda g, l, m: tuple(self._ddp(g, l, m))
-        else:
-            self._ddp, self._head_params = None, []
 
     def step(self, images, teacher_temp=0.07, momentum=0.992):
         self.arch.train()
@@ -584,11 +594,23 @@ class SSLTrainer:
         else:
             for p in self.arch.student.parameters():
                 p.grad = None
-        if self.autocast:
-            with torch.autocast(self.device_type, dtype=torch.bfloat16):
+        if self._reducer is not None:
+            # gradients land in the reducer's buckets; buckets go out as they fill only when every module is used once in the
+            # pass (a second use ADDS to a gradient that an early collective would already have taken)
+            bb = self.arch.student["backbone"] if "backbone" in self.arch.student else None
+            self._reducer.begin(hold=not getattr(bb, "_single_use_pass", False))
+        try:
+            if self.autocast:
+                with torch.autocast(self.device_type, dtype=torch.bfloat16):
+                    loss_dict = self.arch.forward_backward(images, teacher_temp, backward_scope=self._finish_scope)
+            else:
                 loss_dict = self.arch.forward_backward(images, teacher_temp, backward_scope=self._finish_scope)
-        else:
-            loss_dict = self.arch.forward_backward(images, teacher_temp, backward_scope=self._finish_scope)
+        except BaseException:
+            if self._reducer is not None:
+                self._reducer.abort()
+            raise
+        if self._reducer is not None:
+            self._reducer.finish()
         if self._ddp is not None and _world() > 1:                # the heads (outside the DDP wrapper) + the backbone's small tensors
             self._flat_reducer.reduce()
         if self.fused:

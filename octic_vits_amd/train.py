@@ -781,7 +781,10 @@ class GradReducer:
             for p, v in pv:
                 g = p.grad
                 if g is None:
-                    v.zero_()                           # (a parameter that took no part in this pass contributes zeros)
+                    # a parameter that took no part in this pass: its slot carries zeros through the collective (the same on
+                    # every rank) and its .grad STAYS None - optimizers skip such tensors (no weight decay on them either)
+                    v.zero_()
+                    continue
                 elif g.data_ptr() != v.data_ptr():
                     if k in self._fired:
                         raise RuntimeError("GradReducer: a bucket was reduced before one of its gradients was written")

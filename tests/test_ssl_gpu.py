@@ -509,3 +509,51 @@ def test_ssl_step_hybrid_vit_huge_multicrop():
     bad.sort(reverse=True)
     assert len(g_ref) > 30
     assert not bad, "; ".join(f"{n}: {r:.4f}" for _, n, r in bad[:8])
+
+
+def test_ssl_trainer_with_the_own_reducer_on_a_one_rank_rccl_group_equals_the_plain_trainer():
+    """Round 6: SSLTrainer(distributed=True) averages every student gradient with train.GradReducer (no DistributedDataParallel
+    wrapper): on a one-rank RCCL group, on a backbone whose crop sets run as one row tensor (every module used once: the buckets
+    go out during the pass, batched finishes and paired weight gradients stay on), losses and student / teacher parameters must
+    equal the plain trainer's BITWISE - the reducer only changes where gradients are written."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from octic_vits_amd import ssl as S, train as TR
+
+    def run(distributed):
+        torch.manual_seed(0)
+        arch = S.SSLMetaArch(lambda: _hd64_backbone(drop_path=0.4), 256, head_n_prototypes=512, head_hidden_dim=128,
+                             head_bottleneck_dim=64, local_crops_number=4).cuda()
+        for m in (arch.student["backbone"], arch.teacher["backbone"]):
+            m.patch_embed.strict_img_size = False
+        tr = S.SSLTrainer(arch, lr=1e-3, distributed=distributed, local_rank=0)
+        assert (tr._reducer is not None) == distributed and tr._ddp is None
+        images = S.synthetic_multicrop_batch(4, "cuda", seed=3, global_size=32, local_size=16, n_local=4, patch_size=4)
+        losses = []
+        for i in range(3):
+            torch.manual_seed(10 + i)
+            out = tr.step(images, teacher_temp=0.05, momentum=0.99)
+            losses.append(float(out["total"]))
+        return (losses, [p.detach().clone() for p in arch.student.parameters()],
+                [p.detach().clone() for p in arch.teacher.parameters()], tr)
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    old = TR.DDP_FLAT_SMALL_NUMEL
+    TR.DDP_FLAT_SMALL_NUMEL = 20_000
+    try:
+        lb, sb, tb, trb = run(True)
+        assert len(trb._reducer.buckets) >= 1
+    finally:
+        TR.DDP_FLAT_SMALL_NUMEL = old
+        dist.destroy_process_group()
+    la, sa, ta, _ = run(False)
+    assert la == lb, (la, lb)
+    for a, b in zip(sa + ta, sb + tb):
+        assert torch.equal(a, b)
