@@ -321,6 +321,9 @@ def main():
     if os.environ.get("OCTIC_NO_IMAGE"):             # developer A/B: classic row panels for every dense GEMM
         from octic_vits_amd import _lib as _L0
         _L0.route_override(_L0.ROUTE_DENSE_IMAGE, int(os.environ["OCTIC_NO_IMAGE"]) if os.environ["OCTIC_NO_IMAGE"] in ("2", "3") else 2)
+    if os.environ.get("OCTIC_CLS2"):                 # developer A/B: class-token rows as two launches: 1 = never, 2 = wherever legal
+        from octic_vits_amd import _lib as _L1
+        _L1.route_override(_L1.ROUTE_DENSE_CLS2, int(os.environ["OCTIC_CLS2"]))
     if args.resid_fused:
         import octic_vits_amd.functional as _OF2
         _OF2.DENSE_RESID_FUSED = True

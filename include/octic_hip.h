@@ -73,7 +73,8 @@ enum {
   OCTIC_ROUTE_ATTN_ONLINE = 7,     /* octic_attn_fwd*: 1 = persistent online-softmax forward instead of the one-shot one  */
   OCTIC_ROUTE_ATTN_BWD_PAIR = 8,   /* octic_attn_bwd*: 1 = the dq + dkv kernel pair instead of the single-pass backward   */
   OCTIC_ROUTE_DENSE_IMAGE = 9,     /* octic_dense_gemm_nt_tokens: 1 = per-image panels wherever legal, 2 = never, 3 = plain only */
-  OCTIC_ROUTE_COUNT = 10
+  OCTIC_ROUTE_DENSE_CLS2 = 10,     /* class-token rows of per-image launches as two launches (K split): 1 = never, 2 = wherever legal */
+  OCTIC_ROUTE_COUNT = 11
 };
 int octic_route_override(int knob, int value);
 

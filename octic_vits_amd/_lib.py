@@ -15,7 +15,7 @@ F32, BF16 = 0, 1
 ABI_VERSION = 20
 # knobs of octic_route_override (include/octic_hip.h)
 (ROUTE_DENSE_TILE, ROUTE_DENSE_SPLIT, ROUTE_WGRAD_SLABS, ROUTE_WGRAD_TILE, ROUTE_LINEAR_RING, ROUTE_RING_EVEN,
- ROUTE_ATTN_LEGACY, ROUTE_ATTN_ONLINE, ROUTE_ATTN_BWD_PAIR, ROUTE_DENSE_IMAGE) = range(10)
+ ROUTE_ATTN_LEGACY, ROUTE_ATTN_ONLINE, ROUTE_ATTN_BWD_PAIR, ROUTE_DENSE_IMAGE, ROUTE_DENSE_CLS2) = range(11)
 
 c_i64, c_int, c_float, c_void_p = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 

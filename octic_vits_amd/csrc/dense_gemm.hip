@@ -839,6 +839,63 @@ __global__ __launch_bounds__(1024) void dense_cls_kernel(DgArgs a, int tokens, i
   }
 }
 
+
+// Long K (>= 3840): the class-token GEMM as TWO launches - K cut over workgroups, f32 partial tiles, a second launch that sums
+// them in slice order and runs the plain epilogue.  Why: a 16 x 16 tile pulls (16 + 16) K bytes through its CU and a CU
+// sustains ~25 GB/s of first-touch loads, so at K = 5120 the single launch above is 21 us however its waves are arranged;
+// here a workgroup owns 64 rows x 64 columns x 320 of K (82 KB of operands, one batch of loads, W fragments re-used over four row
+// tiles), 320 workgroups for N = 1280, K = 5120.  A kernel boundary is the (cheap) cross-workgroup reduction: no tickets, no
+// fences.  Plain mode only (fc2, the input gradients of fc1 / qkv).
+constexpr int CLS_KSLICE = 320;
+__global__ __launch_bounds__(320) void dense_cls_part_kernel(DgArgs a, int tokens, int nrows, int rows_pad, float* part) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, kg = lane >> 4;
+  const int bw = (blockDim.x >> 6) * 16;                    // columns per workgroup: 64 or 80 (one 16-column tile per wave)
+  const int nnb = a.N / bw, nks = a.K / CLS_KSLICE;
+  const int nb = blockIdx.x % nnb, ks = (blockIdx.x / nnb) % nks, rb = blockIdx.x / (nnb * nks);
+  const int n0 = nb * bw + wid * 16;
+  const bf16* wp = a.B + (int64_t)(n0 + fr) * a.ldb + ks * CLS_KSLICE + kg * 8;
+  const bf16* xp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = rb * 64 + i * 16 + fr;
+    r = r < nrows ? r : nrows - 1;                          // rows past the batch: a valid row, dropped by the second launch
+    xp[i] = a.A + (int64_t)r * tokens * a.lda + ks * CLS_KSLICE + kg * 8;
+  }
+  constexpr int U = CLS_KSLICE / 32;                        // 10 k-steps: ONE batch of 50 loads per wave
+  bf16x8 wf[U], xf[4][U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    wf[j] = *(const bf16x8*)(wp + j * 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf[i][j] = *(const bf16x8*)(xp[i] + j * 32);
+  }
+  f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int j = 0; j < U; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i][j], acc[i], 0, 0, 0);
+  // lane (fr, kg) of row tile i: row rb * 64 + 16 i + fr, columns n0 + 4 kg .. + 3
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rb * 64 + i * 16 + fr;
+    *(f32x4*)(part + ((int64_t)ks * rows_pad + r) * a.N + n0 + 4 * kg) = acc[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_cls_sum_kernel(DgArgs a, int tokens, int nrows, int rows_pad, const float* part) {
+  const int n4 = a.N >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int r = idx / n4, n = (idx - r * n4) * 4;
+  if (r >= nrows) return;
+  const int nks = a.K / CLS_KSLICE;
+  f32x4 v = *(const f32x4*)(part + (int64_t)r * a.N + n);
+  for (int ks = 1; ks < nks; ++ks) v = v + *(const f32x4*)(part + ((int64_t)ks * rows_pad + r) * a.N + n);
+  if (a.bias) v = v + *(const f32x4*)(a.bias + n);
+  *(bf16x4*)(a.C + (int64_t)r * tokens * a.ldc + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Schedule: `full` tiles get one workgroup each; the remaining r = tiles - full tiles (the partial last round on the
 // `cus` workgroup slots) are split along K over `split` workgroups each, so the last round also fills the chip.
@@ -937,13 +994,22 @@ inline int dense_cls_waves(int K) {
 // the panels' plan + ~4 K-tile units for the class-token launch against the classic plan.
 // OCTIC_ROUTE_DENSE_IMAGE: 0 = by the model, 1 = always where legal, 2 = never, 3 = by the model for plain launches only (A/B).
 struct DgTokPlan { DgPlan p; bool image; int images; };
+#ifndef DG_CLS2_US
+#define DG_CLS2_US 15.0    // measured (rocprofv3, B = 64): part 9.0-10.4 us + sum 5.0 us at K = 3840 / 5120
+#endif
 // What the class-token launch costs, in the plan's unit (one K-tile of the 256-wide tile, ~1.54 us): measured on MI355X at
 // B = 64 (rocprofv3, round 6): 7.0 us for N = K = 1280, 11.4 (N 3840), 13.7-16.2 (N 5120), 16.2 (K 3840), 21.1 us (K 5120) -
 // bound by L2 -> CU operand traffic of 16 x 16 output tiles ((16 + 16) K bytes per 512 flops) and by its one memory round trip;
 // fitted as 7 us x (N / 1280)^0.5 x (K / 1280)^0.8, scaled by the batch.
-inline double dense_cls_cost(int B, int N, int K) {
-  const double us = 7.0 * sqrt((double)N / 1280.0) * pow((double)K / 1280.0, 0.8) * (B <= 64 ? 1.0 : (double)B / 64.0);
-  return us / 1.54;
+inline bool dense_cls_two_launches(int mode, int N, int K) {
+  const int v = route(OCTIC_ROUTE_DENSE_CLS2);              // 0 = by shape, 1 = never, 2 = wherever legal
+  const bool legal = mode == DG_PLAIN && (K % CLS_KSLICE) == 0 && (N % 64) == 0;
+  return legal && v != 1 && (v == 2 || K >= 3840);
+}
+inline double dense_cls_cost(int B, int N, int K, int mode) {
+  double us = 7.0 * sqrt((double)N / 1280.0) * pow((double)K / 1280.0, 0.8);
+  if (dense_cls_two_launches(mode, N, K)) us = DG_CLS2_US;   // (two launches, measured: see DG_CLS2_US)
+  return us * (B <= 64 ? 1.0 : (double)B / 64.0) / 1.54;
 }
 inline DgTokPlan dense_plan_tokens(int M, int N, int K, int cus, int mode, int tokens) {
   DgTokPlan t;
@@ -959,7 +1025,7 @@ inline DgTokPlan dense_plan_tokens(int M, int N, int K, int cus, int mode, int t
   // (fc1 with its GELU tails: the panels save 20 us, the class-token launch costs 14-16 - and in the step the pair measured
   // 0.13 ms per step SLOWER than leaving fc1 on classic panels (A/B/C of alternating processes, round 6): the margin keeps it out)
   const double margin = 1.0;
-  const bool pays = mode != DG_DGELU && mode != DG_DFACT && pi.cost + dense_cls_cost(B, N, K) + margin < t.p.cost;
+  const bool pays = mode != DG_DGELU && mode != DG_DFACT && pi.cost + dense_cls_cost(B, N, K, mode) + margin < t.p.cost;
   if (force == 1 || (force == 0 && pays) || (force == 3 && pays && mode == DG_PLAIN)) {
     t.p = pi;
     t.image = true;
@@ -981,7 +1047,12 @@ static int dense_cus() { return device_cus(); }
 // enough for either tile width (the plain mode may pick the 320-wide tile, the fused tails use the 256-wide one)
 int64_t octic_dense_gemm_workspace_bytes(int M, int N, int K) {
   int64_t need = 256;
-  // (the per-image panels of a 257-token batch are planned as 256 rows per image: room for either plan)
+  // (the per-image panels of a 257-token batch are planned as 256 rows per image: room for either plan, and for the f32
+  // partial tiles of the two-launch class-token path behind the ticket words)
+  if ((M % 257) == 0 && (K % CLS_KSLICE) == 0) {
+    const int64_t rows_pad = ((int64_t)(M / 257) + 63) / 64 * 64;
+    need = DG_TICKET_BYTES + (int64_t)(K / CLS_KSLICE) * rows_pad * N * 4 + 256;
+  }
   const int Ms[2] = {M, (M % 257) == 0 ? M / 257 * DG_BM : 0};
   for (int i = 0; i < 2; ++i) {
     if (Ms[i] <= 0) continue;
@@ -1079,7 +1150,18 @@ int octic_dense_gemm_nt_tokens(const void* A, const void* B, int M, int N, int K
     case DG_GELUO: dense_nt_kernel<DG_GELUO, 4><<<p.grid, 512, smem, s>>>(a); break;
     default: return OCTIC_ESHAPE;
   }
-  if (tp.image) {
+  if (tp.image && dense_cls_two_launches(mode, N, K) && workspace && p.split <= 1) {
+    // (the partial tiles live where split-K slabs would: only with a main launch that splits nothing - N = 1280 at any batch
+    // that takes per-image panels; otherwise the single launch below)
+    const int rows_pad = (tp.images + 63) / 64 * 64;
+    float* part = (float*)((char*)workspace + DG_TICKET_BYTES);
+    // 64 or 80 columns per workgroup: whichever keeps the grid within ONE workgroup per CU (a CU sustains ~25 GB/s of
+    // first-touch loads: 320 workgroups on 256 CUs took 14.1 us where 240 took 8.2)
+    const int cus = dense_cus(), per64 = (N / 64) * (K / CLS_KSLICE) * (rows_pad / 64);
+    const int nw = (per64 > cus && (N % 80) == 0 && (N / 80) * (K / CLS_KSLICE) * (rows_pad / 64) <= cus) ? 5 : 4;
+    dense_cls_part_kernel<<<(N / (16 * nw)) * (K / CLS_KSLICE) * (rows_pad / 64), 64 * nw, 0, s>>>(a, tokens, tp.images, rows_pad, part);
+    dense_cls_sum_kernel<<<(tp.images * (N / 4) + 255) / 256, 256, 0, s>>>(a, tokens, tp.images, rows_pad, part);
+  } else if (tp.image) {
     // the class-token rows: row b * tokens of A / C / C2 / H, colsum slab rows behind the panels' 2 * images
     const int grid = (N / 16) * ((tp.images + 15) / 16), cr0 = 2 * tp.images, thr = 64 * dense_cls_waves(K);
     switch (mode) {

@@ -591,10 +591,45 @@ def test_dense_nt_launch_model_takes_per_image_panels_for_vit_huge():
     proj / qkv - exactly one round of 256 workgroups) and says what it does through octic_dense_gemm_plan."""
     o = ops()
     M = 64 * 257
-    for N, K in ((1280, 1280), (1280, 3840)):
+    for N, K in ((1280, 1280), (1280, 3840), (1280, 5120)):
         tile, cs_rows, image, grid = o.dense_plan(M, N, K, 0, 257)
         assert image and tile == 320 and grid == 256, (N, K, tile, image, grid)
         assert cs_rows == 2 * 64 + 4
     assert o.dense_plan(M, 1280, 1280, 0, 0)[2] is False and o.dense_plan(M, 1280, 1280, 2, 257)[2] is False
     assert o.dense_plan(M, 5120, 1280, 5, 257)[2] is False            # measured: no shorter on per-image panels
     assert o.dense_plan(8 * 257, 1280, 1280, 0, 257)[2] is False      # one partial round either way: no extra launch
+
+
+@pytest.mark.parametrize("B,N,K", [(64, 1280, 5120), (64, 1280, 3840), (130, 1280, 640), (5, 640, 960), (64, 320, 320), (17, 1280, 1280)])
+def test_dense_nt_class_token_rows_as_two_launches(B, N, K):
+    """The long-K class-token path (K cut over workgroups into f32 partial tiles + a summing launch; 64- or 80-column
+    workgroups) forced wherever legal, on per-image panels: integer-valued operands bit-exact against torch and against the
+    single-launch class-token kernel; random operands within the bf16 output tolerance, bitwise reproducible."""
+    from octic_vits_amd import _lib
+    o = ops()
+    M = B * 257
+    g = torch.Generator(device=DEV).manual_seed(23)
+    a = torch.randint(-3, 4, (M, K), generator=g, device=DEV).to(torch.bfloat16)
+    b = torch.randint(-2, 3, (N, K), generator=g, device=DEV).to(torch.bfloat16)
+    bias = torch.randint(-4, 5, (N,), generator=g, device=DEV).float()
+    want = (a.float() @ b.float().t() + bias).to(torch.bfloat16)
+    try:
+        _force_image(1)
+        _lib.route_override(_lib.ROUTE_DENSE_CLS2, 2)
+        c2 = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        c2n = o.dense_gemm_nt(a, b, 0, tokens=257)
+        _lib.route_override(_lib.ROUTE_DENSE_CLS2, 1)
+        c1 = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        assert torch.equal(c2, want), f"two launches: {int((c2 != want).sum())} wrong elements"
+        assert torch.equal(c1, want)
+        assert torch.equal(c2n, (a.float() @ b.float().t()).to(torch.bfloat16))
+        a, b = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+        bias = rnd((N,), 3, dtype=torch.float32)
+        _lib.route_override(_lib.ROUTE_DENSE_CLS2, 2)
+        x = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        y = o.dense_gemm_nt(a, b, 0, bias=bias, tokens=257)
+        close(x, a.double() @ b.double().t() + bias.double(), 1e-2, "two launches")
+        assert torch.equal(x, y)
+    finally:
+        _lib.route_override(_lib.ROUTE_DENSE_CLS2, 0)
+        _force_image(0)

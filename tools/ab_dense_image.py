@@ -22,6 +22,8 @@ def one(fn, n=10):
 B = int(os.environ.get("B", 64))
 M = B * 257
 cases = [(1280, 1280, 0), (1280, 5120, 0), (1280, 3840, 0), (3840, 1280, 0), (5120, 1280, 4), (5120, 1280, 5), (5120, 1280, 6)]
+if os.environ.get("CLS2"):        # class-token rows as two launches (K split over workgroups): never / wherever legal
+    _lib.route_override(_lib.ROUTE_DENSE_CLS2, int(os.environ["CLS2"]))
 med = lambda x: sorted(x)[len(x) // 2]
 for (N, K, mode) in cases:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
